@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference on disk); the GPU box
+never executes this.  Usage:  python tests/golden/make_golden.py
+
+What is captured (inputs + expected outputs only -- no reference source):
+  index_tables.npz   lidx/ridx/pidx/sidx for every (L <= 40, level)    [reference: net/inside_index.py, outside_index.py]
+  diora_*.npz        DioraMLP charts, per-level hook scores, gradients  [net/diora.py]
+  cliora_*.npz       cliora.DioraMLP (eval + train with recorded dropout masks), score tensors [net/cliora.py]
+  net_*.npz          Net.forward losses + parameter grads, Trainer._step Adam updates [net/trainer.py]
+  trees in diora_*/cliora_* files from analysis/cky.py + analysis/utils.py hooks
+"""
+import os
+import sys
+import types
+import json
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, '/root/reference')
+sys.modules.setdefault('cv2', types.ModuleType('cv2'))  # trainer.py:13 (visualization only)
+
+from cliora.net import diora as ref_diora            # noqa: E402
+from cliora.net import cliora as ref_cliora          # noqa: E402
+from cliora.net import trainer as ref_trainer        # noqa: E402
+from cliora.net.utils import ImageEncoder            # noqa: E402
+from cliora.net.inside_index import get_inside_index      # noqa: E402
+from cliora.net.outside_index import get_outside_index    # noqa: E402
+from cliora.net.offset_cache import get_offset_cache      # noqa: E402
+from cliora.analysis.cky import ParsePredictor            # noqa: E402
+from cliora.analysis.utils import override_init_with_batch, override_inside_hook, get_actions, get_spans  # noqa: E402
+
+torch.use_deterministic_algorithms(True)
+torch.set_num_threads(4)
+META = dict(torch=torch.__version__, numpy=np.__version__, threads=4)
+
+
+def tree_to_str(t):
+    return str(t)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print('wrote', name, os.path.getsize(path) // 1024, 'KiB')
+
+
+def index_tables():
+    out = {}
+    for L in range(2, 41):
+        off = get_offset_cache(L)
+        out['off_%d' % L] = np.array([off[i] for i in range(L)], dtype=np.int32)
+        li, ri, pi, si = [], [], [], []
+        for level in range(1, L):
+            a, b = get_inside_index(L, level, off)
+            li.append(a.numpy()); ri.append(b.numpy())
+        for level in range(L - 2, -1, -1):
+            a, b = get_outside_index(L, level, off)
+            pi.append(a.numpy()); si.append(b.numpy())
+        out['lidx_%d' % L] = np.concatenate(li).astype(np.int16)
+        out['ridx_%d' % L] = np.concatenate(ri).astype(np.int16)
+        out['pidx_%d' % L] = np.concatenate(pi).astype(np.int16)   # levels L-2..0 concatenated
+        out['sidx_%d' % L] = np.concatenate(si).astype(np.int16)
+    save('index_tables.npz', **out)
+
+
+def seeded_params(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for p in module.parameters():
+        p.data.copy_(torch.randn(p.shape, generator=g))
+
+
+def state_np(module, prefix=''):
+    return {prefix + k.replace('.', '__'): v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def attach_hooks(net):
+    override_init_with_batch(net)
+    override_inside_hook(net)
+
+
+def run_cky(net, B, L):
+    pp = ParsePredictor(net)
+    trees = pp.parse_batch({'sentences': torch.zeros(B, L, dtype=torch.int64)})
+    spans = [get_spans(get_actions(str(t).replace(',', ''))) for t in trees]
+    return trees, spans
+
+
+def diora_case(name, D, B, L, seed, share=True, normalize='unit', full=True):
+    torch.manual_seed(seed)
+    net = ref_diora.DioraMLP(D, outside=True, normalize=normalize, compress=False, share=share)
+    seeded_params(net, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, L, D, generator=g).requires_grad_(True)
+    cot = {k: torch.randn(s, generator=g) for k, s in
+           [('inside_h', (B, L * (L + 1) // 2, D)), ('inside_s', (B, L * (L + 1) // 2, 1)),
+            ('outside_h', (B, L * (L + 1) // 2, D)), ('outside_s', (B, L * (L + 1) // 2, 1))]}
+    # pass 1: training-mode graph for gradients
+    net.train()
+    net(x, x)
+    loss = sum((getattr(net, k) * v).sum() for k, v in cot.items())
+    loss.backward()
+    grads = {'grad__' + k.replace('.', '__'): p.grad.numpy().copy() for k, p in net.named_parameters()}
+    grads['grad__x_span'] = x.grad.numpy().copy()
+    charts = {k: getattr(net, k).detach().numpy().copy() for k in
+              ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')}
+    # pass 2: hooks + CKY
+    net.eval()
+    attach_hooks(net)
+    with torch.no_grad():
+        net(x.detach(), x.detach())
+    hook = {}
+    for level in range(1, L):
+        hook['hook_s_%d' % level] = torch.stack([net.saved_scalars[level][p] for p in range(L - level)], 1).numpy()
+    trees, spans = run_cky(net, B, L)
+    meta = dict(META, D=D, B=B, L=L, seed=seed, share=share, normalize=normalize,
+                trees=[tree_to_str(t) for t in trees], spans=[[list(s) for s in sp] for sp in spans])
+    arrs = dict(meta=np.array(json.dumps(meta)))
+    if full:
+        arrs.update(state_np(net, 'param__'))
+        arrs['x_span'] = x.detach().numpy()
+        arrs.update({'cot__' + k: v.numpy() for k, v in cot.items()})
+        arrs.update(charts)
+        arrs.update(grads)
+        arrs.update(hook)
+    else:
+        # large-D case: params / inputs / cotangents are regenerated from the seed by the test
+        # (same torch build on the GPU box); store small exact slices + float64 checksums.
+        C = L * (L + 1) // 2
+        cells = np.array([0, L - 1, L, C // 2, C - 2, C - 1])
+        arrs['cells'] = cells
+        for k, v in charts.items():
+            arrs[k + '__cells'] = v[:, cells]
+            arrs[k + '__sum'] = np.array(v.astype(np.float64).sum())
+            arrs[k + '__abssum'] = np.array(np.abs(v.astype(np.float64)).sum())
+        arrs['inside_s'] = charts['inside_s']
+        arrs['outside_s'] = charts['outside_s']
+        for k, v in grads.items():
+            arrs[k + '__sum'] = np.array(v.astype(np.float64).sum())
+            arrs[k + '__abssum'] = np.array(np.abs(v.astype(np.float64)).sum())
+            arrs[k + '__head'] = v.reshape(-1)[:64].copy()
+        arrs.update(hook)
+    save(name, **arrs)
+
+
+class RecordingDropout(torch.nn.Module):
+    """Same RNG draws as nn.Dropout(p) on an equally shaped input; keeps the masks."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+        self.masks = []
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        m = torch.nn.functional.dropout(torch.ones_like(x), self.p, True)
+        self.masks.append(m.detach().clone())
+        return x * m
+
+
+def cliora_case(name, D, B, L, seed, R=36):
+    torch.manual_seed(seed)
+    net = ref_cliora.DioraMLP(D, outside=True, normalize='unit', compress=False, share=True)
+    seeded_params(net, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    C = L * (L + 1) // 2
+    x_span = torch.randn(B, L, D, generator=g).requires_grad_(True)
+    x_word = torch.randn(B, L, D, generator=g).requires_grad_(True)
+    obj_span = (0.3 * torch.randn(B, R, D, generator=g)).requires_grad_(True)
+    obj_word = (0.3 * torch.randn(B, R, D, generator=g)).requires_grad_(True)
+    arrs = dict(x_span=x_span.detach().numpy(), x_word=x_word.detach().numpy(),
+                obj_span=obj_span.detach().numpy(), obj_word=obj_word.detach().numpy())
+    arrs.update(state_np(net, 'param__'))
+    outs = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s',
+            'all_atten_score', 'vg_atten_score', 'atten_score')
+    # --- eval mode (dropout off) + hooks + CKY
+    net.eval()
+    attach_hooks(net)
+    with torch.no_grad():
+        net(x_span.detach(), x_word.detach(), obj_span.detach(), obj_word.detach())
+    for k in outs:
+        arrs['eval__' + k] = getattr(net, k).detach().numpy().copy()
+    trees, spans = run_cky(net, B, L)
+    # --- training mode with recorded masks + gradients of the two VL losses
+    net2 = ref_cliora.DioraMLP(D, outside=True, normalize='unit', compress=False, share=True)
+    net2.load_state_dict(net.state_dict())
+    net2.atten_head.dropout = RecordingDropout(0.1)
+    net2.train()
+    torch.manual_seed(seed + 2)
+    net2(x_span, x_word, obj_span, obj_word)
+    for k in outs:
+        arrs['train__' + k] = getattr(net2, k).detach().numpy().copy()
+    for i, m in enumerate(net2.atten_head.dropout.masks):
+        arrs['mask_%d' % i] = m.numpy()
+    sent = torch.zeros(B, L, dtype=torch.int64)
+    lc, _ = ref_trainer.ContrastiveLoss(0.2, 1.0)(sent, net2)
+    lv, _ = ref_trainer.VGLoss(1.0)(sent, net2.vg_atten_score)
+    cot = {k: torch.randn(getattr(net2, k).shape, generator=g) for k in ('inside_h', 'outside_h')}
+    total = lc + lv + sum((getattr(net2, k) * v).sum() for k, v in cot.items())
+    total.backward()
+    arrs['train__contrastive_loss'] = lc.detach().numpy()
+    arrs['train__vg_loss'] = lv.detach().numpy()
+    arrs.update({'cot__' + k: v.numpy() for k, v in cot.items()})
+    for k, p in net2.named_parameters():
+        arrs['grad__' + k.replace('.', '__')] = p.grad.numpy().copy()
+    for k, t in (('x_span', x_span), ('x_word', x_word), ('obj_span', obj_span), ('obj_word', obj_word)):
+        arrs['grad__' + k] = t.grad.numpy().copy()
+    meta = dict(META, D=D, B=B, L=L, R=R, seed=seed, n_masks=len(net2.atten_head.dropout.masks),
+                trees=[tree_to_str(t) for t in trees], spans=[[list(s) for s in sp] for sp in spans])
+    arrs['meta'] = np.array(json.dumps(meta))
+    save(name, **arrs)
+
+
+def net_case(name, D, B, L, V, K, seed, vl):
+    """Whole Net.forward + losses + Trainer._step (trainer.py:243-304, 450-455, 483-501)."""
+    torch.manual_seed(seed)
+    emb = torch.nn.Embedding(V, 32)
+    embed = ref_trainer.Embed(emb, input_size=32, size=D)
+    enc = ImageEncoder(input_size=48, size=D)
+    Diora = ref_cliora.DioraMLP if vl else ref_diora.DioraMLP
+    d = Diora(D, outside=True, normalize='unit', compress=False, share=True)
+    losses = [ref_trainer.ReconstructionSoftmaxLoss(emb, margin=1, k_neg=K, input_size=32, size=D)]
+    if vl:
+        emb.weight.requires_grad = False          # trainer.py:541
+        losses += [ref_trainer.VGLoss(1.0), ref_trainer.ContrastiveLoss(0.2, 1.0)]
+    net = ref_trainer.Net(embed, enc, d, obj_feats=vl, visualize=False, loss_funcs=losses)
+    seeded_params(net, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.copy_(0.05 * torch.randn(p.shape, generator=g))   # reference zero-inits these (utils.py:45-50)
+    sent = torch.randint(0, V, (B, L), generator=g)
+    neg = torch.randperm(V, generator=g)[:K]
+    obj = torch.randn(B, 36, 48, generator=g)
+    arrs = dict(sentences=sent.numpy(), neg_samples=neg.numpy(), obj_feats=obj.numpy())
+    arrs.update(state_np(net, 'param__'))
+    bm = dict(example_ids=list(range(B)), sentences=sent, image_feats=torch.zeros(B, 1), neg_samples=neg,
+              obj_feats=obj, boxes=torch.zeros(B, 36, 4), obj_cates=torch.zeros(B, 36), GT=None,
+              batch_size=B, length=L)
+    tr = ref_trainer.Trainer(net, k_neg=K, ngpus=1, cuda=False)
+    tr.init_optimizer(torch.optim.Adam, dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8))
+    net.eval()                                    # dropout off: deterministic whole-step parity
+    out = tr.run_net(bm)
+    arrs['total_loss'] = out['total_loss'].detach().numpy()
+    tot = out['total_loss'].mean(dim=0).sum()
+    tr.optimizer.zero_grad()
+    tot.backward()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            arrs['grad__' + k.replace('.', '__')] = p.grad.numpy().copy()
+    # three optimisation steps with the Trainer's own update (clip 5.0 + Adam), eval-mode dropout
+    _train = net.train
+    net.train = lambda *a, **k: _train(False)     # keep dropout off while exercising gradient_update
+    steps = []
+    for _ in range(3):
+        r = tr._step(bm, train=True)
+        steps.append(r['total_loss'])
+    net.train = _train
+    arrs['step_losses'] = np.array(steps, dtype=np.float64)
+    arrs.update(state_np(net, 'after3__'))
+    arrs['meta'] = np.array(json.dumps(dict(META, D=D, B=B, L=L, V=V, K=K, seed=seed, vl=vl, lr=2e-3)))
+    save(name, **arrs)
+
+
+if __name__ == '__main__':
+    index_tables()
+    diora_case('diora_c1.npz', D=50, B=8, L=10, seed=1234)                       # BASELINE config 1
+    diora_case('diora_noshare.npz', D=24, B=3, L=7, seed=7, share=False)
+    diora_case('diora_nonorm.npz', D=16, B=2, L=5, seed=9, normalize='none')
+    diora_case('diora_len2.npz', D=20, B=2, L=2, seed=11)
+    diora_case('diora_c2_small.npz', D=400, B=2, L=20, seed=1234, full=False)    # config 2 shape, B=2
+    cliora_case('cliora_small.npz', D=50, B=4, L=8, seed=21)                     # config 3 shape, small
+    net_case('net_diora.npz', D=40, B=4, L=6, V=97, K=10, seed=31, vl=False)
+    net_case('net_cliora.npz', D=40, B=4, L=6, V=97, K=10, seed=33, vl=True)
