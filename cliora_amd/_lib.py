@@ -1,0 +1,125 @@
+"""ctypes binding of include/cliora_chart.h (the C-ABI shared library).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, this raises.  Build it with ``python -m cliora_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libcliora_chart.so')
+
+NORM = {'none': 0, 'unit': 1}
+KCLASS = {'compose_fwd': 0, 'compose_bwd': 1, 'wgrad': 2}
+
+PARAM_FIELDS = ('leaf_w', 'leaf_b', 'in_w1', 'in_b1', 'in_w2', 'in_b2', 'in_mat',
+                'out_w1', 'out_b1', 'out_w2', 'out_b2', 'out_mat', 'root_h')
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+class ChartLibError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ChartLibError('HIP extension %s is missing: run `python -m cliora_amd.build` '
+                            '(there is no CPU fallback for the chart path)' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.cliora_plan_create.argtypes = [i32] * 6 + [C.POINTER(vp)]
+    L.cliora_plan_create.restype = i32
+    L.cliora_plan_destroy.argtypes = [vp]
+    L.cliora_plan_destroy.restype = None
+    L.cliora_plan_fwd_workspace_bytes.argtypes = [vp]
+    L.cliora_plan_fwd_workspace_bytes.restype = sz
+    L.cliora_plan_bwd_workspace_bytes.argtypes = [vp]
+    L.cliora_plan_bwd_workspace_bytes.restype = sz
+    L.cliora_plan_table.argtypes = [vp, C.c_char_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(sz)]
+    L.cliora_plan_table.restype = i32
+    L.cliora_chart_forward.argtypes = [vp, C.POINTER(Params)] + [vp] * 8 + [vp, sz, i32, vp]
+    L.cliora_chart_forward.restype = i32
+    L.cliora_chart_backward.argtypes = [vp, C.POINTER(Params)] + [vp] * 11 + [vp, sz, vp, sz, vp, vp, C.POINTER(Params), i32, vp]
+    L.cliora_chart_backward.restype = i32
+    L.cliora_inside_pair_scores.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(sz)]
+    L.cliora_inside_pair_scores.restype = i32
+    L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
+    L.cliora_cky_decode.restype = i32
+    L.cliora_prof_enable.argtypes = [i32, i32]
+    L.cliora_prof_enable.restype = i32
+    L.cliora_prof_read.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), vp]
+    L.cliora_prof_read.restype = i32
+    L.cliora_last_error.restype = C.c_char_p
+    L.cliora_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ChartLibError('%s failed (%d): %s' % (what, rc, lib().cliora_last_error().decode()))
+
+
+class Plan:
+    """Owns one cliora_plan (chart shape + device index tables)."""
+
+    def __init__(self, B, L, D, share=True, normalize='unit', R=0):
+        self.key = (B, L, D, bool(share), normalize, R)
+        self.B, self.L, self.D, self.share, self.normalize, self.R = B, L, D, bool(share), normalize, R
+        self.C = L * (L + 1) // 2
+        self.Dp = (D + 15) // 16 * 16
+        h = C.c_void_p()
+        check(lib().cliora_plan_create(B, L, D, int(bool(share)), NORM[normalize], R, C.byref(h)), 'cliora_plan_create')
+        self.handle = h
+        self.fwd_bytes = lib().cliora_plan_fwd_workspace_bytes(h)
+        self.bwd_bytes = lib().cliora_plan_bwd_workspace_bytes(h)
+
+    def table(self, name):
+        import numpy as np
+        ptr = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        check(lib().cliora_plan_table(self.handle, name.encode(), C.byref(ptr), C.byref(n)), 'cliora_plan_table')
+        if n.value == 0:
+            return np.zeros(0, dtype=np.int32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                lib().cliora_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_plans = {}
+
+
+def get_plan(B, L, D, share, normalize, R, device_index):
+    key = (B, L, D, bool(share), normalize, R, device_index)
+    pl = _plans.get(key)
+    if pl is None:
+        if len(_plans) > 64:
+            _plans.clear()
+        pl = _plans[key] = Plan(B, L, D, share, normalize, R)
+    return pl
+
+
+def prof_enable(kclass, on=True):
+    check(lib().cliora_prof_enable(KCLASS[kclass], int(on)), 'cliora_prof_enable')
+
+
+def prof_read(kclass, stream=0):
+    ms, n = C.c_double(), C.c_longlong()
+    check(lib().cliora_prof_read(KCLASS[kclass], C.byref(ms), C.byref(n), C.c_void_p(stream)), 'cliora_prof_read')
+    return ms.value, n.value

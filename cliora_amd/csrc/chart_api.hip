@@ -1,0 +1,600 @@
+// C ABI of the chart engine: plan management + forward / backward sequencing.
+// See include/cliora_chart.h for the contract and the reference lines it replaces.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cliora_chart.h"
+#include "chart_kernels.hpp"
+#include "gemm_kernels.hpp"
+#include "plan.hpp"
+
+using namespace cliora;
+
+struct cliora_plan {
+    Plan p;
+    bool uploaded = false;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPOK(expr)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CLIORA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+#define LAUNCHOK(name)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CLIORA_EHIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define OKR(expr) do { int rc_ = (expr); if (rc_ != CLIORA_OK) return rc_; } while (0)
+
+// ------------------------------------------------------------------ profiling (HIP events)
+namespace {
+struct ProfClass {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t used = 0;
+    double total_ms = 0;
+    long long launches = 0;
+};
+ProfClass g_prof[CLIORA_KCLASS_COUNT];
+std::mutex g_prof_mu;
+
+struct ProfScope {
+    ProfClass* pc = nullptr;
+    hipStream_t st;
+    hipEvent_t stop{};
+    ProfScope(int cls, hipStream_t s) : st(s) {
+        ProfClass& c = g_prof[cls];
+        if (!c.on) return;
+        if (c.used + 2 > c.ev.size()) {
+            for (int k = 0; k < 256; ++k) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c.ev.push_back(e); }
+        }
+        pc = &c;
+        hipEventRecord(c.ev[c.used], st);
+        stop = c.ev[c.used + 1];
+        c.used += 2;
+    }
+    ~ProfScope() { if (pc) hipEventRecord(stop, st); }
+};
+}  // namespace
+
+extern "C" int cliora_prof_enable(int cls, int on) {
+    if (cls < 0 || cls >= CLIORA_KCLASS_COUNT) return fail(CLIORA_EINVAL, "bad kernel class");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[cls].on = on != 0;
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_prof_read(int cls, double* total_ms, long long* launches, void* stream) {
+    if (cls < 0 || cls >= CLIORA_KCLASS_COUNT) return fail(CLIORA_EINVAL, "bad kernel class");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfClass& c = g_prof[cls];
+    HIPOK(hipStreamSynchronize((hipStream_t)stream));
+    for (size_t k = 0; k + 1 < c.used; k += 2) {
+        float ms = 0;
+        HIPOK(hipEventElapsedTime(&ms, c.ev[k], c.ev[k + 1]));
+        c.total_ms += ms;
+        c.launches += 1;
+    }
+    c.used = 0;
+    if (total_ms) *total_ms = c.total_ms;
+    if (launches) *launches = c.launches;
+    c.total_ms = 0; c.launches = 0;
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ plan
+extern "C" int cliora_plan_create(int B, int L, int D, int share, int normalize, int R, cliora_plan** out) {
+    if (!out) return fail(CLIORA_EINVAL, "out is NULL");
+    cliora_plan* pl = new (std::nothrow) cliora_plan();
+    if (!pl) return fail(CLIORA_ENOMEM, "host allocation failed");
+    const std::string e = build_plan(pl->p, B, L, D, share, normalize, R);
+    if (!e.empty()) { delete pl; return fail(CLIORA_EINVAL, e); }
+    *out = pl;
+    return CLIORA_OK;
+}
+
+extern "C" void cliora_plan_destroy(cliora_plan* plan) {
+    if (!plan) return;
+    if (plan->p.d_tables) (void)hipFree(plan->p.d_tables);
+    delete plan;
+}
+
+extern "C" size_t cliora_plan_fwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.fwd.total * sizeof(float) : 0; }
+extern "C" size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.bwd.total * sizeof(float) : 0; }
+
+extern "C" int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count) {
+    if (!plan || !name || !data || !count) return fail(CLIORA_EINVAL, "NULL argument");
+    const std::vector<int32_t>* v = find_table(plan->p, name);
+    if (!v) return fail(CLIORA_EINVAL, std::string("unknown table ") + name);
+    *data = v->data();
+    *count = v->size();
+    return CLIORA_OK;
+}
+
+static int ensure_uploaded(cliora_plan* plan, hipStream_t st) {
+    if (plan->uploaded) return CLIORA_OK;
+    std::vector<int32_t> flat = flatten_tables(plan->p);
+    HIPOK(hipMalloc((void**)&plan->p.d_tables, flat.size() * sizeof(int32_t)));
+    HIPOK(hipMemcpyAsync(plan->p.d_tables, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPOK(hipStreamSynchronize(st));   // `flat` dies at scope exit
+    plan->p.d_tables_count = flat.size();
+    plan->uploaded = true;
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ launch helpers
+static int pick_tiles(int ntiles16) {
+    for (int t : {5, 4, 2, 1}) if (ntiles16 % t == 0) return t;
+    return 1;
+}
+
+template <int CT, class AP, class EP>
+static int launch_rows_ct(hipStream_t st, const float* W, int K, int ncols, int nrows, AP ap, EP ep) {
+    const size_t lds = (size_t)CT * 16 * (K + WS_LDS_PAD) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPOK(hipFuncSetAttribute((const void*)rows_gemm_ws<CT, AP, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int ntiles = (nrows + 15) / 16;
+    const int gy = ncols / (16 * CT);
+    int gx = (ntiles + 3) / 4;
+    const int cap = std::max(1, 256 / gy);
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((rows_gemm_ws<CT, AP, EP>), dim3(gx, gy), dim3(WS_THREADS), lds, st, W, K, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ws");
+    return CLIORA_OK;
+}
+
+// out[r][j] = sum_k A(r,k) W[j][k] for j < ncols (multiple of 16), K multiple of 16
+template <class AP, class EP>
+static int launch_rows(hipStream_t st, const float* W, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const size_t budget = 150 * 1024;
+    const int nt = ncols / 16;
+    for (int ct : {5, 4, 2, 1}) {
+        if (nt % ct) continue;
+        if ((size_t)ct * 16 * (K + WS_LDS_PAD) * sizeof(float) > budget) continue;
+        switch (ct) {
+            case 5: return launch_rows_ct<5>(st, W, K, ncols, nrows, ap, ep);
+            case 4: return launch_rows_ct<4>(st, W, K, ncols, nrows, ap, ep);
+            case 2: return launch_rows_ct<2>(st, W, K, ncols, nrows, ap, ep);
+            default: return launch_rows_ct<1>(st, W, K, ncols, nrows, ap, ep);
+        }
+    }
+    return fail(CLIORA_EINVAL, "weight block does not fit LDS");
+}
+
+template <int T, class AP, class BP>
+static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats,
+                       float* out, float* colsum_out) {
+    const int blocks = (Mi / (T * 16)) * (Nj / (T * 16));
+    size_t per_slice = (size_t)Mi * Nj + (colsum_out ? Mi : 0);
+    int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 2048 / blocks));
+    nsl = std::min(nsl, (nrows + 15) / 16);
+    nsl = std::max(4, nsl / 4 * 4);
+    if ((size_t)nsl * per_slice > slab_floats) return fail(CLIORA_ENOMEM, "slab too small for the weight-gradient GEMM");
+    int rps = (nrows + nsl - 1) / nsl;
+    rps = (rps + 3) / 4 * 4;
+    float* csl = slab + (size_t)nsl * Mi * Nj;
+    if (colsum_out)
+        hipLaunchKernelGGL((tn_gemm<T, T, true, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
+    else
+        hipLaunchKernelGGL((tn_gemm<T, T, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
+    LAUNCHOK("tn_gemm");
+    const size_t n = (size_t)Mi * Nj;
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
+    LAUNCHOK("slab_reduce");
+    if (colsum_out) {
+        hipLaunchKernelGGL(slab_reduce, dim3((Mi + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Mi, colsum_out);
+        LAUNCHOK("slab_reduce(colsum)");
+    }
+    return CLIORA_OK;
+}
+
+// out[i][j] = sum_r A(r,i) B(r,j); colsum_out[i] = sum_r A(r,i) (optional)
+template <class AP, class BP>
+static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, BP bp, float* slab, size_t slab_floats,
+                     float* out, float* colsum_out) {
+    if (nrows <= 0) {
+        HIPOK(hipMemsetAsync(out, 0, (size_t)Mi * Nj * sizeof(float), st));
+        if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Mi * sizeof(float), st));
+        return CLIORA_OK;
+    }
+    switch (pick_tiles(Dp / 16)) {
+        case 5: return launch_tn_t<5>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        case 4: return launch_tn_t<4>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        case 2: return launch_tn_t<2>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        default: return launch_tn_t<1>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+    }
+}
+
+static int run_copies(hipStream_t st, const CopyTable& tab) {
+    if (tab.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(copy2d_multi, dim3(64, tab.n), dim3(256), 0, st, tab);
+    LAUNCHOK("copy2d_multi");
+    return CLIORA_OK;
+}
+
+static void add_copy(CopyTable& t, float* dst, int ldd, int drows, int dcols, const float* s0, int ld0, int rows0, int cols0,
+                     int r0, int c0, int T0, const float* s1 = nullptr, int ld1 = 0, int rows1 = 0, int cols1 = 0, int r1 = 0,
+                     int c1 = 0, int T1 = 0) {
+    CopyDesc& d = t.d[t.n++];
+    d.dst = dst; d.ldd = ldd; d.drows = drows; d.dcols = dcols;
+    d.s[0] = CopySrc{s0, ld0, rows0, cols0, r0, c0, T0};
+    d.s[1] = CopySrc{s1, ld1, rows1, cols1, r1, c1, T1};
+}
+
+static inline unsigned cells_grid(int ncells) { return (unsigned)((ncells + 3) / 4); }
+
+struct Dev {   // device views for one call
+    const int32_t *arow, *brow, *trow;
+    UseTab use[N_ROLES];
+};
+static Dev dev_views(const Plan& p) {
+    Dev d;
+    const int32_t* t = p.d_tables;
+    d.arow = t + p.dev.arow; d.brow = t + p.dev.brow; d.trow = t + p.dev.trow;
+    for (int r = 0; r < N_ROLES; ++r)
+        d.use[r] = UseTab{t + p.dev.use_off[r], t + p.dev.use_row[r], t + p.dev.use_stride[r], t + p.dev.use_partner[r]};
+    return d;
+}
+
+static LevelArgs level_args(const Plan& p, int level, bool outside_pass) {
+    LevelArgs g;
+    g.B = p.B; g.C = p.C; g.Dp = p.Dp; g.Lc = p.L - level;
+    g.N = outside_pass ? p.Nout(level) : p.Nin(level);
+    g.off = p.level_offset[level];
+    g.rowbase = (int)(outside_pass ? p.row_base_out(level) : p.row_base_in(level));
+    return g;
+}
+
+// ------------------------------------------------------------------ forward
+extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
+                                    const float* drop_mask, float* inside_h, float* inside_s, float* outside_h,
+                                    float* outside_s, float* inside_c, void* fwd_ws, size_t fwd_ws_bytes, int run_outside,
+                                    void* stream) {
+    (void)obj_span; (void)drop_mask; (void)inside_c;
+    if (!plan || !P || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws)
+        return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.R != 0) return fail(CLIORA_EINVAL, "CLIORA (R > 0) plans are not implemented in this build");
+    if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    OKR(ensure_uploaded(plan, st));
+    const Dev dv = dev_views(p);
+    float* ws = (float*)fwd_ws;
+    const FwdLayout& f = p.fwd;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, nb = p.nblk, ldpi = nb * Dp;
+    const bool padded = D != Dp;
+    float* IH = padded ? ws + f.ihp : inside_h;
+    float* OH = padded ? ws + f.ohp : outside_h;
+    float* IS = inside_s;
+    float* OS = outside_s;
+    const float* X = padded ? ws + f.xp : x_span;
+    const float* w1o = p.share ? P->in_w1 : P->out_w1;
+    if (!p.share && (!P->out_w1 || !P->out_b1 || !P->out_w2 || !P->out_b2 || !P->out_mat))
+        return fail(CLIORA_EINVAL, "share=0 needs the out_* parameters");
+
+    // ---- pack parameters into padded / concatenated / transposed layouts ----
+    {
+        CopyTable t; t.n = 0;
+        add_copy(t, ws + f.wl, Dp, Dp, Dp, P->leaf_w, D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.wlT, Dp, Dp, Dp, P->leaf_w, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.bl, Dp, 1, Dp, P->leaf_b, D, 1, D, 0, 0, 0);
+        // Wcat rows: [W1L_in ; W1R_in ; mat_in^T ; (W1L_out ; mat_out^T)]
+        add_copy(t, ws + f.wcat + 0 * (size_t)Dp * Dp, Dp, Dp, Dp, P->in_w1, 2 * D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.wcat + 1 * (size_t)Dp * Dp, Dp, Dp, Dp, P->in_w1, 2 * D, D, D, 0, D, 0);
+        add_copy(t, ws + f.wcat + 2 * (size_t)Dp * Dp, Dp, Dp, Dp, P->in_mat, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.wcatT + 0 * Dp, ldpi, Dp, Dp, P->in_w1, 2 * D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.wcatT + 1 * Dp, ldpi, Dp, Dp, P->in_w1, 2 * D, D, D, 0, D, 1);
+        add_copy(t, ws + f.wcatT + 2 * Dp, ldpi, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.bcat, Dp, 1, Dp, P->in_b1, D, 1, D, 0, 0, 0);
+        add_copy(t, ws + f.bcat + Dp, Dp, 1, 2 * Dp, nullptr, 0, 0, 0, 0, 0, 0);
+        if (!p.share) {
+            add_copy(t, ws + f.wcat + 3 * (size_t)Dp * Dp, Dp, Dp, Dp, P->out_w1, 2 * D, D, D, 0, 0, 0);
+            add_copy(t, ws + f.wcat + 4 * (size_t)Dp * Dp, Dp, Dp, Dp, P->out_mat, D, D, D, 0, 0, 1);
+            add_copy(t, ws + f.wcatT + 3 * Dp, ldpi, Dp, Dp, P->out_w1, 2 * D, D, D, 0, 0, 1);
+            add_copy(t, ws + f.wcatT + 4 * Dp, ldpi, Dp, Dp, P->out_mat, D, D, D, 0, 0, 0);
+            add_copy(t, ws + f.bcat + 3 * Dp, Dp, 1, Dp, P->out_b1, D, 1, D, 0, 0, 0);
+            add_copy(t, ws + f.bcat + 4 * Dp, Dp, 1, Dp, nullptr, 0, 0, 0, 0, 0, 0);
+            add_copy(t, ws + f.w2o, Dp, Dp, Dp, P->out_w2, D, D, D, 0, 0, 0);
+            add_copy(t, ws + f.w2oT, Dp, Dp, Dp, P->out_w2, D, D, D, 0, 0, 1);
+            add_copy(t, ws + f.b2o, Dp, 1, Dp, P->out_b2, D, 1, D, 0, 0, 0);
+        }
+        add_copy(t, ws + f.w1ro, Dp, Dp, Dp, w1o, 2 * D, D, D, 0, D, 0);
+        add_copy(t, ws + f.w1roT, Dp, Dp, Dp, w1o, 2 * D, D, D, 0, D, 1);
+        add_copy(t, ws + f.w2i, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.w2iT, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.b2i, Dp, 1, Dp, P->in_b2, D, 1, D, 0, 0, 0);
+        add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
+        if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+
+    // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
+    OKR(launch_rows(st, ws + f.wl, Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, ws + f.t, Dp, B * L, L, C, 0, Dp, p.normalize,
+                       IH, ws + f.nrmi, IS);
+    LAUNCHOK("unit_norm_rows");
+    if (L > 1)
+        OKR(launch_rows(st, ws + f.wcat, Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
+                        StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
+
+    // ---- inside pass (diora.py:295-331) ----
+    for (int level = 1; level < L; ++level) {
+        const LevelArgs g = level_args(p, level, false);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
+                           IH, IS, IS, ws + f.sp, ws + f.pp, IS);
+        LAUNCHOK("pair_scores_fwd");
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+            OKR(launch_rows(st, ws + f.w2i, Dp, Dp, nrows,
+                            ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi},
+                            StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
+        }
+        hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, IH,
+                           ws + f.nrmi);
+        LAUNCHOK("cell_aggregate_fwd");
+        if (level < L - 1)
+            OKR(launch_rows(st, ws + f.wcat, Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+                            StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
+    }
+
+    // ---- outside pass (diora.py:337-398) ----
+    if (run_outside) {
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH,
+                           ws + f.nrmo, OS);
+        LAUNCHOK("unit_norm_rows(root)");
+        if (L > 1)
+            OKR(launch_rows(st, ws + f.w1ro, Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+        for (int level = L - 2; level >= 0; --level) {
+            const LevelArgs g = level_args(p, level, true);
+            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            hipLaunchKernelGGL(pair_scores_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, dv.arow, dv.brow,
+                               ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS, ws + f.sp, ws + f.pp, OS);
+            LAUNCHOK("pair_scores_fwd(out)");
+            {
+                ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+                OKR(launch_rows(st, ws + f.w2o, Dp, Dp, nrows,
+                                ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp},
+                                StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
+            }
+            hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, OH,
+                               ws + f.nrmo);
+            LAUNCHOK("cell_aggregate_fwd(out)");
+            if (level >= 1)
+                OKR(launch_rows(st, ws + f.w1ro, Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                                StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
+        }
+    } else {
+        HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
+    }
+    if (padded) {
+        CopyTable t; t.n = 0;
+        add_copy(t, inside_h, D, B * C, D, IH, Dp, B * C, D, 0, 0, 0);
+        add_copy(t, outside_h, D, B * C, D, OH, Dp, B * C, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ backward
+extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
+                                     const float* drop_mask, const float* inside_h, const float* inside_s,
+                                     const float* outside_h, const float* outside_s, const float* d_inside_h,
+                                     const float* d_inside_s, const float* d_outside_h, const float* d_outside_s,
+                                     void* fwd_ws, size_t fwd_ws_bytes, void* bwd_ws, size_t bwd_ws_bytes, float* d_x_span,
+                                     float* d_obj_span, const cliora_params* G, int ran_outside, void* stream) {
+    (void)obj_span; (void)drop_mask; (void)d_obj_span; (void)P;
+    if (!plan || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws || !bwd_ws || !G)
+        return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.R != 0) return fail(CLIORA_EINVAL, "CLIORA (R > 0) plans are not implemented in this build");
+    if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    if (bwd_ws_bytes < p.bwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "backward workspace too small");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "backward called before forward");
+    hipStream_t st = (hipStream_t)stream;
+    const Dev dv = dev_views(p);
+    float* ws = (float*)fwd_ws;
+    float* wb = (float*)bwd_ws;
+    const FwdLayout& f = p.fwd;
+    const BwdLayout& bw = p.bwd;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, nb = p.nblk, ldpi = nb * Dp;
+    const bool padded = D != Dp;
+    const float* IH = padded ? ws + f.ihp : inside_h;
+    const float* OH = padded ? ws + f.ohp : outside_h;
+    const float* IS = inside_s;
+    const float* OS = outside_s;
+    const float* X = padded ? ws + f.xp : x_span;
+    float *VH = wb + bw.vh, *dG = wb + bw.dg, *dStot = wb + bw.dstot, *DA = wb + bw.da, *DS = wb + bw.ds;
+    float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
+    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po;
+
+    if (ran_outside) {
+        for (int level = 0; level <= L - 1; ++level) {
+            const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
+            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            hipLaunchKernelGGL(cell_gather_bwd_out, dim3(cells_grid(ncell)), dim3(256), 0, st, g, D, d_outside_h,
+                               level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
+            LAUNCHOK("cell_gather_bwd_out");
+            if (level >= 1)
+                OKR(launch_rows(st, ws + f.w1roT, Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                                StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+            if (level == L - 1) {
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(256), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+                LAUNCHOK("root_bwd");
+                break;
+            }
+            hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, Y, Sp, Pp,
+                               OS, dStot, dG, DS);
+            LAUNCHOK("cell_scores_bwd(out)");
+            {
+                ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
+                OKR(launch_rows(st, ws + f.w2oT, Dp, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
+                                ComposeBwdE{dv.arow, dv.brow, g.rowbase, PI + (size_t)p.blk_plo * Dp, ldpi, PO, Dp, DA, Dp}));
+            }
+        }
+        {
+            ProfScope ps(CLIORA_KCLASS_WGRAD, st);
+            OKR(launch_tn(st, (int)p.R_out, Dp, Dp, Dp, ComposeDzA{dv.trow, (int)p.R_in, dG, Y, Pp, Dp},
+                          ComposeXA{dv.arow, dv.brow, (int)p.R_in, PI + (size_t)p.blk_plo * Dp, ldpi, PO, Dp},
+                          wb + bw.slab, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o));
+        }
+        OKR(launch_tn(st, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+                      (float*)nullptr));
+    } else {
+        HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
+    }
+
+    for (int level = L - 1; level >= 0; --level) {
+        const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(cell_gather_bwd_in, dim3(cells_grid(ncell)), dim3(256), 0, st, g, D, d_inside_h,
+                           level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside,
+                           DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
+        LAUNCHOK("cell_gather_bwd_in");
+        if (level <= L - 2)
+            OKR(launch_rows(st, ws + f.wcatT, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                            StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (level == 0) break;
+        hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, Y, Sp, Pp, IS,
+                           dStot, dG, DS);
+        LAUNCHOK("cell_scores_bwd(in)");
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
+            OKR(launch_rows(st, ws + f.w2iT, Dp, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
+                            ComposeBwdE{dv.arow, dv.brow, g.rowbase, PI, ldpi, PI + Dp, ldpi, DA, Dp}));
+        }
+    }
+    // leaves
+    hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IH, ws + f.nrmi, p.normalize, ws + f.t, dU);
+    LAUNCHOK("leaf_bwd_pre");
+    if (d_x_span)
+        OKR(launch_rows(st, ws + f.wlT, Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+    {
+        ProfScope ps(CLIORA_KCLASS_WGRAD, st);
+        OKR(launch_tn(st, (int)p.R_in, Dp, Dp, Dp, ComposeDzA{dv.trow, 0, dG, Y, Pp, Dp},
+                      ComposeXA{dv.arow, dv.brow, 0, PI, ldpi, PI + Dp, ldpi}, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+    }
+    OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat,
+                  wb + bw.gbcat));
+    OKR(launch_tn(st, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
+
+    // ---- scatter packed gradients back to the reference parameter shapes ----
+    {
+        CopyTable t; t.n = 0;
+        const size_t DD = (size_t)Dp * Dp;
+        if (G->leaf_w) add_copy(t, G->leaf_w, D, D, D, wb + bw.gwl, Dp, D, D, 0, 0, 0);
+        if (G->leaf_b) add_copy(t, G->leaf_b, D, 1, D, wb + bw.gbl, Dp, 1, D, 0, 0, 0);
+        if (G->root_h) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
+        if (p.share) {
+            if (G->in_w1) {
+                add_copy(t, G->in_w1, 2 * D, D, D, wb + bw.gwcat, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->in_w1 + D, 2 * D, D, D, wb + bw.gwcat + DD, Dp, D, D, 0, 0, 0, wb + bw.gw1ro, Dp, D, D, 0, 0, 0);
+            }
+            if (G->in_b1) add_copy(t, G->in_b1, D, 1, D, wb + bw.gbcat, Dp, 1, D, 0, 0, 0);
+            if (G->in_mat) add_copy(t, G->in_mat, D, D, D, wb + bw.gwcat + 2 * DD, Dp, D, D, 0, 0, 1);
+            if (G->in_w2) add_copy(t, G->in_w2, D, D, D, wb + bw.gw2i, Dp, D, D, 0, 0, 0, wb + bw.gw2o, Dp, D, D, 0, 0, 0);
+            if (G->in_b2) add_copy(t, G->in_b2, D, 1, D, wb + bw.gb2i, Dp, 1, D, 0, 0, 0, wb + bw.gb2o, Dp, 1, D, 0, 0, 0);
+        } else {
+            if (G->in_w1) {
+                add_copy(t, G->in_w1, 2 * D, D, D, wb + bw.gwcat, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->in_w1 + D, 2 * D, D, D, wb + bw.gwcat + DD, Dp, D, D, 0, 0, 0);
+            }
+            if (G->in_b1) add_copy(t, G->in_b1, D, 1, D, wb + bw.gbcat, Dp, 1, D, 0, 0, 0);
+            if (G->in_mat) add_copy(t, G->in_mat, D, D, D, wb + bw.gwcat + 2 * DD, Dp, D, D, 0, 0, 1);
+            if (G->in_w2) add_copy(t, G->in_w2, D, D, D, wb + bw.gw2i, Dp, D, D, 0, 0, 0);
+            if (G->in_b2) add_copy(t, G->in_b2, D, 1, D, wb + bw.gb2i, Dp, 1, D, 0, 0, 0);
+            if (G->out_w1) {
+                add_copy(t, G->out_w1, 2 * D, D, D, wb + bw.gwcat + 3 * DD, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->out_w1 + D, 2 * D, D, D, wb + bw.gw1ro, Dp, D, D, 0, 0, 0);
+            }
+            if (G->out_b1) add_copy(t, G->out_b1, D, 1, D, wb + bw.gbcat + 3 * Dp, Dp, 1, D, 0, 0, 0);
+            if (G->out_mat) add_copy(t, G->out_mat, D, D, D, wb + bw.gwcat + 4 * DD, Dp, D, D, 0, 0, 1);
+            if (G->out_w2) add_copy(t, G->out_w2, D, D, D, wb + bw.gw2o, Dp, D, D, 0, 0, 0);
+            if (G->out_b2) add_copy(t, G->out_b2, D, 1, D, wb + bw.gb2o, Dp, 1, D, 0, 0, 0);
+        }
+        OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ hooks / CKY
+extern "C" int cliora_inside_pair_scores(const cliora_plan* plan, void* fwd_ws, int level, const float** scores, size_t* count) {
+    if (!plan || !fwd_ws || !scores || !count) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (level < 1 || level >= p.L) return fail(CLIORA_EINVAL, "level out of range");
+    *scores = (const float*)fwd_ws + p.fwd.sp + p.row_base_in(level);
+    *count = (size_t)p.B * (p.L - level) * level;
+    return CLIORA_OK;
+}
+
+// One wavefront per sentence.  val[] (chart of best scores) lives in LDS; leaves start at 1
+// (analysis/cky.py:24-25, 39).  Candidate = (val_l + val_r) + (s_n - max_n s) in fp32, in that
+// order (cky.py:83, utils.py:89-90); argmax keeps the first maximum (cky.py:86).
+__global__ __launch_bounds__(64) void cky_kernel(int L, int C, const int32_t* __restrict__ level_off_tab_a, const int32_t* __restrict__ pair_a,
+                                                 const int32_t* __restrict__ pair_b, const int32_t* __restrict__ lvl_base, int B,
+                                                 const float* __restrict__ Sp, int32_t* __restrict__ split) {
+    extern __shared__ float val[];
+    (void)level_off_tab_a;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int c = lane; c < C; c += 64) val[c] = 1.f;
+    for (int c = lane; c < L; c += 64) split[(size_t)b * C + c] = -1;
+    __syncthreads();
+    int off = L;   // cell id of (level 1, pos 0)
+    for (int level = 1; level < L; ++level) {
+        const int Lc = L - level, N = level;
+        for (int pos = 0; pos < Lc; ++pos) {
+            const int loc = lvl_base[level] + pos * N;
+            const size_t row0 = (size_t)B * lvl_base[level] + ((size_t)b * Lc + pos) * N;
+            const bool an = lane < N;
+            const float s = an ? Sp[row0 + lane] : -INFINITY;
+            const float smax = wave_max(s);
+            float cand = -INFINITY;
+            if (an) cand = (val[pair_a[loc + lane]] + val[pair_b[loc + lane]]) + (s - smax);
+            float best = cand; int bi = an ? lane : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            __syncthreads();
+            if (lane == 0) { val[off + pos] = best; split[(size_t)b * C + off + pos] = bi; }
+            __syncthreads();
+        }
+        off += Lc;
+    }
+}
+
+extern "C" int cliora_cky_decode(cliora_plan* plan, void* fwd_ws, int32_t* split_out, void* stream) {
+    if (!plan || !fwd_ws || !split_out) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "cky called before forward");
+    Plan& p = plan->p;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cky_kernel, dim3(p.B), dim3(64), p.C * sizeof(float), st, p.L, p.C, (const int32_t*)nullptr,
+                       p.d_tables + p.dev.pair_a_in, p.d_tables + p.dev.pair_b_in, p.d_tables + p.dev.lvl_base_in, p.B,
+                       (const float*)fwd_ws + p.fwd.sp, split_out);
+    LAUNCHOK("cky_kernel");
+    return CLIORA_OK;
+}
+
+extern "C" const char* cliora_last_error(void) { return g_err.c_str(); }
+extern "C" const char* cliora_version(void) { return "cliora_amd 0.1 (gfx950)"; }

@@ -1,0 +1,462 @@
+// Chart-level kernels for the DIORA inside-outside recursion (gfx950).
+//
+// The compose MLP of the reference (cliora/net/diora.py:65-72)
+//     h = relu(W2 relu(W1 [a;b] + b1) + b2)
+// is evaluated in factored form: every chart CELL is projected once
+//     PL = W1[:, :D] h + b1,   PR = W1[:, D:] h,   QL = mat^T h
+// and every span PAIR then costs one add+ReLU, one D x D layer (MFMA) and one D-dot
+// for the bilinear score a^T mat b = QL(a) . b  (diora.py:89-97, 125-134).
+//
+// Memory-bound kernels here give one wavefront to one chart cell; rows are read
+// with 16-byte vector loads (Dp is a multiple of 16 floats, pad columns are zero).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_kernels.hpp"
+
+namespace cliora {
+
+constexpr float UNIT_EPS = 1e-8f;   // cliora/net/utils.py:10
+
+struct LevelArgs {
+    int B, C, Dp, Lc, N, off;   // target cells of this level: chart row b*C + off + p, p < Lc; N splits each
+    int rowbase;                // first global pair row of the level; row = rowbase + (b*Lc + p)*N + n
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 c) {
+    return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// ---------------------------------------------------------------------------------
+// Generic padded 2-D copy / transpose / sum, driven by a descriptor table:
+//   dst[r][c] = sum_s src_s[(r0_s + (T_s ? c : r))][c0_s + (T_s ? r : c)]   (0 outside the source)
+// Used to pack parameters into the padded/concatenated layouts, to pad inputs,
+// un-pad outputs, and to scatter packed gradients back to the reference shapes.
+// ---------------------------------------------------------------------------------
+struct CopySrc { const float* p; int ld, rows, cols, r0, c0, T; };
+struct CopyDesc { float* dst; int ldd, drows, dcols; CopySrc s[2]; };
+constexpr int MAX_COPY = 32;
+struct CopyTable { CopyDesc d[MAX_COPY]; int n; };
+
+__global__ void copy2d_multi(CopyTable tab) {
+    const CopyDesc& d = tab.d[blockIdx.y];
+    const long long total = (long long)d.drows * d.dcols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / d.dcols), c = (int)(e - (long long)r * d.dcols);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const CopySrc& s = d.s[k];
+            if (s.p) {
+                const int sr = s.T ? c : r, sc = s.T ? r : c;
+                if (sr < s.rows && sc < s.cols) v += s.p[(size_t)(s.r0 + sr) * s.ld + s.c0 + sc];
+            }
+        }
+        d.dst[(size_t)r * d.ldd + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// dst[b*C + off + p] = src_row / max(||src_row||, eps)   (utils.py:11-14)
+// src row = (b*rows_per_b + p) * src_ld (src_ld = 0 broadcasts one row: the root vector, diora.py:337-356)
+// also writes the raw norm and zeroes the cell's score.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unit_norm_rows(const float* __restrict__ src, int src_ld, int nrows, int rows_per_b,
+                                                      int C, int off, int Dp, int normalize,
+                                                      float* __restrict__ H, float* __restrict__ nrm, float* __restrict__ S) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int b = r / rows_per_b, p = r - b * rows_per_b;
+    const size_t crow = (size_t)b * C + off + p;
+    const float* s = src + (size_t)r * src_ld;
+    const int nv = Dp >> 2;
+    float4 v0 = f4zero(), v1 = f4zero();
+    if (lane < nv) v0 = ld4(s + 4 * lane);
+    if (lane + 64 < nv) v1 = ld4(s + 4 * (lane + 64));
+    const float nr = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
+    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+    float* h = H + crow * Dp;
+    if (lane < nv) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
+    if (lane + 64 < nv) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
+    if (lane == 0) { nrm[crow] = nr; S[crow] = 0.f; }
+}
+
+// ---------------------------------------------------------------------------------
+// Per-split scores and their softmax for one level (diora.py:125-134 / 177-185):
+//   s_n = QL(a_n) . H(b_n) + S(a_n) + S(b_n);  p = softmax_n(s);  S(target) = sum_n p_n s_n
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+                                                       const float* __restrict__ QA, int ldA, const float* __restrict__ HB,
+                                                       const float* SA, const float* SB,
+                                                       float* __restrict__ Sp, float* __restrict__ Pp, float* Sout) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int row0 = g.rowbase + t * g.N;
+    const int nv = g.Dp >> 2;
+    float my_s = -INFINITY;
+    for (int n = 0; n < g.N; ++n) {
+        const int ar = arow[row0 + n], br = brow[row0 + n];
+        const float* qa = QA + (size_t)ar * ldA;
+        const float* hb = HB + (size_t)br * g.Dp;
+        float d = 0.f;
+        if (lane < nv) d = f4dot(ld4(qa + 4 * lane), ld4(hb + 4 * lane));
+        if (lane + 64 < nv) d += f4dot(ld4(qa + 4 * (lane + 64)), ld4(hb + 4 * (lane + 64)));
+        d = wave_sum(d);
+        const float s = d + SA[ar] + SB[br];
+        if (lane == n) my_s = s;
+    }
+    const float m = wave_max(my_s);
+    const float e = lane < g.N ? expf(my_s - m) : 0.f;
+    const float pn = e / wave_sum(e);
+    if (lane < g.N) { Sp[row0 + lane] = my_s; Pp[row0 + lane] = pn; }
+    const float st = wave_sum(lane < g.N ? pn * my_s : 0.f);
+    if (lane == 0) Sout[(size_t)b * g.C + g.off + p] = st;
+}
+
+// ---------------------------------------------------------------------------------
+// Softmax-weighted sum of the per-split compose outputs + unit norm (diora.py:137-149):
+//   g = sum_n p_n y_n;  H(target) = g / max(||g||, eps)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ Pp,
+                                                          int normalize, float* __restrict__ H, float* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int row0 = g.rowbase + t * g.N;
+    const int nv = g.Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    float4 v0 = f4zero(), v1 = f4zero();
+    for (int n = 0; n < g.N; ++n) {
+        const float pn = Pp[row0 + n];
+        const float* y = Y + (size_t)(row0 + n) * g.Dp;
+        if (a0) v0 = f4fma(pn, ld4(y + 4 * lane), v0);
+        if (a1) v1 = f4fma(pn, ld4(y + 4 * (lane + 64)), v1);
+    }
+    const float nr = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
+    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    float* h = H + crow * g.Dp;
+    if (a0) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
+    if (a1) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
+    if (lane == 0) nrm[crow] = nr;
+}
+
+// ---------------------------------------------------------------------------------
+// Backward, step 1 for the cells of one level: gather every use of the cell.
+//   inside cell c (as left child a / right child b in the inside pass, as sibling in the outside pass):
+//     dPL  = sum_{a-uses} DA[row]            dPR = sum_{b-uses} DA[row]
+//     dQL  = sum_{a-uses} ds[row] * H(partner)
+//     vH   = dH_ext + sum_{b-uses} ds[row] * QL(partner)       (then += dP . Wcat by the GEMM that follows)
+//     vS   = dS_ext + sum_{all uses} ds[row]
+// ---------------------------------------------------------------------------------
+struct UseTab { const int32_t *off, *row, *stride, *partner; };
+
+__device__ __forceinline__ float4 ld_ext(const float* base, int D, int col) {
+    // cotangent rows keep the caller's stride D (may be unaligned): element loads with a bound
+    float4 v = f4zero();
+    if (col + 0 < D) v.x = base[col + 0];
+    if (col + 1 < D) v.y = base[col + 1];
+    if (col + 2 < D) v.z = base[col + 2];
+    if (col + 3 < D) v.w = base[col + 3];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
+                                                          UseTab ina, UseTab inb, UseTab outa, int with_outside,
+                                                          const float* __restrict__ DA, const float* __restrict__ DS,
+                                                          const float* __restrict__ PI, int ldpi, int share,
+                                                          const float* __restrict__ IH, const float* __restrict__ OH,
+                                                          float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ dStot) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int c = g.off + p;
+    const size_t crow = (size_t)b * g.C + c;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const int bC = b * g.C;
+    float vS = dS_ext ? dS_ext[crow] : 0.f;
+    for (int v = lane; v < ((nv + 63) & ~63); v += 64) {
+        const bool act = v < nv;
+        const int col = 4 * v;
+        float4 vh = (dH_ext && act) ? ld_ext(dH_ext + crow * D, D, col) : f4zero();
+        float4 dPL = f4zero(), dPR = f4zero(), dQL = f4zero(), dPLo = f4zero(), dQLo = f4zero();
+        for (int u = inb.off[c]; u < inb.off[c + 1]; ++u) {
+            const size_t r = (size_t)inb.row[u] + (size_t)b * inb.stride[u];
+            const float ds = DS[r];
+            if (v == lane) vS += ds;
+            if (act) {
+                vh = f4fma(ds, ld4(PI + (size_t)(bC + inb.partner[u]) * ldpi + 2 * Dp + col), vh);
+                dPR = f4add(dPR, ld4(DA + r * Dp + col));
+            }
+        }
+        for (int u = ina.off[c]; u < ina.off[c + 1]; ++u) {
+            const size_t r = (size_t)ina.row[u] + (size_t)b * ina.stride[u];
+            const float ds = DS[r];
+            if (v == lane) vS += ds;
+            if (act) {
+                dPL = f4add(dPL, ld4(DA + r * Dp + col));
+                dQL = f4fma(ds, ld4(IH + (size_t)(bC + ina.partner[u]) * Dp + col), dQL);
+            }
+        }
+        if (with_outside)
+            for (int u = outa.off[c]; u < outa.off[c + 1]; ++u) {
+                const size_t r = (size_t)outa.row[u] + (size_t)b * outa.stride[u];
+                const float ds = DS[r];
+                if (v == lane) vS += ds;
+                if (act) {
+                    dPLo = f4add(dPLo, ld4(DA + r * Dp + col));
+                    dQLo = f4fma(ds, ld4(OH + (size_t)(bC + outa.partner[u]) * Dp + col), dQLo);
+                }
+            }
+        if (act) {
+            float* o = dPI + crow * ldpi + col;
+            if (share) {
+                st4(o, f4add(dPL, dPLo)); st4(o + Dp, dPR); st4(o + 2 * Dp, f4add(dQL, dQLo));
+            } else {
+                st4(o, dPL); st4(o + Dp, dPR); st4(o + 2 * Dp, dQL); st4(o + 3 * Dp, dPLo); st4(o + 4 * Dp, dQLo);
+            }
+            st4(VH + crow * Dp + col, vh);
+        }
+    }
+    if (lane == 0) dStot[crow] = vS;
+}
+
+//   outside cell c (as parent in the outside pass):
+//     dPRo = sum DA[row];  vH = dH_ext + sum ds[row] * QLo(sibling);  vS = dS_ext + sum ds[row]
+__global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
+                                                           UseTab outb, const float* __restrict__ DA, const float* __restrict__ DS,
+                                                           const float* __restrict__ PI, int ldpi, int blk_qlo,
+                                                           float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ dStot) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int c = g.off + p;
+    const size_t crow = (size_t)b * g.C + c;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const int bC = b * g.C;
+    float vS = dS_ext ? dS_ext[crow] : 0.f;
+    for (int v = lane; v < ((nv + 63) & ~63); v += 64) {
+        const bool act = v < nv;
+        const int col = 4 * v;
+        float4 vh = (dH_ext && act) ? ld_ext(dH_ext + crow * D, D, col) : f4zero();
+        float4 dPR = f4zero();
+        for (int u = outb.off[c]; u < outb.off[c + 1]; ++u) {
+            const size_t r = (size_t)outb.row[u] + (size_t)b * outb.stride[u];
+            const float ds = DS[r];
+            if (v == lane) vS += ds;
+            if (act) {
+                vh = f4fma(ds, ld4(PI + (size_t)(bC + outb.partner[u]) * ldpi + blk_qlo * Dp + col), vh);
+                dPR = f4add(dPR, ld4(DA + r * Dp + col));
+            }
+        }
+        if (act) {
+            st4(dPO + crow * Dp + col, dPR);
+            st4(VH + crow * Dp + col, vh);
+        }
+    }
+    if (lane == 0) dStot[crow] = vS;
+}
+
+// unit-norm backward for one row held as two float4 per lane: H = g / max(||g||, eps)
+__device__ __forceinline__ void unit_norm_bwd(float4& v0, float4& v1, float4 h0, float4 h1, float nr, int normalize) {
+    if (!normalize) return;
+    if (nr > UNIT_EPS) {
+        const float dot = wave_sum(f4dot(v0, h0) + f4dot(v1, h1));
+        const float inv = 1.f / nr;
+        v0 = make_float4((v0.x - h0.x * dot) * inv, (v0.y - h0.y * dot) * inv, (v0.z - h0.z * dot) * inv, (v0.w - h0.w * dot) * inv);
+        v1 = make_float4((v1.x - h1.x * dot) * inv, (v1.y - h1.y * dot) * inv, (v1.z - h1.z * dot) * inv, (v1.w - h1.w * dot) * inv);
+    } else {
+        const float inv = 1.f / UNIT_EPS;   // clamp(min=eps) passes no gradient to the norm
+        v0 = make_float4(v0.x * inv, v0.y * inv, v0.z * inv, v0.w * inv);
+        v1 = make_float4(v1.x * inv, v1.y * inv, v1.z * inv, v1.w * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Backward, step 2 for the target cells of one level: unit-norm backward, then the
+// softmax / score backward:   dp_n = dG . y_n
+//   ds_n = p_n [ (dp_n - sum_m p_m dp_m) + dS_tot (1 + s_n - S) ]
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ H,
+                                                       const float* __restrict__ nrm, int normalize,
+                                                       const float* __restrict__ Y, const float* __restrict__ Sp, const float* __restrict__ Pp,
+                                                       const float* __restrict__ Schart, const float* __restrict__ dStot,
+                                                       float* __restrict__ dG, float* __restrict__ DS) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
+    if (a0) { v0 = ld4(VH + crow * Dp + 4 * lane); h0 = ld4(H + crow * Dp + 4 * lane); }
+    if (a1) { v1 = ld4(VH + crow * Dp + 4 * (lane + 64)); h1 = ld4(H + crow * Dp + 4 * (lane + 64)); }
+    unit_norm_bwd(v0, v1, h0, h1, nrm[crow], normalize);
+    if (a0) st4(dG + crow * Dp + 4 * lane, v0);
+    if (a1) st4(dG + crow * Dp + 4 * (lane + 64), v1);
+    if (g.N == 0) return;
+    const int row0 = g.rowbase + t * g.N;
+    float dp = 0.f;
+    for (int n = 0; n < g.N; ++n) {
+        const float* y = Y + (size_t)(row0 + n) * Dp;
+        float d = 0.f;
+        if (a0) d = f4dot(v0, ld4(y + 4 * lane));
+        if (a1) d += f4dot(v1, ld4(y + 4 * (lane + 64)));
+        d = wave_sum(d);
+        if (lane == n) dp = d;
+    }
+    const bool an = lane < g.N;
+    const float pn = an ? Pp[row0 + lane] : 0.f;
+    const float sn = an ? Sp[row0 + lane] : 0.f;
+    const float mean = wave_sum(pn * dp);
+    const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + sn - Schart[crow]));
+    if (an) DS[row0 + lane] = ds;
+}
+
+// leaves: H = unit(T), T = tanh(U)  (diora.py:58-63, 283-292):  dU = normbwd(vH) * (1 - T^2)
+__global__ __launch_bounds__(256) void leaf_bwd_pre(int B, int L, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
+                                                    const float* __restrict__ nrm, int normalize, const float* __restrict__ T,
+                                                    float* __restrict__ dU) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * L) return;
+    const int b = r / L, p = r - b * L;
+    const size_t crow = (size_t)b * C + p;
+    const int nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
+    if (a0) { v0 = ld4(VH + crow * Dp + 4 * lane); h0 = ld4(H + crow * Dp + 4 * lane); }
+    if (a1) { v1 = ld4(VH + crow * Dp + 4 * (lane + 64)); h1 = ld4(H + crow * Dp + 4 * (lane + 64)); }
+    unit_norm_bwd(v0, v1, h0, h1, nrm[crow], normalize);
+    if (a0) {
+        const float4 t = ld4(T + (size_t)r * Dp + 4 * lane);
+        st4(dU + (size_t)r * Dp + 4 * lane, make_float4(v0.x * (1.f - t.x * t.x), v0.y * (1.f - t.y * t.y), v0.z * (1.f - t.z * t.z), v0.w * (1.f - t.w * t.w)));
+    }
+    if (a1) {
+        const float4 t = ld4(T + (size_t)r * Dp + 4 * (lane + 64));
+        st4(dU + (size_t)r * Dp + 4 * (lane + 64), make_float4(v1.x * (1.f - t.x * t.x), v1.y * (1.f - t.y * t.y), v1.z * (1.f - t.z * t.z), v1.w * (1.f - t.w * t.w)));
+    }
+}
+
+// outside root: OH[root] = unit(root_vector) broadcast over the batch (diora.py:337-356);
+// d root_vector = sum_b normbwd(vH[b, root]).  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void root_bwd(int B, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
+                                                const float* __restrict__ nrm, int normalize, float* __restrict__ groot) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float acc0 = 0.f, acc1 = 0.f;          // columns tid and tid + 256
+    for (int b = 0; b < B; ++b) {
+        const size_t crow = (size_t)b * C + C - 1;
+        const float v0 = tid < Dp ? VH[crow * Dp + tid] : 0.f, v1 = tid + 256 < Dp ? VH[crow * Dp + tid + 256] : 0.f;
+        const float h0 = tid < Dp ? H[crow * Dp + tid] : 0.f, h1 = tid + 256 < Dp ? H[crow * Dp + tid + 256] : 0.f;
+        if (!normalize) { acc0 += v0; acc1 += v1; continue; }
+        const float nr = nrm[crow];
+        if (nr > UNIT_EPS) {
+            red[tid] = v0 * h0 + v1 * h1;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+            const float dot = red[0];
+            __syncthreads();
+            acc0 += (v0 - h0 * dot) / nr; acc1 += (v1 - h1 * dot) / nr;
+        } else {
+            acc0 += v0 / UNIT_EPS; acc1 += v1 / UNIT_EPS;
+        }
+    }
+    if (tid < Dp) groot[tid] = acc0;
+    if (tid + 256 < Dp) groot[tid + 256] = acc1;
+}
+
+// ---------------------------------------------------------------------------------
+// Functors for the MFMA kernels
+// ---------------------------------------------------------------------------------
+// A rows = plain rows of a matrix
+struct PlainRowsA {
+    const float* p; int ld;
+    struct Ctx { const float* r; };
+    __device__ Ctx row(int r) const { return Ctx{p + (size_t)r * ld}; }
+    __device__ float4 load(const Ctx& c, int k) const { return ld4(c.r + k); }
+    __device__ float val(const Ctx& c, int col) const { return c.r[col]; }
+};
+// A rows = the cells of one chart level, all sentences: row r = b*Lc + p -> chart row b*C + off + p
+struct LevelRowsA {
+    const float* p; int ld, C, off, Lc;
+    struct Ctx { const float* r; };
+    __device__ Ctx row(int r) const { const int b = r / Lc; return Ctx{p + ((size_t)b * C + off + (r - b * Lc)) * ld}; }
+    __device__ float4 load(const Ctx& c, int k) const { return ld4(c.r + k); }
+};
+// compose layer 1, factored: x = relu(PL(a) + PR(b))           (diora.py:65-68 first Linear + ReLU)
+struct ComposeXA {
+    const int32_t *arow, *brow; int rowbase;
+    const float* A; int ldA; const float* Bm; int ldB;
+    struct Ctx { const float *pa, *pb; };
+    __device__ Ctx row(int r) const { return Ctx{A + (size_t)arow[rowbase + r] * ldA, Bm + (size_t)brow[rowbase + r] * ldB}; }
+    __device__ float4 load(const Ctx& c, int k) const {
+        const float4 u = ld4(c.pa + k), v = ld4(c.pb + k);
+        return make_float4(fmaxf(u.x + v.x, 0.f), fmaxf(u.y + v.y, 0.f), fmaxf(u.z + v.z, 0.f), fmaxf(u.w + v.w, 0.f));
+    }
+    __device__ float val(const Ctx& c, int col) const { return fmaxf(c.pa[col] + c.pb[col], 0.f); }
+};
+// dz = p_n * dG(target) masked by the second ReLU (y > 0)
+struct ComposeDzA {
+    const int32_t* trow; int rowbase;
+    const float *dG, *Y, *Pp; int Dp;
+    struct Ctx { const float *g, *y; float pn; };
+    __device__ Ctx row(int r) const {
+        const size_t gr = (size_t)rowbase + r;
+        return Ctx{dG + (size_t)trow[gr] * Dp, Y + gr * Dp, Pp[gr]};
+    }
+    __device__ float4 load(const Ctx& c, int k) const {
+        const float4 g = ld4(c.g + k), y = ld4(c.y + k);
+        return make_float4(y.x > 0.f ? c.pn * g.x : 0.f, y.y > 0.f ? c.pn * g.y : 0.f, y.z > 0.f ? c.pn * g.z : 0.f, y.w > 0.f ? c.pn * g.w : 0.f);
+    }
+    __device__ float val(const Ctx& c, int col) const { return c.y[col] > 0.f ? c.pn * c.g[col] : 0.f; }
+};
+
+// epilogues
+struct StoreRowsE {            // out[r*ld + col] = act(v + bias[col]); ACT 0 none, 1 tanh, 2 relu; cols >= ncols skipped
+    float* out; int ld; const float* bias; int act; int ncols;
+    struct RCtx { float* o; };
+    __device__ RCtx row(int r) const { return RCtx{out + (size_t)r * ld}; }
+    __device__ void store(const RCtx& rc, int col, float v) const {
+        if (col >= ncols) return;
+        if (bias) v += bias[col];
+        if (act == 1) v = tanhf(v); else if (act == 2) v = fmaxf(v, 0.f);
+        rc.o[col] = v;
+    }
+};
+struct StoreLevelE {           // level row r -> chart row; out[crow*ld + col] = v + bias[col]   (or += when accumulate)
+    float* out; int ld, C, off, Lc; const float* bias; int accumulate;
+    struct RCtx { float* o; };
+    __device__ RCtx row(int r) const { const int b = r / Lc; return RCtx{out + ((size_t)b * C + off + (r - b * Lc)) * ld}; }
+    __device__ void store(const RCtx& rc, int col, float v) const {
+        if (bias) v += bias[col];
+        if (accumulate) v += rc.o[col];
+        rc.o[col] = v;
+    }
+};
+struct ComposeBwdE {           // DA[row][col] = (x > 0) ? v : 0 with x = PL(a) + PR(b)      (first ReLU backward)
+    const int32_t *arow, *brow; int rowbase;
+    const float* A; int ldA; const float* Bm; int ldB;
+    float* DA; int Dp;
+    struct RCtx { const float *pa, *pb; float* o; };
+    __device__ RCtx row(int r) const {
+        const size_t gr = (size_t)rowbase + r;
+        return RCtx{A + (size_t)arow[gr] * ldA, Bm + (size_t)brow[gr] * ldB, DA + gr * Dp};
+    }
+    __device__ void store(const RCtx& rc, int col, float v) const { rc.o[col] = (rc.pa[col] + rc.pb[col] > 0.f) ? v : 0.f; }
+};
+
+}  // namespace cliora

@@ -1,0 +1,217 @@
+#include "plan.hpp"
+
+#include <algorithm>
+
+namespace cliora {
+
+static inline int ncells(int L) { return L * (L + 1) / 2; }
+
+static size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
+
+std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R) {
+    if (B < 1 || L < 1 || D < 1) return "B, L, D must be positive";
+    if (D > 512) return "D > 512 is not supported by the weight-stationary kernels";
+    if (L > 64) return "L > 64 is not supported (one split per lane in the score kernels)";
+    if (R < 0 || R > 64) return "R (image regions) must be in [0, 64]";
+    if (normalize != 0 && normalize != 1) return "normalize must be 0 (none) or 1 (unit)";
+    p.B = B; p.L = L; p.D = D; p.Dp = (D + 15) / 16 * 16; p.C = ncells(L);
+    p.share = share ? 1 : 0; p.normalize = normalize; p.R = R;
+    p.nblk = p.share ? 3 : 5;
+    p.blk_plo = p.share ? 0 : 3;
+    p.blk_qlo = p.share ? 2 : 4;
+    p.P_in = (L - 1) * L * (L + 1) / 6;
+    p.P_out = (L - 1) * L * (L + 1) / 3;
+    p.R_in = (long long)B * p.P_in;
+    p.R_out = (long long)B * p.P_out;
+    if (p.R_in + p.R_out > 0x7fffffffLL / 2) return "batch too large for 32-bit pair rows";
+
+    const int C = p.C;
+    p.level_offset.resize(L);
+    for (int lv = 0; lv < L; ++lv) p.level_offset[lv] = C - ncells(L - lv);
+    auto cell = [&](int level, int pos) { return p.level_offset[level] + pos; };
+
+    // ---- per-level pair tables -------------------------------------------------
+    p.lvl_base_in.assign(L, 0);
+    p.lvl_base_out.assign(L, 0);
+    p.pair_a_in.clear(); p.pair_b_in.clear(); p.pair_a_out.clear(); p.pair_b_out.clear();
+    std::vector<std::vector<std::vector<int32_t>>> tmp(N_ROLES, std::vector<std::vector<int32_t>>(C));
+    // each use is pushed as three ints: row, stride, partner
+    auto push_use = [&](int role, int c, long long row, int stride, int partner) {
+        tmp[role][c].push_back((int32_t)row);
+        tmp[role][c].push_back(stride);
+        tmp[role][c].push_back(partner);
+    };
+    int acc = 0;
+    for (int lv = 1; lv < L; ++lv) {          // inside: target (lv, pos), split n: left (n,pos), right (lv-n-1, pos+n+1)
+        p.lvl_base_in[lv] = acc;
+        const int Lc = L - lv, N = lv;
+        for (int pos = 0; pos < Lc; ++pos)
+            for (int n = 0; n < N; ++n) {
+                const int a = cell(n, pos), b = cell(lv - n - 1, pos + n + 1);
+                p.pair_a_in.push_back(a);
+                p.pair_b_in.push_back(b);
+                const long long row = (long long)B * acc + (pos * N + n);
+                push_use(ROLE_INA, a, row, Lc * N, b);
+                push_use(ROLE_INB, b, row, Lc * N, a);
+            }
+        acc += Lc * N;
+    }
+    acc = 0;
+    for (int lv = 0; lv + 1 < L; ++lv) {      // outside: target (lv, pos); our split order: parents that START left of
+        p.lvl_base_out[lv] = acc;             // the target first (target = right child), then parents that END right of it
+        const int Lc = L - lv, N = L - lv - 1;
+        for (int pos = 0; pos < Lc; ++pos)
+            for (int n = 0; n < N; ++n) {
+                int sib, par;
+                if (n < pos) {                 // parent [q, pos+lv], sibling [q, pos-1]
+                    const int q = n;
+                    par = cell(pos + lv - q, q);
+                    sib = cell(pos - 1 - q, q);
+                } else {                       // parent [pos, r], sibling [pos+lv+1, r]
+                    const int r = pos + lv + 1 + (n - pos);
+                    par = cell(r - pos, pos);
+                    sib = cell(r - pos - lv - 1, pos + lv + 1);
+                }
+                p.pair_a_out.push_back(sib);
+                p.pair_b_out.push_back(par);
+                const long long row = p.R_in + (long long)B * acc + (pos * N + n);
+                push_use(ROLE_OUTA, sib, row, Lc * N, par);
+                push_use(ROLE_OUTB, par, row, Lc * N, sib);
+            }
+        acc += Lc * N;
+    }
+    for (int r = 0; r < N_ROLES; ++r) {
+        UseList& u = p.uses[r];
+        u.off.assign(C + 1, 0);
+        u.row.clear(); u.stride.clear(); u.partner.clear();
+        for (int c = 0; c < C; ++c) {
+            const auto& v = tmp[r][c];
+            for (size_t i = 0; i < v.size(); i += 3) {
+                u.row.push_back(v[i]); u.stride.push_back(v[i + 1]); u.partner.push_back(v[i + 2]);
+            }
+            u.off[c + 1] = (int32_t)u.row.size();
+        }
+    }
+
+    // ---- per-row maps (batch expanded) ---------------------------------------------
+    {
+        const size_t Rt = (size_t)(p.R_in + p.R_out);
+        p.arow.resize(Rt); p.brow.resize(Rt); p.trow.resize(Rt);
+        for (int pass = 0; pass < 2; ++pass) {
+            const auto& ta = pass ? p.pair_a_out : p.pair_a_in;
+            const auto& tb = pass ? p.pair_b_out : p.pair_b_in;
+            const auto& base = pass ? p.lvl_base_out : p.lvl_base_in;
+            const int lv0 = pass ? 0 : 1, lv1 = pass ? L - 1 : L;
+            for (int lv = lv0; lv < lv1; ++lv) {
+                const int Lc = L - lv, N = pass ? L - lv - 1 : lv;
+                const long long rb = pass ? p.row_base_out(lv) : p.row_base_in(lv);
+                for (int b = 0; b < B; ++b)
+                    for (int pos = 0; pos < Lc; ++pos)
+                        for (int n = 0; n < N; ++n) {
+                            const int loc = pos * N + n;
+                            const size_t r = (size_t)(rb + (long long)b * Lc * N + loc);
+                            p.arow[r] = b * C + ta[base[lv] + loc];
+                            p.brow[r] = b * C + tb[base[lv] + loc];
+                            p.trow[r] = b * C + cell(lv, pos);
+                        }
+            }
+        }
+    }
+
+    // ---- workspace layouts -----------------------------------------------------
+    const size_t Dp = p.Dp, nb = p.nblk, BC = (size_t)B * C, BL = (size_t)B * L;
+    const size_t Rt = (size_t)(p.R_in + p.R_out);
+    const bool padded = (p.D != p.Dp);
+    {
+        FwdLayout& f = p.fwd;
+        size_t o = 0;
+        auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
+        f.wl = take(Dp * Dp); f.bl = take(Dp); f.wlT = take(Dp * Dp);
+        f.wcat = take(nb * Dp * Dp); f.bcat = take(nb * Dp); f.wcatT = take(nb * Dp * Dp);
+        f.w1ro = take(Dp * Dp); f.w1roT = take(Dp * Dp);
+        f.w2i = take(Dp * Dp); f.b2i = take(Dp); f.w2iT = take(Dp * Dp);
+        if (p.share) { f.w2o = f.w2i; f.b2o = f.b2i; f.w2oT = f.w2iT; }
+        else { f.w2o = take(Dp * Dp); f.b2o = take(Dp); f.w2oT = take(Dp * Dp); }
+        f.rootp = take(Dp);
+        f.xp = take(padded ? BL * Dp : 0);
+        f.ihp = take(padded ? BC * Dp : 0);
+        f.ohp = take(padded ? BC * Dp : 0);
+        f.objp = take((padded && R > 0) ? (size_t)B * R * Dp : 0);
+        f.t = take(BL * Dp);
+        f.pi = take(BC * nb * Dp);
+        f.po = take(BC * Dp);
+        f.y = take(Rt * Dp);
+        f.sp = take(Rt);
+        f.pp = take(Rt);
+        f.nrmi = take(BC);
+        f.nrmo = take(BC);
+        // CLIORA per-cell attention state: pre-attention unit vector u (Dp), probabilities after
+        // dropout (R, padded to 64), and two norms.
+        f.att = take(R > 0 ? BC * (Dp + 64 + 4) : 0);
+        f.total = o;
+    }
+    {
+        BwdLayout& b = p.bwd;
+        size_t o = 0;
+        auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
+        b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
+        b.da = take(Rt * Dp); b.ds = take(Rt);
+        b.dpi = take(BC * nb * Dp); b.dpo = take(BC * Dp);
+        b.du = take(BL * Dp); b.dxp = take(padded ? BL * Dp : 0);
+        // split-K slabs: at most 1024 wave-sized partial blocks of 80x80 per weight-gradient GEMM
+        b.slab_floats = (size_t)2048 * 80 * 80;
+        b.slab = take(b.slab_floats);
+        b.gwcat = take(nb * Dp * Dp); b.gbcat = take(nb * Dp); b.gw1ro = take(Dp * Dp);
+        b.gw2i = take(Dp * Dp); b.gb2i = take(Dp); b.gw2o = take(Dp * Dp); b.gb2o = take(Dp);
+        b.gwl = take(Dp * Dp); b.gbl = take(Dp); b.groot = take(Dp);
+        b.dobjp = take(R > 0 ? (size_t)B * R * Dp : 0);
+        b.total = o;
+    }
+    return "";
+}
+
+std::vector<int32_t> flatten_tables(Plan& p) {
+    std::vector<int32_t> flat;
+    auto put = [&](const std::vector<int32_t>& v) {
+        size_t at = flat.size();
+        flat.insert(flat.end(), v.begin(), v.end());
+        while (flat.size() % 4) flat.push_back(0);
+        return at;
+    };
+    p.dev.pair_a_in = put(p.pair_a_in); p.dev.pair_b_in = put(p.pair_b_in);
+    p.dev.pair_a_out = put(p.pair_a_out); p.dev.pair_b_out = put(p.pair_b_out);
+    for (int r = 0; r < N_ROLES; ++r) {
+        p.dev.use_off[r] = put(p.uses[r].off);
+        p.dev.use_row[r] = put(p.uses[r].row);
+        p.dev.use_stride[r] = put(p.uses[r].stride);
+        p.dev.use_partner[r] = put(p.uses[r].partner);
+    }
+    p.dev.lvl_base_in = put(p.lvl_base_in);
+    p.dev.arow = put(p.arow); p.dev.brow = put(p.brow); p.dev.trow = put(p.trow);
+    if (flat.empty()) flat.push_back(0);
+    return flat;
+}
+
+const std::vector<int32_t>* find_table(const Plan& p, const std::string& name) {
+    if (name == "level_offset") return &p.level_offset;
+    if (name == "pair_a_in") return &p.pair_a_in;
+    if (name == "pair_b_in") return &p.pair_b_in;
+    if (name == "pair_a_out") return &p.pair_a_out;
+    if (name == "pair_b_out") return &p.pair_b_out;
+    if (name == "pair_lvl_base_in") return &p.lvl_base_in;
+    if (name == "pair_lvl_base_out") return &p.lvl_base_out;
+    if (name == "arow") return &p.arow;
+    if (name == "brow") return &p.brow;
+    if (name == "trow") return &p.trow;
+    static const char* roles[N_ROLES] = {"ina", "inb", "outa", "outb"};
+    for (int r = 0; r < N_ROLES; ++r) {
+        const std::string s = roles[r];
+        if (name == "use_off_" + s) return &p.uses[r].off;
+        if (name == "use_row_" + s) return &p.uses[r].row;
+        if (name == "use_stride_" + s) return &p.uses[r].stride;
+        if (name == "use_partner_" + s) return &p.uses[r].partner;
+    }
+    return nullptr;
+}
+
+}  // namespace cliora

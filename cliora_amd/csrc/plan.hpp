@@ -1,0 +1,98 @@
+// Chart plan: host-side index tables, use lists and workspace layout for one
+// (B, L, D, share, normalize, R) chart shape.  Pure C++ (no HIP calls) so that
+// it can be exercised on a box without a GPU.
+//
+// Reference behaviour restated here (tables only, closed form):
+//   cliora/net/offset_cache.py:1-7        level offsets
+//   cliora/net/inside_index.py:131-197    inside (left,right) per split
+//   cliora/net/outside_index.py:39-62     outside (parent,sibling) per split
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace cliora {
+
+constexpr int ROLE_INA = 0;   // inside cell used as LEFT child in the inside pass
+constexpr int ROLE_INB = 1;   // inside cell used as RIGHT child in the inside pass
+constexpr int ROLE_OUTA = 2;  // inside cell used as SIBLING in the outside pass
+constexpr int ROLE_OUTB = 3;  // outside cell used as PARENT in the outside pass
+constexpr int N_ROLES = 4;
+
+struct UseList {
+    std::vector<int32_t> off;      // C+1, CSR offsets per cell
+    std::vector<int32_t> row;      // batch-independent part of the pair row
+    std::vector<int32_t> stride;   // per-sentence row stride of that level (Lc*N)
+    std::vector<int32_t> partner;  // the other cell of the pair
+};
+
+// Offsets are in floats from the start of the workspace; every region starts 64-float aligned.
+struct FwdLayout {
+    size_t wl, bl, wlT;                 // leaf fc (Dp x Dp), bias, transpose
+    size_t wcat, bcat, wcatT;           // inside-cell projection: (nblk*Dp x Dp), bias, transpose (Dp x nblk*Dp)
+    size_t w1ro, w1roT;                 // outside-cell projection W1[:, D:] of the outside compose
+    size_t w2i, b2i, w2iT;              // second compose layer, inside weights
+    size_t w2o, b2o, w2oT;              // outside weights (alias of inside when shared)
+    size_t rootp;                       // root vector, padded
+    size_t xp, ihp, ohp;                // padded copies (only when D != Dp; else unused)
+    size_t objp;                        // padded obj (CLIORA, D != Dp)
+    size_t t;                           // leaf tanh output (B*L x Dp)
+    size_t pi, po;                      // projections of inside cells (B*C x nblk*Dp) / outside cells (B*C x Dp)
+    size_t y;                           // per-pair compose output (R x Dp)
+    size_t sp, pp;                      // per-pair score / softmax weight (R)
+    size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
+    size_t att;                         // CLIORA: per-cell attention state (see kernels_vl)
+    size_t total;
+};
+
+struct BwdLayout {
+    size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C)
+    size_t da, ds;                      // per-pair grads (R x Dp), (R)
+    size_t dpi, dpo;                    // grads of the projections
+    size_t du, dxp;                     // leaf pre-activation grad, padded dx
+    size_t slab;                        // split-K partial sums for the weight-gradient GEMMs
+    size_t gwcat, gbcat, gw1ro, gw2i, gb2i, gw2o, gb2o, gwl, gbl, groot;   // packed parameter grads
+    size_t dobjp;                       // CLIORA
+    size_t total;
+    size_t slab_floats;
+};
+
+struct Plan {
+    int B, L, D, Dp, C, share, normalize, R;
+    int nblk;                 // projection blocks per inside cell: PL, PR, QL (+ PLo, QLo when not shared)
+    int blk_plo, blk_qlo;     // which block the outside pass reads for sibling PL / QL
+    int P_in, P_out;          // span pairs per sentence
+    long long R_in, R_out;    // pair rows in the batch
+    std::vector<int32_t> level_offset;                 // L
+    std::vector<int32_t> lvl_base_in, lvl_base_out;    // L: pairs per sentence before this level
+    std::vector<int32_t> pair_a_in, pair_b_in;         // P_in   (left, right) cell per local pair p*N+n
+    std::vector<int32_t> pair_a_out, pair_b_out;       // P_out  (sibling, parent)
+    UseList uses[N_ROLES];
+    // per global pair row (inside rows first, then outside rows): chart row (b*C + cell) of the
+    // a-operand cell, the b-operand cell and the target cell
+    std::vector<int32_t> arow, brow, trow;
+    FwdLayout fwd;
+    BwdLayout bwd;
+
+    // device copies (filled lazily by the HIP side)
+    int32_t* d_tables = nullptr;
+    size_t d_tables_count = 0;
+    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in; } dev;
+
+    int Lc(int level) const { return L - level; }
+    int Nin(int level) const { return level; }
+    int Nout(int level) const { return L - level - 1; }
+    long long row_base_in(int level) const { return (long long)B * lvl_base_in[level]; }
+    long long row_base_out(int level) const { return R_in + (long long)B * lvl_base_out[level]; }
+};
+
+// Builds every host table and the workspace layouts.  Returns "" or an error message.
+std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R);
+
+// Flattens all int32 tables into one array (to upload once); fills p.dev offsets.
+std::vector<int32_t> flatten_tables(Plan& p);
+
+const std::vector<int32_t>* find_table(const Plan& p, const std::string& name);
+
+}  // namespace cliora

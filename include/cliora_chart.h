@@ -1,0 +1,144 @@
+/*
+ * cliora_chart.h -- C ABI of the MI355X-native DIORA/CLIORA chart engine.
+ *
+ * Drop-in boundary for ONE path of bobwan1995/cliora: the chart-based
+ * inside-outside recursion behind DioraMLP.forward().  The reference has no
+ * native code and no FFI; what a maintainer replaces is the body of
+ *     cliora/net/diora.py:424-450   DioraBase.forward  (text-only DIORA)
+ *     cliora/net/cliora.py:438-468  DioraBase.forward  (CLIORA, vision-language)
+ * and the autograd graph torch builds under it (driven from
+ *     cliora/net/trainer.py:288     self.diora(embed_span, embed_word, obj_span, obj_word)
+ *     cliora/net/trainer.py:450-455 Trainer.gradient_update -> loss.backward()).
+ * INTEGRATION.md shows the ctypes stub that binds these entry points.
+ *
+ * Conventions: plain pointers and sizes only, no torch types.  Every data
+ * pointer is a DEVICE pointer to contiguous row-major fp32 unless it says
+ * otherwise.  The caller owns every buffer (allocates, frees); the library only
+ * reads/writes them and keeps no per-call state outside the plan and the
+ * caller's workspaces.  All work is enqueued on `stream` (a hipStream_t passed
+ * as void*) and returns without synchronising.  Every function returns 0 on
+ * success, a negative CLIORA_E* code otherwise; it never throws.
+ * cliora_last_error() gives the message for the calling thread.
+ *
+ * Chart layout (cliora/net/offset_cache.py:1-7): cell (level, pos) = span of
+ * words [pos, pos+level]; id = C - (L-level)(L-level+1)/2 + pos, C = L(L+1)/2.
+ */
+#ifndef CLIORA_CHART_H
+#define CLIORA_CHART_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIORA_OK 0
+#define CLIORA_EINVAL (-1)   /* bad argument / unsupported shape */
+#define CLIORA_EHIP (-2)     /* a HIP runtime call failed */
+#define CLIORA_ENOMEM (-3)   /* workspace too small */
+
+#define CLIORA_NORM_NONE 0   /* cliora/net/utils.py:17-27 NormalizeFunc('none') */
+#define CLIORA_NORM_UNIT 1   /* NormalizeFunc('unit'): x / max(||x||, 1e-8)     */
+
+typedef struct cliora_plan cliora_plan;
+
+/* Parameters of DioraMLP in the reference's own shapes (cliora/net/diora.py:453-471):
+ *   leaf_w (D,D), leaf_b (D)          inside_compose_func.leaf_fc.{weight,bias}
+ *   w1 (D,2D), b1 (D)                 *_compose_func.h_fcs.0.{weight,bias}
+ *   w2 (D,D),  b2 (D)                 *_compose_func.h_fcs.2.{weight,bias}
+ *   mat (D,D)                         *_score_func.mat
+ *   root_h (D)                        root_vector_out_h
+ * With share=1 the out_* pointers are ignored (the reference aliases the modules,
+ * diora.py:459-461).  The same struct carries gradients (same shapes, written,
+ * not accumulated). */
+typedef struct cliora_params {
+    float *leaf_w, *leaf_b;
+    float *in_w1, *in_b1, *in_w2, *in_b2, *in_mat;
+    float *out_w1, *out_b1, *out_w2, *out_b2, *out_mat;
+    float *root_h;
+} cliora_params;
+
+/* A plan fixes (batch B, length L, size D, share, normalize, number of image
+ * regions R; R = 0 selects text-only DIORA) and owns the small device index
+ * tables for that chart shape: per-level (left,right) / (sibling,parent) cell
+ * tables (cliora/net/inside_index.py:182-197, outside_index.py:93-127) and the
+ * per-cell use lists the backward gathers over.  Creating a plan allocates
+ * device memory; do it outside the step loop (the reference caches the same
+ * tables in Index, cliora/net/utils.py:67-134). */
+int cliora_plan_create(int B, int L, int D, int share, int normalize, int R, cliora_plan** out);
+void cliora_plan_destroy(cliora_plan* plan);
+
+/* Bytes the caller must provide.  fwd workspace: written by forward, must stay
+ * untouched until the matching backward.  bwd workspace: scratch. */
+size_t cliora_plan_fwd_workspace_bytes(const cliora_plan* plan);
+size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan);
+
+/* Host view of a plan table (int32), for tests and tooling.  Names:
+ * "level_offset", "pair_a_in", "pair_b_in", "pair_a_out", "pair_b_out",
+ * "pair_lvl_base_in", "pair_lvl_base_out", "use_off_<role>", "use_row_<role>",
+ * "use_stride_<role>", "use_partner_<role>" with role in {ina, inb, outa, outb}.
+ * Works without a GPU. */
+int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count);
+
+/* Forward: DioraBase.forward -- leaf transform, inside pass, and (run_outside != 0)
+ * root init + outside pass (diora.py:283-398).
+ *   x_span     (B,L,D)   in
+ *   obj_span   (B,R,D)   in, CLIORA only (else NULL)
+ *   drop_mask  CLIORA training only: pre-scaled dropout masks (0 or 1/(1-p)) for the
+ *              AttentionHead (cliora.py:32,40), concatenated per call site: leaves
+ *              (B,L,R) then inside levels 1..L-1 (B,L-level,R); NULL = no dropout (eval)
+ *   inside_h/outside_h (B,C,D), inside_s/outside_s (B,C)   out
+ *   inside_c   (B,C,D)   out, CLIORA only (else NULL): unit(context) at the leaves, 0 above
+ * For DioraMLP the c charts are identically zero (diora.py:70); the caller zero-fills
+ * them once, they are not touched here. */
+int cliora_chart_forward(cliora_plan* plan, const cliora_params* params,
+                         const float* x_span, const float* obj_span, const float* drop_mask,
+                         float* inside_h, float* inside_s, float* outside_h, float* outside_s,
+                         float* inside_c,
+                         void* fwd_workspace, size_t fwd_workspace_bytes,
+                         int run_outside, void* stream);
+
+/* Backward of the call above (what torch.autograd replays through diora.py:295-398).
+ * d_* are the cotangents of the four chart outputs (any may be NULL = zero).
+ * Writes d_x_span (B,L,D), d_obj_span (B,R,D, CLIORA) and every field of `grads`
+ * that is non-NULL (shared weights: inside+outside contributions summed into in_*). */
+int cliora_chart_backward(cliora_plan* plan, const cliora_params* params,
+                          const float* x_span, const float* obj_span, const float* drop_mask,
+                          const float* inside_h, const float* inside_s,
+                          const float* outside_h, const float* outside_s,
+                          const float* d_inside_h, const float* d_inside_s,
+                          const float* d_outside_h, const float* d_outside_s,
+                          void* fwd_workspace, size_t fwd_workspace_bytes,
+                          void* bwd_workspace, size_t bwd_workspace_bytes,
+                          float* d_x_span, float* d_obj_span, const cliora_params* grads,
+                          int ran_outside, void* stream);
+
+/* Per-split inside scores the reference hands to inside_hook (diora.py:331-334):
+ * for `level`, a (B, L-level, level) block laid out exactly like the reference's
+ * s.view(B, Lc, N, 1).  Returns a device pointer into the fwd workspace. */
+int cliora_inside_pair_scores(const cliora_plan* plan, void* fwd_workspace, int level,
+                              const float** scores, size_t* count);
+
+/* CKY decode (cliora/analysis/cky.py:31-99 + analysis/utils.py:78-95): best binary
+ * tree per sentence from the inside per-split scores of the last forward; first
+ * maximum wins.  split_out (B, C) int32 device: chosen split n per cell (leaves -1);
+ * the tree is rebuilt from it on the host. */
+int cliora_cky_decode(cliora_plan* plan, void* fwd_workspace, int32_t* split_out, void* stream);
+
+/* Optional HIP-event timing of one kernel class (used by bench.py for the roofline
+ * line): enable, run steps, then read the accumulated device time and launch count. */
+int cliora_prof_enable(int kernel_class, int on);
+int cliora_prof_read(int kernel_class, double* total_ms, long long* launches, void* stream);
+#define CLIORA_KCLASS_COMPOSE_FWD 0
+#define CLIORA_KCLASS_COMPOSE_BWD 1
+#define CLIORA_KCLASS_WGRAD 2
+#define CLIORA_KCLASS_COUNT 3
+
+const char* cliora_last_error(void);
+const char* cliora_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIORA_CHART_H */
