@@ -51,8 +51,8 @@ def lib():
     L.cliora_chart_forward.restype = i32
     L.cliora_chart_backward.argtypes = [vp, C.POINTER(Params)] + [vp] * 11 + [vp, sz, vp, sz, vp, vp, C.POINTER(Params), i32, vp]
     L.cliora_chart_backward.restype = i32
-    L.cliora_inside_pair_scores.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(sz)]
-    L.cliora_inside_pair_scores.restype = i32
+    L.cliora_inside_pair_states.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.cliora_inside_pair_states.restype = i32
     L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
     L.cliora_cky_decode.restype = i32
     L.cliora_prof_enable.argtypes = [i32, i32]

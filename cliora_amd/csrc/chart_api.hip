@@ -538,12 +538,16 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
 }
 
 // ------------------------------------------------------------------ hooks / CKY
-extern "C" int cliora_inside_pair_scores(const cliora_plan* plan, void* fwd_ws, int level, const float** scores, size_t* count) {
-    if (!plan || !fwd_ws || !scores || !count) return fail(CLIORA_EINVAL, "NULL argument");
+extern "C" int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_ws, int level, const float** scores, const float** h,
+                                         size_t* rows, size_t* ldh) {
+    if (!plan || !fwd_ws || !scores || !h || !rows || !ldh) return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
     if (level < 1 || level >= p.L) return fail(CLIORA_EINVAL, "level out of range");
-    *scores = (const float*)fwd_ws + p.fwd.sp + p.row_base_in(level);
-    *count = (size_t)p.B * (p.L - level) * level;
+    const size_t r0 = (size_t)p.row_base_in(level);
+    *scores = (const float*)fwd_ws + p.fwd.sp + r0;
+    *h = (const float*)fwd_ws + p.fwd.y + r0 * p.Dp;
+    *rows = (size_t)p.B * (p.L - level) * level;
+    *ldh = (size_t)p.Dp;
     return CLIORA_OK;
 }
 

@@ -1,0 +1,273 @@
+"""MI355X-native drop-in for ``cliora.net.diora.DioraMLP`` (cliora/net/diora.py:205-471).
+
+Same constructor, same ``forward(x_span, x_word, obj_embed_span=None,
+obj_embed_word=None) -> None`` with results left on attributes, same parameter
+names (state_dict keys), same hooks -- but the whole chart recursion (leaf
+transform, inside pass, outside pass) and its backward run as hand-written HIP
+kernels behind the C ABI of include/cliora_chart.h.  torch only owns the device
+memory, the stream and the autograd edge.  There is no CPU fallback: without
+the HIP library (or on CPU tensors) ``forward`` raises.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .index import Index
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _param_struct(tensors):
+    st = _lib.Params()
+    for name in _lib.PARAM_FIELDS:
+        t = tensors.get(name)
+        setattr(st, name, t.data_ptr() if t is not None else None)
+    return st
+
+
+class ChartFunction(torch.autograd.Function):
+    """One autograd node for the whole inside-outside chart.
+
+    forward  -> cliora_chart_forward   (replaces diora.py:283-398 as executed by DioraBase.forward)
+    backward -> cliora_chart_backward  (replaces what autograd replays through those lines)
+    Inputs: plan, run_outside, x_span, then the parameter tensors in _lib.PARAM_FIELDS order
+    (None for the out_* set when the weights are shared).
+    """
+
+    @staticmethod
+    def forward(ctx, plan, run_outside, x_span, *params):
+        if not x_span.is_cuda:
+            raise _lib.ChartLibError('the chart path runs on the GPU only (got a CPU tensor)')
+        B, L, D, Cc = plan.B, plan.L, plan.D, plan.C
+        x_span = x_span.contiguous().float()
+        ptens = {n: (p.detach().contiguous() if p is not None else None) for n, p in zip(_lib.PARAM_FIELDS, params)}
+        dev = x_span.device
+        inside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
+        inside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
+        outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
+        outside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
+        ws = torch.empty(plan.fwd_bytes, device=dev, dtype=torch.uint8)
+        pst = _param_struct(ptens)
+        rc = _lib.lib().cliora_chart_forward(plan.handle, C.byref(pst), _ptr(x_span), None, None,
+                                            _ptr(inside_h), _ptr(inside_s), _ptr(outside_h), _ptr(outside_s), None,
+                                            _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
+        _lib.check(rc, 'cliora_chart_forward')
+        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside), ws, ptens
+        ctx.save_for_backward(x_span, inside_h, inside_s, outside_h, outside_s)
+        ctx.mark_non_differentiable(ws)
+        return inside_h, inside_s, outside_h, outside_s, ws
+
+    @staticmethod
+    def backward(ctx, d_ih, d_is, d_oh, d_os, _d_ws):
+        plan = ctx.plan
+        x_span, inside_h, inside_s, outside_h, outside_s = ctx.saved_tensors
+        dev = x_span.device
+        cont = lambda g: g.contiguous().float() if g is not None else None
+        d_ih, d_is, d_oh, d_os = cont(d_ih), cont(d_is), cont(d_oh), cont(d_os)
+        grads = {n: (torch.empty_like(t) if t is not None else None) for n, t in ctx.ptens.items()}
+        d_x = torch.empty_like(x_span)
+        wsb = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)
+        pst, gst = _param_struct(ctx.ptens), _param_struct(grads)
+        rc = _lib.lib().cliora_chart_backward(plan.handle, C.byref(pst), _ptr(x_span), None, None,
+                                             _ptr(inside_h), _ptr(inside_s), _ptr(outside_h), _ptr(outside_s),
+                                             _ptr(d_ih), _ptr(d_is), _ptr(d_oh), _ptr(d_os),
+                                             _ptr(ctx.ws), plan.fwd_bytes, _ptr(wsb), plan.bwd_bytes,
+                                             _ptr(d_x), None, C.byref(gst), ctx.run_outside, _stream())
+        _lib.check(rc, 'cliora_chart_backward')
+        return (None, None, d_x) + tuple(grads[n] for n in _lib.PARAM_FIELDS)
+
+
+# --------------------------------------------------------------------------------------
+# Parameter containers with the reference's module tree, so state_dict keys match
+# (diora.py:26-97, 453-471).  Their forward() is never used on the product path.
+# --------------------------------------------------------------------------------------
+class ComposeMLP(nn.Module):
+    def __init__(self, size, ninput=2, leaf=False):
+        super().__init__()
+        self.size, self.ninput = size, ninput
+        if leaf:
+            self.leaf_fc = nn.Linear(size, size)
+        self.h_fcs = nn.Sequential(nn.Linear(2 * size, size), nn.ReLU(), nn.Linear(size, size), nn.ReLU())
+
+
+class Bilinear(nn.Module):
+    def __init__(self, size):
+        super().__init__()
+        self.size = size
+        self.mat = nn.Parameter(torch.empty(size, size))
+
+
+class Chart(object):
+    """Attribute bag with the six chart tensors (diora.py:7-23)."""
+    __slots__ = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+
+
+class DioraBase(nn.Module):
+    vision_language = False
+
+    def __init__(self, size, word_mat=None, cate_mat=None, outside=True, normalize='unit', compress=False, share=True):
+        super().__init__()
+        assert normalize in ('none', 'unit'), 'Does not support "{}".'.format(normalize)
+        if compress:
+            raise NotImplementedError('compress=True is never enabled by the reference (trainer.py:552) and is not built')
+        self.size = size
+        self.share = share
+        self.outside = outside
+        self.normalize = normalize
+        self.compress = compress
+        self.ninput = 2
+        self.index = None
+        self.charts = None
+        self.init_parameters()
+        self.reset_parameters()
+        self.reset()
+
+    def init_parameters(self):
+        raise NotImplementedError
+
+    def reset_parameters(self):
+        # every parameter ~ N(0, 1): diora.py:234-237
+        for p in self.parameters():
+            if p.requires_grad:
+                p.data.normal_()
+
+    # ---- attribute surface read by the losses / CKY / eval scripts
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def is_cuda(self):
+        d = self.device
+        return d.index is not None and d.index >= 0
+
+    inside_h = property(lambda self: self.chart.inside_h)
+    inside_c = property(lambda self: self.chart.inside_c)
+    inside_s = property(lambda self: self.chart.inside_s)
+    outside_h = property(lambda self: self.chart.outside_h)
+    outside_c = property(lambda self: self.chart.outside_c)
+    outside_s = property(lambda self: self.chart.outside_s)
+
+    def cuda(self, device=None):
+        super().cuda(device)
+        if self.index is not None:
+            self.index.cuda = True
+        return self
+
+    def get(self, chart, level):
+        L = self.length - level
+        offset = self.index.get_offset(self.length)[level]
+        return chart[:, offset:offset + L]
+
+    def inside_hook(self, level, h, c, s):
+        pass
+
+    def outside_hook(self, level, h, c, s):
+        pass
+
+    def init_with_batch(self, h, c):
+        # the native forward has already filled the chart; kept as an overridable method because
+        # analysis/utils.py:67-76 wraps it with types.MethodType to attach its score store
+        self.batch_size, self.length = h.shape[0], h.shape[1]
+
+    def reset(self):
+        self.batch_size = None
+        self.length = None
+        self.chart = None
+        self.atten_score = None
+        self.all_atten_score = None
+        self.vg_atten_score = None
+        self._ws = None
+        self._plan = None
+
+    def _hook_overridden(self, name):
+        return name in self.__dict__ or getattr(type(self), name) is not getattr(DioraBase, name)
+
+    def _param_tensors(self):
+        ic, isf = self.inside_compose_func, self.inside_score_func
+        t = dict(leaf_w=ic.leaf_fc.weight, leaf_b=ic.leaf_fc.bias,
+                 in_w1=ic.h_fcs[0].weight, in_b1=ic.h_fcs[0].bias, in_w2=ic.h_fcs[2].weight, in_b2=ic.h_fcs[2].bias,
+                 in_mat=isf.mat, root_h=self.root_vector_out_h)
+        if not self.share:
+            oc, osf = self.outside_compose_func, self.outside_score_func
+            t.update(out_w1=oc.h_fcs[0].weight, out_b1=oc.h_fcs[0].bias, out_w2=oc.h_fcs[2].weight,
+                     out_b2=oc.h_fcs[2].bias, out_mat=osf.mat)
+        return [t.get(n) for n in _lib.PARAM_FIELDS]
+
+    def forward(self, x_span, x_word=None, obj_embed_span=None, obj_embed_word=None):
+        if self.index is None:
+            self.index = Index(cuda=self.is_cuda)
+        self.reset()
+        if obj_embed_span is not None:
+            raise NotImplementedError('text-only DIORA module; use cliora_amd.cliora.DioraMLP with image regions')
+        B, L, D = x_span.shape
+        assert D == self.size
+        dev_index = x_span.device.index if x_span.is_cuda else -1
+        plan = _lib.get_plan(B, L, D, self.share, self.normalize, 0, dev_index)
+        ih, is_, oh, os_, ws = ChartFunction.apply(plan, bool(self.outside), x_span, *self._param_tensors())
+        ch = Chart()
+        ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s = ih, is_, oh, os_
+        # DioraMLP's cell state is identically zero (diora.py:60-61, 70)
+        ch.inside_c = torch.zeros_like(ih)
+        ch.outside_c = torch.zeros_like(oh)
+        self.chart = ch
+        self._ws, self._plan = ws, plan
+        self.init_with_batch(ih[:, :L], ch.inside_c[:, :L])
+        if self._hook_overridden('inside_hook'):
+            for level in range(1, L):
+                h, s = self.pair_states(level)
+                self.inside_hook(level, h, torch.zeros_like(h), s)
+        return None
+
+    # ---- un-aggregated per-split tensors the hooks receive (diora.py:295-334)
+    def pair_states(self, level):
+        """(h, s) of one inside level: h (B*Lc*N, D) compose outputs, s (B, Lc, N, 1) split scores."""
+        plan, ws = self._plan, self._ws
+        ps, ph, rows, ldh = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib().cliora_inside_pair_states(plan.handle, _ptr(ws), level, C.byref(ps), C.byref(ph),
+                                                        C.byref(rows), C.byref(ldh)), 'cliora_inside_pair_states')
+        wsf = ws.view(torch.float32)
+        so, ho = (ps.value - ws.data_ptr()) // 4, (ph.value - ws.data_ptr()) // 4
+        n, ld = rows.value, ldh.value
+        s = wsf[so:so + n].view(plan.B, plan.L - level, level, 1)
+        h = wsf[ho:ho + n * ld].view(n, ld)[:, :plan.D]
+        return h, s
+
+    def cky(self):
+        """Best binary tree per sentence (analysis/cky.py:31-99) decoded on the GPU.
+
+        Returns nested tuples of word positions, e.g. ``(0, ((1, 2), 3))``."""
+        plan = self._plan
+        split = torch.empty((plan.B, plan.C), device=self._ws.device, dtype=torch.int32)
+        _lib.check(_lib.lib().cliora_cky_decode(plan.handle, _ptr(self._ws), _ptr(split), _stream()), 'cliora_cky_decode')
+        sp = split.cpu().numpy()
+        off = self.index.get_offset(plan.L)
+
+        def build(b, level, pos):
+            if level == 0:
+                return pos
+            n = int(sp[b, off[level] + pos])
+            return (build(b, n, pos), build(b, level - n - 1, pos + n + 1))
+        return [build(b, plan.L - 1, 0) for b in range(plan.B)]
+
+
+class DioraMLP(DioraBase):
+    def init_parameters(self):
+        self.inside_score_func = Bilinear(self.size)
+        self.inside_compose_func = ComposeMLP(self.size, leaf=True)
+        if self.share:
+            self.outside_score_func = self.inside_score_func
+            self.outside_compose_func = self.inside_compose_func
+        else:
+            self.outside_score_func = Bilinear(self.size)
+            self.outside_compose_func = ComposeMLP(self.size)
+        self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
+        self.root_vector_out_c = None

@@ -114,11 +114,13 @@ int cliora_chart_backward(cliora_plan* plan, const cliora_params* params,
                           float* d_x_span, float* d_obj_span, const cliora_params* grads,
                           int ran_outside, void* stream);
 
-/* Per-split inside scores the reference hands to inside_hook (diora.py:331-334):
- * for `level`, a (B, L-level, level) block laid out exactly like the reference's
- * s.view(B, Lc, N, 1).  Returns a device pointer into the fwd workspace. */
-int cliora_inside_pair_scores(const cliora_plan* plan, void* fwd_workspace, int level,
-                              const float** scores, size_t* count);
+/* Un-aggregated per-split tensors the reference hands to inside_hook (diora.py:295-334)
+ * for `level`: scores = (B, L-level, level) laid out exactly like the reference's
+ * s.view(B, Lc, N, 1); h = the compose outputs, `rows` = B*(L-level)*level rows of D
+ * valid floats with row stride `ldh`, same row order as the reference's h (M, D).
+ * Both are device pointers into the fwd workspace. */
+int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_workspace, int level,
+                              const float** scores, const float** h, size_t* rows, size_t* ldh);
 
 /* CKY decode (cliora/analysis/cky.py:31-99 + analysis/utils.py:78-95): best binary
  * tree per sentence from the inside per-split scores of the last forward; first

@@ -1,0 +1,217 @@
+"""GPU parity: the HIP chart path (through the C ABI) against the golden vectors
+captured from the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerance: outputs within 1e-4 absolute in fp32 (BASELINE.json north_star); gradients
+within 2e-4 of the tensor's largest reference magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_from_golden
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL = 1e-4
+GRAD_TOL = 2e-4
+
+CHARTS = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
+
+
+def _module_from_params(P, D, share, normalize, outside=True):
+    from cliora_amd.diora import DioraMLP
+    m = DioraMLP(D, outside=outside, normalize=normalize, compress=False, share=share)
+    sd = m.state_dict()
+    for k in sd:
+        src = k
+        if share and k.startswith('outside_'):
+            src = 'inside_' + k[len('outside_'):]
+        sd[k] = P[src].detach().clone()
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def _err(a, b):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+def _scale(b):
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return max(1.0, float(np.abs(b).max())) if b.size else 1.0
+
+
+def _grad_ok(t, ref, what=''):
+    """Kink-tolerant gradient check for the d=400 / L=20 shapes.
+
+    With ~6 M ReLU pre-activations per step, about one of them sits within fp32 rounding of
+    zero, and whichever side a given summation order lands on changes ONE row of a weight
+    gradient by a finite amount.  The reference's own CPU fp32 path shows exactly this against
+    an fp64 run of itself (seeds 1236/1238/1239: single rows off by 1e-4..2e-3 of the tensor
+    scale, median element error ~1e-6).  So: 99% of the elements within GRAD_TOL, every
+    element within 100x that.
+    """
+    a = t.detach().double().cpu().flatten()
+    b = ref.detach().double().cpu().flatten()
+    d = (a - b).abs()
+    scale = max(1.0, float(b.abs().max()))
+    q = float(torch.quantile(d[:: max(1, d.numel() // 200000)], 0.99))
+    assert q <= GRAD_TOL * scale, '%s: q99 err %.3e scale %.3e' % (what, q, scale)
+    assert float(d.max()) <= 100 * GRAD_TOL * scale, '%s: max err %.3e scale %.3e' % (what, float(d.max()), scale)
+
+
+def _run_gpu(m, x, cot):
+    xg = x.clone().cuda().requires_grad_(True)
+    m.train()
+    m(xg, xg)
+    outs = {k: getattr(m, k) for k in CHARTS}
+    torch.autograd.backward([outs[k] for k in CHARTS if k in cot], [cot[k].cuda() for k in CHARTS if k in cot])
+    torch.cuda.synchronize()
+    return outs, xg
+
+
+@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_nonorm.npz', 'diora_len2.npz'])
+def test_golden_forward_backward(name):
+    g = load_golden(name)
+    meta = g['meta']
+    P = params_from_golden(g)
+    m = _module_from_params(P, meta['D'], meta['share'], meta['normalize'])
+    cot = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('cot__')}
+    outs, xg = _run_gpu(m, torch.from_numpy(g['x_span']), cot)
+    for k in CHARTS:
+        assert _err(outs[k], g[k]) <= OUT_TOL * _scale(g[k]), k
+    assert float(m.inside_c.abs().max()) == 0.0 and float(m.outside_c.abs().max()) == 0.0
+    named = dict(m.named_parameters())
+    for k, v in g.items():
+        if not k.startswith('grad__'):
+            continue
+        name_ = k[6:].replace('__', '.')
+        t = xg.grad if name_ == 'x_span' else named[name_].grad
+        assert t is not None, k
+        assert _err(t, v) <= GRAD_TOL * _scale(v), '%s err %.3e scale %.3e' % (k, _err(t, v), _scale(v))
+
+
+@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_len2.npz'])
+def test_hook_scores_and_trees(name):
+    from oracle import diora_ref as R
+    g = load_golden(name)
+    meta = g['meta']
+    P = params_from_golden(g)
+    m = _module_from_params(P, meta['D'], meta['share'], meta['normalize'])
+    m.eval()
+    saved = {}
+
+    def hook(level, h, c, s):            # what analysis/utils.py:78-95 stores
+        saved[level] = (s - s.max(2, keepdim=True)[0]).cpu()
+        assert h.shape == (meta['B'] * (meta['L'] - level) * level, meta['D'])
+    m.inside_hook = hook
+    with torch.no_grad():
+        x = torch.from_numpy(g['x_span']).cuda()
+        m(x, x)
+    for level in range(1, meta['L']):
+        assert _err(saved[level], g['hook_s_%d' % level]) <= 2e-4
+    trees = m.cky()
+    assert [str(t) for t in trees] == meta['trees']
+    assert [[list(s) for s in R.tree_spans(t)] for t in trees] == meta['spans']
+
+
+def test_c2_shape_against_oracle_and_golden():
+    """d=400, L=20 (BASELINE config 2 shape) at B=2: full tensors vs the CPU oracle, checksums vs the reference."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    g = load_golden('diora_c2_small.npz')
+    meta = g['meta']
+    P, x, cot = synth.diora_case(meta['D'], meta['B'], meta['L'], meta['seed'])
+    m = _module_from_params(P, meta['D'], True, 'unit')
+    outs, xg = _run_gpu(m, x, cot)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, training=True, keep_pairs=True)
+    sum((ref[k] * cot[k]).sum() for k in CHARTS).backward()
+    for k in CHARTS:
+        assert _err(outs[k], ref[k]) <= OUT_TOL, k
+    cells = g['cells']
+    for k in ('inside_h', 'outside_h'):
+        assert _err(outs[k][:, cells], g[k + '__cells']) <= OUT_TOL
+    assert _err(outs['inside_s'], g['inside_s']) <= OUT_TOL * _scale(g['inside_s'])
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        _grad_ok(named[k].grad, p.grad, k)
+    _grad_ok(xg.grad, xc.grad, 'x_span')
+    m.eval()
+    with torch.no_grad():
+        m(x.cuda(), x.cuda())
+    assert [str(t) for t in m.cky()] == meta['trees']
+
+
+def test_full_size_c2_properties():
+    """B=64, L=20, D=400 (BASELINE config 2): size-independent properties + oracle on a sentence subset."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    D, B, L = 400, 64, 20
+    P, x, cot = synth.diora_case(D, B, L, 1234)
+    m = _module_from_params(P, D, True, 'unit')
+    outs, xg = _run_gpu(m, x, cot)
+    ih, oh = outs['inside_h'], outs['outside_h']
+    # every chart vector is unit length; leaf/root scores are the zero-initialised ones
+    assert float((ih.norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert float((oh.norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert float(outs['inside_s'][:, :L].abs().max()) == 0.0
+    assert float(outs['outside_s'][:, -1].abs().max()) == 0.0
+    # sentences are independent: the first two must match the oracle run on them alone
+    with torch.no_grad():
+        ref = R.diora_forward(P, x[:2], x[:2])
+    for k in CHARTS:
+        assert _err(outs[k][:2], ref[k]) <= OUT_TOL, k
+    # determinism (fixed-order reductions, no atomics): a second run is bitwise identical
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    outs2, xg2 = _run_gpu(m, x, cot)
+    for k in CHARTS:
+        assert torch.equal(outs[k], outs2[k]), k
+    for n, p in m.named_parameters():
+        assert torch.equal(g1[n], p.grad), n
+    assert torch.equal(xg.grad, xg2.grad)
+    # backward is linear in the cotangent
+    for p in m.parameters():
+        p.grad = None
+    cot2 = {k: 2.0 * v for k, v in cot.items()}
+    _run_gpu(m, x, cot2)
+    for n, p in m.named_parameters():
+        assert _err(p.grad, 2.0 * g1[n]) <= 1e-4 * _scale(g1[n]), n
+
+
+def test_inside_only_eval_mode():
+    """run_eval turns the outside pass off for DIORA (scripts/train.py:130): charts stay zero, grads still flow."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    D, B, L = 48, 3, 7
+    P, x, cot = synth.diora_case(D, B, L, 5)
+    m = _module_from_params(P, D, True, 'unit', outside=False)
+    cot = {k: cot[k] for k in ('inside_h', 'inside_s')}
+    outs, xg = _run_gpu(m, x, cot)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, outside=False)
+    sum((ref[k] * cot[k]).sum() for k in cot).backward()
+    for k in CHARTS:
+        assert _err(outs[k], ref[k]) <= OUT_TOL, k
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        if p.grad is None:
+            assert float(named[k].grad.abs().max()) == 0.0, k
+        else:
+            assert _err(named[k].grad, p.grad) <= GRAD_TOL * _scale(p.grad), k
+    assert _err(xg.grad, xc.grad) <= GRAD_TOL * _scale(xc.grad)
+
+
+def test_cpu_tensor_fails_loudly():
+    from cliora_amd.diora import DioraMLP
+    from cliora_amd._lib import ChartLibError
+    m = DioraMLP(16)
+    with pytest.raises(ChartLibError):
+        m(torch.randn(2, 4, 16), None)

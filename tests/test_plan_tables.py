@@ -1,0 +1,88 @@
+"""CPU tests of the native host logic: the C-ABI library loads, exports every symbol the
+header declares, and its chart tables agree with the tables captured from the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from cliora_amd import _lib
+from cliora_amd.index import Index
+from oracle import chart_layout as CL
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'cliora_chart.h')).read()
+    names = set(re.findall(r'\b(cliora_[a-z_]+)\s*\(', hdr))
+    assert len(names) >= 12
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(L, n), n
+    assert b'gfx950' in _lib.lib().cliora_version()
+
+
+@pytest.mark.parametrize('L', [2, 3, 4, 7, 10, 20, 33, 40])
+def test_tables_match_reference(golden, L):
+    g = golden('index_tables.npz')
+    ix = Index()
+    off = ix.get_offset(L)
+    assert [off[i] for i in range(L)] == g['off_%d' % L].tolist()
+    li = np.concatenate([ix.get_inside_index(L, lv)[0].numpy() for lv in range(1, L)])
+    ri = np.concatenate([ix.get_inside_index(L, lv)[1].numpy() for lv in range(1, L)])
+    assert np.array_equal(li, g['lidx_%d' % L]) and np.array_equal(ri, g['ridx_%d' % L])
+    pi = np.concatenate([ix.get_outside_index(L, lv)[0].numpy() for lv in range(L - 2, -1, -1)])
+    si = np.concatenate([ix.get_outside_index(L, lv)[1].numpy() for lv in range(L - 2, -1, -1)])
+    assert np.array_equal(pi, g['pidx_%d' % L]) and np.array_equal(si, g['sidx_%d' % L])
+
+
+@pytest.mark.parametrize('B,L', [(1, 1), (2, 2), (3, 6), (2, 11)])
+def test_use_lists_and_row_maps(B, L):
+    pl = _lib.Plan(B, L, 20)
+    C = L * (L + 1) // 2
+    P_in, P_out = CL.n_inside_pairs(L), CL.n_outside_pairs(L)
+    arow, brow, trow = pl.table('arow'), pl.table('brow'), pl.table('trow')
+    assert len(arow) == B * (P_in + P_out)
+    # every pair row appears exactly once in the a-role and once in the b-role use lists of its pass
+    seen = {r: np.zeros(len(arow), dtype=np.int32) for r in ('ina', 'inb', 'outa', 'outb')}
+    for role in seen:
+        uo, ur, us, up = (pl.table('use_%s_%s' % (k, role)) for k in ('off', 'row', 'stride', 'partner'))
+        assert len(uo) == C + 1
+        for c in range(C):
+            for u in range(uo[c], uo[c + 1]):
+                for b in range(B):
+                    row = ur[u] + b * us[u]
+                    seen[role][row] += 1
+                    mine, other = (arow, brow) if role in ('ina', 'outa') else (brow, arow)
+                    assert mine[row] == b * C + c and other[row] == b * C + up[u]
+    nin = B * P_in
+    assert (seen['ina'][:nin] == 1).all() and (seen['inb'][:nin] == 1).all()
+    assert (seen['outa'][nin:] == 1).all() and (seen['outb'][nin:] == 1).all()
+    assert seen['ina'][nin:].sum() == 0 and seen['outa'][:nin].sum() == 0
+    # a target's children tile its span: inside  a=[p..], b=[..end];  outside  sibling + target = parent
+    off = pl.table('level_offset')
+
+    def span(cell):
+        lv = int(np.searchsorted(off, cell, side='right') - 1)
+        pos = cell - off[lv]
+        return pos, pos + lv
+    for r in range(len(arow)):
+        ta, tb, tt = span(arow[r] % C), span(brow[r] % C), span(trow[r] % C)
+        if r < nin:
+            assert ta[0] == tt[0] and tb[1] == tt[1] and ta[1] + 1 == tb[0]
+        else:   # a = sibling (inside chart), b = parent (outside chart)
+            assert tb[0] == min(ta[0], tt[0]) and tb[1] == max(ta[1], tt[1])
+            assert (ta[1] + 1 == tt[0]) or (tt[1] + 1 == ta[0])
+
+
+def test_plan_rejects_bad_shapes():
+    for args in [(0, 5, 16), (2, 5, 600), (2, 70, 16)]:
+        with pytest.raises(_lib.ChartLibError):
+            _lib.Plan(*args)
+
+
+def test_workspace_sizes_scale():
+    a, b = _lib.Plan(8, 10, 50), _lib.Plan(64, 20, 400)
+    assert 0 < a.fwd_bytes < b.fwd_bytes and 0 < a.bwd_bytes < b.bwd_bytes
+    assert b.fwd_bytes < 2 << 30 and b.bwd_bytes < 2 << 30
