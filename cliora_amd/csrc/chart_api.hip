@@ -140,38 +140,56 @@ static int pick_tiles(int ntiles16) {
     return 1;
 }
 
-template <int CT, class AP, class EP>
-static int launch_rows_ct(hipStream_t st, const float* W, int K, int ncols, int nrows, AP ap, EP ep) {
-    const size_t lds = (size_t)CT * 16 * (K + WS_LDS_PAD) * sizeof(float);
+template <int CT, int SC, int WAVES, class AP, class EP>
+static int launch_rows_inst(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    const size_t lds = (size_t)CT * 16 * (Kseg + WS_LDS_PAD) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        HIPOK(hipFuncSetAttribute((const void*)rows_gemm_ws<CT, AP, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPOK(hipFuncSetAttribute((const void*)rows_gemm_ws<CT, SC, WAVES, AP, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const int ntiles = (nrows + 15) / 16;
     const int gy = ncols / (16 * CT);
-    int gx = (ntiles + 3) / 4;
+    int gx = (ntiles + WAVES - 1) / WAVES;
     const int cap = std::max(1, 256 / gy);
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((rows_gemm_ws<CT, AP, EP>), dim3(gx, gy), dim3(WS_THREADS), lds, st, W, K, nrows, ap, ep);
+    hipLaunchKernelGGL((rows_gemm_ws<CT, SC, WAVES, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, W, Kseg * nseg, Kseg, nseg,
+                       nrows, ap, ep);
     LAUNCHOK("rows_gemm_ws");
     return CLIORA_OK;
 }
 
-// out[r][j] = sum_k A(r,k) W[j][k] for j < ncols (multiple of 16), K multiple of 16
+template <int CT, int SC, class AP, class EP>
+static int launch_rows_waves(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    // one wave per SIMD while the launch cannot fill the chip twice over; two per SIMD beyond that
+    const long long tasks = (long long)((nrows + 15) / 16) * (ncols / (16 * CT));
+    if (tasks > 1536) return launch_rows_inst<CT, SC, 8>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    return launch_rows_inst<CT, SC, 4>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+}
+
+template <int CT, class AP, class EP>
+static int launch_rows_ct(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    const int chunks = Kseg / 16;
+    if (chunks % 5 == 0) return launch_rows_waves<CT, 5>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    if (chunks % 4 == 0) return launch_rows_waves<CT, 4>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    if (chunks % 2 == 0) return launch_rows_waves<CT, 2>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    return launch_rows_waves<CT, 1>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+}
+
+// out[r][j] = sum_k A(r,k) W[j][k] for j < ncols (multiple of 16); k runs over nseg segments of Kseg (multiple of 16)
 template <class AP, class EP>
-static int launch_rows(hipStream_t st, const float* W, int K, int ncols, int nrows, AP ap, EP ep) {
+static int launch_rows(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
     if (nrows <= 0) return CLIORA_OK;
     const size_t budget = 150 * 1024;
     const int nt = ncols / 16;
     for (int ct : {5, 4, 2, 1}) {
         if (nt % ct) continue;
-        if ((size_t)ct * 16 * (K + WS_LDS_PAD) * sizeof(float) > budget) continue;
+        if ((size_t)ct * 16 * (Kseg + WS_LDS_PAD) * sizeof(float) > budget) continue;
         switch (ct) {
-            case 5: return launch_rows_ct<5>(st, W, K, ncols, nrows, ap, ep);
-            case 4: return launch_rows_ct<4>(st, W, K, ncols, nrows, ap, ep);
-            case 2: return launch_rows_ct<2>(st, W, K, ncols, nrows, ap, ep);
-            default: return launch_rows_ct<1>(st, W, K, ncols, nrows, ap, ep);
+            case 5: return launch_rows_ct<5>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+            case 4: return launch_rows_ct<4>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+            case 2: return launch_rows_ct<2>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+            default: return launch_rows_ct<1>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
         }
     }
     return fail(CLIORA_EINVAL, "weight block does not fit LDS");
@@ -325,12 +343,12 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
-    OKR(launch_rows(st, ws + f.wl, Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    OKR(launch_rows(st, ws + f.wl, Dp, 1, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, ws + f.t, Dp, B * L, L, C, 0, Dp, p.normalize,
                        IH, ws + f.nrmi, IS);
     LAUNCHOK("unit_norm_rows");
     if (L > 1)
-        OKR(launch_rows(st, ws + f.wcat, Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
+        OKR(launch_rows(st, ws + f.wcat, Dp, 1, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
     // ---- inside pass (diora.py:295-331) ----
@@ -342,7 +360,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("pair_scores_fwd");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-            OKR(launch_rows(st, ws + f.w2i, Dp, Dp, nrows,
+            OKR(launch_rows(st, ws + f.w2i, Dp, 1, Dp, nrows,
                             ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi},
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
@@ -350,7 +368,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            ws + f.nrmi);
         LAUNCHOK("cell_aggregate_fwd");
         if (level < L - 1)
-            OKR(launch_rows(st, ws + f.wcat, Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows(st, ws + f.wcat, Dp, 1, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                             StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
 
@@ -360,7 +378,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            ws + f.nrmo, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows(st, ws + f.w1ro, Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_rows(st, ws + f.w1ro, Dp, 1, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -369,7 +387,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             LAUNCHOK("pair_scores_fwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                OKR(launch_rows(st, ws + f.w2o, Dp, Dp, nrows,
+                OKR(launch_rows(st, ws + f.w2o, Dp, 1, Dp, nrows,
                                 ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp},
                                 StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
             }
@@ -377,7 +395,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                ws + f.nrmo);
             LAUNCHOK("cell_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows(st, ws + f.w1ro, Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows(st, ws + f.w1ro, Dp, 1, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
         }
     } else {
@@ -433,7 +451,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
             LAUNCHOK("cell_gather_bwd_out");
             if (level >= 1)
-                OKR(launch_rows(st, ws + f.w1roT, Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                OKR(launch_rows(st, ws + f.w1roT, Dp, 1, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                                 StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
             if (level == L - 1) {
                 hipLaunchKernelGGL(root_bwd, dim3(1), dim3(256), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
@@ -445,7 +463,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("cell_scores_bwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-                OKR(launch_rows(st, ws + f.w2oT, Dp, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
+                OKR(launch_rows(st, ws + f.w2oT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
                                 ComposeBwdE{dv.arow, dv.brow, g.rowbase, PI + (size_t)p.blk_plo * Dp, ldpi, PO, Dp, DA, Dp}));
             }
         }
@@ -472,7 +490,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows(st, ws + f.wcatT, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows(st, ws + f.wcatT, Dp, nb, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == 0) break;
         hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, Y, Sp, Pp, IS,
@@ -480,7 +498,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         LAUNCHOK("cell_scores_bwd(in)");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-            OKR(launch_rows(st, ws + f.w2iT, Dp, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
+            OKR(launch_rows(st, ws + f.w2iT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
                             ComposeBwdE{dv.arow, dv.brow, g.rowbase, PI, ldpi, PI + Dp, ldpi, DA, Dp}));
         }
     }
@@ -488,7 +506,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IH, ws + f.nrmi, p.normalize, ws + f.t, dU);
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
-        OKR(launch_rows(st, ws + f.wlT, Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+        OKR(launch_rows(st, ws + f.wlT, Dp, 1, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     {
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);
         OKR(launch_tn(st, (int)p.R_in, Dp, Dp, Dp, ComposeDzA{dv.trow, 0, dG, Y, Pp, Dp},

@@ -386,16 +386,20 @@ __global__ __launch_bounds__(256) void root_bwd(int B, int C, int Dp, const floa
 struct PlainRowsA {
     const float* p; int ld;
     struct Ctx { const float* r; };
+    using Raw = float4;
     __device__ Ctx row(int r) const { return Ctx{p + (size_t)r * ld}; }
-    __device__ float4 load(const Ctx& c, int k) const { return ld4(c.r + k); }
+    __device__ Raw fetch(const Ctx& c, int k) const { return ld4(c.r + k); }
+    __device__ float4 finish(const Ctx&, const Raw& v) const { return v; }
     __device__ float val(const Ctx& c, int col) const { return c.r[col]; }
 };
 // A rows = the cells of one chart level, all sentences: row r = b*Lc + p -> chart row b*C + off + p
 struct LevelRowsA {
     const float* p; int ld, C, off, Lc;
     struct Ctx { const float* r; };
+    using Raw = float4;
     __device__ Ctx row(int r) const { const int b = r / Lc; return Ctx{p + ((size_t)b * C + off + (r - b * Lc)) * ld}; }
-    __device__ float4 load(const Ctx& c, int k) const { return ld4(c.r + k); }
+    __device__ Raw fetch(const Ctx& c, int k) const { return ld4(c.r + k); }
+    __device__ float4 finish(const Ctx&, const Raw& v) const { return v; }
 };
 // compose layer 1, factored: x = relu(PL(a) + PR(b))           (diora.py:65-68 first Linear + ReLU)
 struct ComposeXA {
@@ -403,9 +407,10 @@ struct ComposeXA {
     const float* A; int ldA; const float* Bm; int ldB;
     struct Ctx { const float *pa, *pb; };
     __device__ Ctx row(int r) const { return Ctx{A + (size_t)arow[rowbase + r] * ldA, Bm + (size_t)brow[rowbase + r] * ldB}; }
-    __device__ float4 load(const Ctx& c, int k) const {
-        const float4 u = ld4(c.pa + k), v = ld4(c.pb + k);
-        return make_float4(fmaxf(u.x + v.x, 0.f), fmaxf(u.y + v.y, 0.f), fmaxf(u.z + v.z, 0.f), fmaxf(u.w + v.w, 0.f));
+    struct Raw { float4 u, v; };
+    __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.pa + k), ld4(c.pb + k)}; }
+    __device__ float4 finish(const Ctx&, const Raw& r) const {
+        return make_float4(fmaxf(r.u.x + r.v.x, 0.f), fmaxf(r.u.y + r.v.y, 0.f), fmaxf(r.u.z + r.v.z, 0.f), fmaxf(r.u.w + r.v.w, 0.f));
     }
     __device__ float val(const Ctx& c, int col) const { return fmaxf(c.pa[col] + c.pb[col], 0.f); }
 };
@@ -418,33 +423,39 @@ struct ComposeDzA {
         const size_t gr = (size_t)rowbase + r;
         return Ctx{dG + (size_t)trow[gr] * Dp, Y + gr * Dp, Pp[gr]};
     }
-    __device__ float4 load(const Ctx& c, int k) const {
-        const float4 g = ld4(c.g + k), y = ld4(c.y + k);
-        return make_float4(y.x > 0.f ? c.pn * g.x : 0.f, y.y > 0.f ? c.pn * g.y : 0.f, y.z > 0.f ? c.pn * g.z : 0.f, y.w > 0.f ? c.pn * g.w : 0.f);
+    struct Raw { float4 g, y; };
+    __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.g + k), ld4(c.y + k)}; }
+    __device__ float4 finish(const Ctx& c, const Raw& r) const {
+        return make_float4(r.y.x > 0.f ? c.pn * r.g.x : 0.f, r.y.y > 0.f ? c.pn * r.g.y : 0.f, r.y.z > 0.f ? c.pn * r.g.z : 0.f, r.y.w > 0.f ? c.pn * r.g.w : 0.f);
     }
     __device__ float val(const Ctx& c, int col) const { return c.y[col] > 0.f ? c.pn * c.g[col] : 0.f; }
 };
 
 // epilogues
 struct StoreRowsE {            // out[r*ld + col] = act(v + bias[col]); ACT 0 none, 1 tanh, 2 relu; cols >= ncols skipped
-    float* out; int ld; const float* bias; int act; int ncols;
+    float* out; int ld; const float* bias; int act; int ncols;   // vector path when ld % 4 == 0 (16-B aligned rows)
     struct RCtx { float* o; };
     __device__ RCtx row(int r) const { return RCtx{out + (size_t)r * ld}; }
-    __device__ void store(const RCtx& rc, int col, float v) const {
+    __device__ float f(float v) const { return act == 1 ? tanhf(v) : (act == 2 ? fmaxf(v, 0.f) : v); }
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
         if (col >= ncols) return;
-        if (bias) v += bias[col];
-        if (act == 1) v = tanhf(v); else if (act == 2) v = fmaxf(v, 0.f);
-        rc.o[col] = v;
+        if (bias) { const float4 b = ld4(bias + col); v = f4add(v, b); }
+        v = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+        if ((ld & 3) == 0 && col + 3 < ncols) { st4(rc.o + col, v); return; }
+        rc.o[col] = v.x;
+        if (col + 1 < ncols) rc.o[col + 1] = v.y;
+        if (col + 2 < ncols) rc.o[col + 2] = v.z;
+        if (col + 3 < ncols) rc.o[col + 3] = v.w;
     }
 };
 struct StoreLevelE {           // level row r -> chart row; out[crow*ld + col] = v + bias[col]   (or += when accumulate)
     float* out; int ld, C, off, Lc; const float* bias; int accumulate;
     struct RCtx { float* o; };
     __device__ RCtx row(int r) const { const int b = r / Lc; return RCtx{out + ((size_t)b * C + off + (r - b * Lc)) * ld}; }
-    __device__ void store(const RCtx& rc, int col, float v) const {
-        if (bias) v += bias[col];
-        if (accumulate) v += rc.o[col];
-        rc.o[col] = v;
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
+        if (bias) v = f4add(v, ld4(bias + col));
+        if (accumulate) v = f4add(v, ld4(rc.o + col));
+        st4(rc.o + col, v);
     }
 };
 struct ComposeBwdE {           // DA[row][col] = (x > 0) ? v : 0 with x = PL(a) + PR(b)      (first ReLU backward)
@@ -456,7 +467,11 @@ struct ComposeBwdE {           // DA[row][col] = (x > 0) ? v : 0 with x = PL(a) 
         const size_t gr = (size_t)rowbase + r;
         return RCtx{A + (size_t)arow[gr] * ldA, Bm + (size_t)brow[gr] * ldB, DA + gr * Dp};
     }
-    __device__ void store(const RCtx& rc, int col, float v) const { rc.o[col] = (rc.pa[col] + rc.pb[col] > 0.f) ? v : 0.f; }
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
+        const float4 a = ld4(rc.pa + col), b = ld4(rc.pb + col);
+        st4(rc.o + col, make_float4(a.x + b.x > 0.f ? v.x : 0.f, a.y + b.y > 0.f ? v.y : 0.f, a.z + b.z > 0.f ? v.z : 0.f,
+                                    a.w + b.w > 0.f ? v.w : 0.f));
+    }
 };
 
 }  // namespace cliora

@@ -41,63 +41,105 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-constexpr int WS_THREADS = 256;
-constexpr int WS_LDS_PAD = 4;   // floats; keeps 16-B alignment of every row
+constexpr int WS_THREADS = 256;   // tn_gemm workgroup size
+constexpr int WS_LDS_PAD = 0;   // the LDS image is the plain row-major block (written by LDS-DMA, lane-linear)
 
 // ---------------------------------------------------------------------------------
 // rows_gemm_ws
-//   W      : [ncols_total][K] row-major (the nn.Linear layout: out x in), K % 16 == 0
+//   W      : [ncols_total][ldw] row-major (the nn.Linear layout: out x in); the reduction runs over
+//            nseg segments of Kseg columns (Kseg % (16*SC) == 0); one segment is LDS-resident at a time
 //   grid.y : column blocks of CT*16 output columns;  grid.x: row-tile walkers
-//   AProd  : struct with  Ctx row(int r) const;  float4 load(const Ctx&, int k) const;
-//   Epi    : struct with  RCtx row(int r) const;  void store(const RCtx&, int col, float v) const;
+//   WAVES  : wavefronts per workgroup (4 = one per SIMD, 8 = two per SIMD to hide load latency)
+//   SC     : 16-deep k-chunks fetched per prefetch stage; the A fragments of stage s+1 are
+//            in flight while the MFMAs of stage s issue (register double buffer, no barrier)
+//   AProd  : Ctx row(int r);  Raw fetch(const Ctx&, int k)  (issues the loads);
+//            float4 finish(const Ctx&, const Raw&)          (ALU part: add / ReLU / mask)
+//   Epi    : RCtx row(int r);  void store4(const RCtx&, int col, float4 v)   (4 consecutive columns)
+//   The weight fragment is the MFMA's A operand and the row fragment its B operand, i.e. the tile is
+//   computed transposed: a lane ends up with 4 CONSECUTIVE output columns of ONE row per accumulator,
+//   so the epilogue is one 16-byte access per lane per 16x16 tile.
 // ---------------------------------------------------------------------------------
-template <int CT, class AProd, class Epi>
-__global__ __launch_bounds__(WS_THREADS) void rows_gemm_ws(const float* __restrict__ W, int K, int nrows,
+template <int CT, int SC, int WAVES, class AProd, class Epi>
+__global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restrict__ W, int ldw, int Kseg, int nseg, int nrows,
                                                            AProd ap, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_w[];
-    const int ldb = K + WS_LDS_PAD;
+    constexpr int T = WAVES * 64;
+    const int ldb = Kseg + WS_LDS_PAD;
     const int col0 = blockIdx.y * (CT * 16);
-    {
-        const float* Wb = W + (size_t)col0 * K;
-        const int k4 = K >> 2;
-        for (int idx = threadIdx.x; idx < CT * 16 * k4; idx += WS_THREADS) {
-            const int r = idx / k4, c = idx - r * k4;
-            const float4 v = *reinterpret_cast<const float4*>(Wb + (size_t)r * K + c * 4);
-            *reinterpret_cast<float4*>(lds_w + r * ldb + c * 4) = v;
-        }
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int ntiles = (nrows + 15) >> 4;
     const float* bbase = lds_w + i * ldb + 4 * q;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    using Raw = typename AProd::Raw;
+
+    // stage the CT*16 x Kseg weight block of K-segment `seg` into LDS with LDS-DMA: every wave
+    // instruction moves 1 KiB (lane -> 16 B), all of a wave's pieces are in flight together
+    auto stage = [&](int seg) {
+        const float* Wb = W + (size_t)col0 * ldw + (size_t)seg * Kseg;
+        const int k4 = Kseg >> 2, n4 = CT * 16 * k4;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        for (int e0 = wv * 64; e0 < n4; e0 += T) {
+            const int e = e0 + lane;
+            if (e < n4) {
+                const int r = e / k4, c = e - r * k4;
+                __builtin_amdgcn_global_load_lds((const void*)(Wb + (size_t)r * ldw + c * 4),
+                                                 (__attribute__((address_space(3))) void*)(lds_w + e0 * 4), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (nseg == 1) { stage(0); __syncthreads(); }
+
+    for (int tile0 = blockIdx.x * WAVES; tile0 < ntiles; tile0 += gridDim.x * WAVES) {
+        const int tile = tile0 + wave;
+        const bool active = tile < ntiles;       // inactive waves still take part in the barriers
         int row = tile * 16 + i;
-        if (row >= nrows) row = nrows - 1;          // clamp: computed, never stored
+        if (row >= nrows) row = nrows - 1;       // clamp: computed, never stored
         const auto ctx = ap.row(row);
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int kc = 0; kc < K; kc += 16) {
-            const float4 a = ap.load(ctx, kc + 4 * q);
+        for (int seg = 0; seg < nseg; ++seg) {
+            if (nseg > 1) { __syncthreads(); stage(seg); __syncthreads(); }
+            if (!active) continue;
+            const int kbase = seg * Kseg;
+            Raw cur[SC], nxt[SC];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float4 b = *reinterpret_cast<const float4*>(bbase + c * 16 * ldb + kc);
-                acc[c] = mfma16(a.x, b.x, acc[c]);
-                acc[c] = mfma16(a.y, b.y, acc[c]);
-                acc[c] = mfma16(a.z, b.z, acc[c]);
-                acc[c] = mfma16(a.w, b.w, acc[c]);
+            for (int j = 0; j < SC; ++j) cur[j] = ap.fetch(ctx, kbase + 16 * j + 4 * q);
+            for (int ks = 0; ks < Kseg; ks += 16 * SC) {
+                const bool more = ks + 16 * SC < Kseg;
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctx, kbase + ks + 16 * (SC + j) + 4 * q);
+                }
+#pragma unroll
+                for (int j = 0; j < SC; ++j) {
+                    const float4 a = ap.finish(ctx, cur[j]);
+                    float4 b[CT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(bbase + c * 16 * ldb + ks + 16 * j);
+                    // k-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA
+                    // has a 40-cycle dependent latency against a 32-cycle issue interval)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].x, a.x, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].y, a.y, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].z, a.z, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].w, a.w, acc[c]);
+                }
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < SC; ++j) cur[j] = nxt[j];
+                }
             }
         }
+        if (active && tile * 16 + i < nrows) {
+            const auto rc = epi.row(tile * 16 + i);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = tile * 16 + q * 4 + reg;
-            if (r < nrows) {
-                const auto rc = epi.row(r);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) epi.store(rc, col0 + c * 16 + i, acc[c][reg]);
-            }
+            for (int c = 0; c < CT; ++c)
+                epi.store4(rc, col0 + c * 16 + 4 * q, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
         }
     }
 }
