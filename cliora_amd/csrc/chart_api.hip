@@ -239,6 +239,54 @@ static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, B
     }
 }
 
+// the big weight-gradient GEMM over span-pair rows: C = DZ^T X (Mi = Nj = Dp), LDS-DMA fed, split over row slices
+template <int NIT, int NJT>
+static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, int nkb, float* slab,
+                                size_t slab_floats, float* out, float* colsum_out) {
+    const size_t per_slice = (size_t)Dp * Dp + Dp;
+    int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 256 / nkb));
+    nsl = std::max(1, std::min(nsl, (nrows + 63) / 64));
+    int rps = (nrows + nsl - 1) / nsl;
+    rps = (rps + TN_RS - 1) / TN_RS * TN_RS;
+    nsl = (nrows + rps - 1) / rps;
+    const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPOK(hipFuncSetAttribute((const void*)tn_gemm_dma<NIT, NJT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    float* csl = slab + (size_t)nsl * Dp * Dp;
+    hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
+    LAUNCHOK("tn_gemm_dma");
+    const size_t n = (size_t)Dp * Dp;
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
+    LAUNCHOK("slab_reduce");
+    hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out);
+    LAUNCHOK("slab_reduce(colsum)");
+    return CLIORA_OK;
+}
+
+static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, float* slab, size_t slab_floats,
+                           float* out, float* colsum_out) {
+    if (nrows <= 0) {
+        HIPOK(hipMemsetAsync(out, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
+        return CLIORA_OK;
+    }
+    // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
+    // nkb column blocks of NJT = ceil(NT/nkb) j-tiles
+    const int NT = Dp / 16;
+#define TN_CASE(nit, njt, nkb) return launch_tn_pairs_inst<nit, njt>(st, DZ, X, nrows, Dp, nkb, slab, slab_floats, out, colsum_out)
+    if (NT <= 4) TN_CASE(1, 4, 1);
+    if (NT <= 8) TN_CASE(2, 8, 1);
+    if (NT <= 12) TN_CASE(3, 12, 1);
+    if (NT <= 16) TN_CASE(4, 8, 2);
+    if (NT <= 20) TN_CASE(5, 10, 2);
+    if (NT <= 27) TN_CASE(7, 9, 3);     // 63 accumulator tiles = 252 registers: the most that stays spill-free
+    TN_CASE(8, 8, 4);
+#undef TN_CASE
+}
+
 static int run_copies(hipStream_t st, const CopyTable& tab) {
     if (tab.n == 0) return CLIORA_OK;
     hipLaunchKernelGGL(copy2d_multi, dim3(64, tab.n), dim3(256), 0, st, tab);
@@ -361,7 +409,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
             OKR(launch_rows(st, ws + f.w2i, Dp, 1, Dp, nrows,
-                            ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi},
+                            ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi, ws + f.x, Dp},
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
         hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, IH,
@@ -388,7 +436,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
                 OKR(launch_rows(st, ws + f.w2o, Dp, 1, Dp, nrows,
-                                ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp},
+                                ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.x, Dp},
                                 StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
             }
             hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, OH,
@@ -441,7 +489,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const float* X = padded ? ws + f.xp : x_span;
     float *VH = wb + bw.vh, *dG = wb + bw.dg, *dStot = wb + bw.dstot, *DA = wb + bw.da, *DS = wb + bw.ds;
     float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
-    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po;
+    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po, *Xp = ws + f.x;
+    float* DZ = wb + bw.dz;
 
     if (ran_outside) {
         for (int level = 0; level <= L - 1; ++level) {
@@ -463,15 +512,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("cell_scores_bwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-                OKR(launch_rows(st, ws + f.w2oT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
-                                ComposeBwdE{dv.arow, dv.brow, g.rowbase, PI + (size_t)p.blk_plo * Dp, ldpi, PO, Dp, DA, Dp}));
+                OKR(launch_rows(st, ws + f.w2oT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+                                ComposeBwdE{Xp, DA, g.rowbase, Dp}));
             }
         }
-        {
+        if (!p.share) {
             ProfScope ps(CLIORA_KCLASS_WGRAD, st);
-            OKR(launch_tn(st, (int)p.R_out, Dp, Dp, Dp, ComposeDzA{dv.trow, (int)p.R_in, dG, Y, Pp, Dp},
-                          ComposeXA{dv.arow, dv.brow, (int)p.R_in, PI + (size_t)p.blk_plo * Dp, ldpi, PO, Dp},
-                          wb + bw.slab, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o));
+            OKR(launch_tn_pairs(st, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
+                                wb + bw.gw2o, wb + bw.gb2o));
         }
         OKR(launch_tn(st, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
                       (float*)nullptr));
@@ -498,8 +546,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         LAUNCHOK("cell_scores_bwd(in)");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-            OKR(launch_rows(st, ws + f.w2iT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp},
-                            ComposeBwdE{dv.arow, dv.brow, g.rowbase, PI, ldpi, PI + Dp, ldpi, DA, Dp}));
+            OKR(launch_rows(st, ws + f.w2iT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+                            ComposeBwdE{Xp, DA, g.rowbase, Dp}));
         }
     }
     // leaves
@@ -508,9 +556,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     if (d_x_span)
         OKR(launch_rows(st, ws + f.wlT, Dp, 1, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     {
+        // shared weights: inside and outside pair rows are one contiguous range -> one launch
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);
-        OKR(launch_tn(st, (int)p.R_in, Dp, Dp, Dp, ComposeDzA{dv.trow, 0, dG, Y, Pp, Dp},
-                      ComposeXA{dv.arow, dv.brow, 0, PI, ldpi, PI + Dp, ldpi}, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+        const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
+        OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+        if (p.share) {
+            HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
+            HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
+        }
     }
     OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat,
                   wb + bw.gbcat));

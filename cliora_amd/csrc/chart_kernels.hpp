@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256) void root_bwd(int B, int C, int Dp, const floa
 // ---------------------------------------------------------------------------------
 // Functors for the MFMA kernels
 // ---------------------------------------------------------------------------------
+struct Raw2 { float4 u, v; };   // two 16-byte loads in flight (shared by the gather producers)
+
 // A rows = plain rows of a matrix
 struct PlainRowsA {
     const float* p; int ld;
@@ -390,6 +392,8 @@ struct PlainRowsA {
     __device__ Ctx row(int r) const { return Ctx{p + (size_t)r * ld}; }
     __device__ Raw fetch(const Ctx& c, int k) const { return ld4(c.r + k); }
     __device__ float4 finish(const Ctx&, const Raw& v) const { return v; }
+    static constexpr bool kSide = false;
+    __device__ void side(const Ctx&, int, float4) const {}
     __device__ float val(const Ctx& c, int col) const { return c.r[col]; }
 };
 // A rows = the cells of one chart level, all sentences: row r = b*Lc + p -> chart row b*C + off + p
@@ -400,35 +404,44 @@ struct LevelRowsA {
     __device__ Ctx row(int r) const { const int b = r / Lc; return Ctx{p + ((size_t)b * C + off + (r - b * Lc)) * ld}; }
     __device__ Raw fetch(const Ctx& c, int k) const { return ld4(c.r + k); }
     __device__ float4 finish(const Ctx&, const Raw& v) const { return v; }
+    static constexpr bool kSide = false;
+    __device__ void side(const Ctx&, int, float4) const {}
 };
 // compose layer 1, factored: x = relu(PL(a) + PR(b))           (diora.py:65-68 first Linear + ReLU)
 struct ComposeXA {
     const int32_t *arow, *brow; int rowbase;
     const float* A; int ldA; const float* Bm; int ldB;
-    struct Ctx { const float *pa, *pb; };
-    __device__ Ctx row(int r) const { return Ctx{A + (size_t)arow[rowbase + r] * ldA, Bm + (size_t)brow[rowbase + r] * ldB}; }
-    struct Raw { float4 u, v; };
+    float* X; int Dp;                       // side output: x rows (global pair row order, row stride Dp)
+    struct Ctx { const float *pa, *pb; float* xo; };
+    __device__ Ctx row(int r) const {
+        const size_t gr = (size_t)rowbase + r;
+        return Ctx{A + (size_t)arow[gr] * ldA, Bm + (size_t)brow[gr] * ldB, X + gr * Dp};
+    }
+    using Raw = Raw2;
     __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.pa + k), ld4(c.pb + k)}; }
     __device__ float4 finish(const Ctx&, const Raw& r) const {
         return make_float4(fmaxf(r.u.x + r.v.x, 0.f), fmaxf(r.u.y + r.v.y, 0.f), fmaxf(r.u.z + r.v.z, 0.f), fmaxf(r.u.w + r.v.w, 0.f));
     }
-    __device__ float val(const Ctx& c, int col) const { return fmaxf(c.pa[col] + c.pb[col], 0.f); }
+    static constexpr bool kSide = true;
+    __device__ void side(const Ctx& c, int k, float4 v) const { st4(c.xo + k, v); }
 };
 // dz = p_n * dG(target) masked by the second ReLU (y > 0)
 struct ComposeDzA {
     const int32_t* trow; int rowbase;
     const float *dG, *Y, *Pp; int Dp;
-    struct Ctx { const float *g, *y; float pn; };
+    float* DZ;                              // side output: dz rows (global pair row order, row stride Dp)
+    struct Ctx { const float *g, *y; float pn; float* zo; };
     __device__ Ctx row(int r) const {
         const size_t gr = (size_t)rowbase + r;
-        return Ctx{dG + (size_t)trow[gr] * Dp, Y + gr * Dp, Pp[gr]};
+        return Ctx{dG + (size_t)trow[gr] * Dp, Y + gr * Dp, Pp[gr], DZ + gr * Dp};
     }
-    struct Raw { float4 g, y; };
+    using Raw = Raw2;   // u = dG chunk, v = Y chunk
     __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.g + k), ld4(c.y + k)}; }
     __device__ float4 finish(const Ctx& c, const Raw& r) const {
-        return make_float4(r.y.x > 0.f ? c.pn * r.g.x : 0.f, r.y.y > 0.f ? c.pn * r.g.y : 0.f, r.y.z > 0.f ? c.pn * r.g.z : 0.f, r.y.w > 0.f ? c.pn * r.g.w : 0.f);
+        return make_float4(r.v.x > 0.f ? c.pn * r.u.x : 0.f, r.v.y > 0.f ? c.pn * r.u.y : 0.f, r.v.z > 0.f ? c.pn * r.u.z : 0.f, r.v.w > 0.f ? c.pn * r.u.w : 0.f);
     }
-    __device__ float val(const Ctx& c, int col) const { return c.y[col] > 0.f ? c.pn * c.g[col] : 0.f; }
+    static constexpr bool kSide = true;
+    __device__ void side(const Ctx& c, int k, float4 v) const { st4(c.zo + k, v); }
 };
 
 // epilogues
@@ -458,19 +471,16 @@ struct StoreLevelE {           // level row r -> chart row; out[crow*ld + col] =
         st4(rc.o + col, v);
     }
 };
-struct ComposeBwdE {           // DA[row][col] = (x > 0) ? v : 0 with x = PL(a) + PR(b)      (first ReLU backward)
-    const int32_t *arow, *brow; int rowbase;
-    const float* A; int ldA; const float* Bm; int ldB;
-    float* DA; int Dp;
-    struct RCtx { const float *pa, *pb; float* o; };
+struct ComposeBwdE {           // DA[row][col] = (x > 0) ? v : 0, x = relu(PL(a) + PR(b)) as stored by the forward
+    const float* X; float* DA; int rowbase, Dp;
+    struct RCtx { const float* x; float* o; };
     __device__ RCtx row(int r) const {
         const size_t gr = (size_t)rowbase + r;
-        return RCtx{A + (size_t)arow[gr] * ldA, Bm + (size_t)brow[gr] * ldB, DA + gr * Dp};
+        return RCtx{X + gr * Dp, DA + gr * Dp};
     }
     __device__ void store4(const RCtx& rc, int col, float4 v) const {
-        const float4 a = ld4(rc.pa + col), b = ld4(rc.pb + col);
-        st4(rc.o + col, make_float4(a.x + b.x > 0.f ? v.x : 0.f, a.y + b.y > 0.f ? v.y : 0.f, a.z + b.z > 0.f ? v.z : 0.f,
-                                    a.w + b.w > 0.f ? v.w : 0.f));
+        const float4 x = ld4(rc.x + col);
+        st4(rc.o + col, make_float4(x.x > 0.f ? v.x : 0.f, x.y > 0.f ? v.y : 0.f, x.z > 0.f ? v.z : 0.f, x.w > 0.f ? v.w : 0.f));
     }
 };
 

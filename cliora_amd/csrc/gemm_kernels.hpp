@@ -115,6 +115,9 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
 #pragma unroll
                 for (int j = 0; j < SC; ++j) {
                     const float4 a = ap.finish(ctx, cur[j]);
+                    // optional side output of the A fragment (materialises x / dz for the weight-gradient
+                    // GEMM): each column block writes its 1/gridDim.y share of the k-chunks
+                    if (AProd::kSide && ((ks >> 4) + j) % (int)gridDim.y == (int)blockIdx.y) ap.side(ctx, kbase + ks + 16 * j + 4 * q, a);
                     float4 b[CT];
 #pragma unroll
                     for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(bbase + c * 16 * ldb + ks + 16 * j);
@@ -209,6 +212,157 @@ __global__ __launch_bounds__(WS_THREADS) void tn_gemm(int nrows, int rows_per_sl
             v += __shfl_xor(v, 32);
             if (q == 0) colsum[(size_t)slice * Mi + i0 + a * 16 + i] = v;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// tn_gemm_dma:  C[i][j] = sum_r A[r][i] B[r][j]  for the big weight gradient (rows = span pairs).
+//   A (dz) and B (x) are dense row-major matrices the compose kernels materialised.  One
+//   workgroup (4 waves, one per SIMD) owns ALL Mi rows of C x one block of up to NJT*16 columns
+//   for one slice of the pair rows.  16 pair rows per stage are brought into LDS by LDS-DMA
+//   (global_load_lds, 1 KiB per wave instruction, no VGPR staging, no VALU), double buffered:
+//   stage s+1 lands while stage s feeds the MFMAs.  The accumulators take most of the register
+//   file (NIT*NJT 16x16 tiles per wave) -- that is what bounds the HBM traffic per pair row at
+//   Mi + nkb*... bytes; see DESIGN.md.
+//   NIT = i-tiles per wave (every wave runs the same count: a short share re-computes its last
+//   tile and skips the duplicate store -- the workgroup waits for its longest wave anyway);
+//   NJT = j-tiles per column block (short blocks likewise).
+//   slab: [nslices][Mi][Nj];  colsum (COLSUM): [nslices][Mi] = sum_r A[r][i]
+// ---------------------------------------------------------------------------------
+constexpr int TN_RS = 16;       // pair rows per stage (4 MFMA k-steps)
+constexpr int TN_NP = 12;       // LDS-DMA pieces per wave per stage, upper bound: (Mi/16 + NJT + 3) / 4
+
+template <int NIT, int NJT, bool COLSUM>
+__global__ __launch_bounds__(256) void tn_gemm_dma(const float* __restrict__ A, const float* __restrict__ B, int nrows,
+                                                   int rows_per_slice, int Mi, int Nj, int nkb,
+                                                   float* __restrict__ slab, float* __restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) float lds_t[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int kb = blockIdx.x % nkb, slice = blockIdx.x / nkb;
+    const int NTI = Mi >> 4, NTJ = Nj >> 4;
+    const int jbase = NTJ / nkb, jrem = NTJ % nkb;
+    const int jt0 = kb * jbase + min(kb, jrem);
+    const int njt = jbase + (kb < jrem ? 1 : 0);            // j-tiles of this block (<= NJT)
+    const int ibase = NTI / 4, irem = NTI % 4;
+    const int it0 = wave * ibase + min(wave, irem);
+    const int nit = max(1, ibase + (wave < irem ? 1 : 0));  // i-tiles of this wave (<= NIT)
+    const bool has_tiles = ibase + (wave < irem ? 1 : 0) > 0;
+    const int ldA = Mi, ldX = NJT * 16;                     // Mi % 32 == 16 and ldX % 32 == 16 read conflict-free
+    const int UA = TN_RS * (Mi >> 2), UX = TN_RS * (ldX >> 2);   // 16-byte units per stage: A region, X region
+    const int bufsz = TN_RS * (ldA + ldX);
+    const int x4 = ldX >> 2, xv4 = njt * 4;                 // float4 columns per X row: allocated, valid
+
+    const int rbeg = slice * rows_per_slice;
+    const int rend = min(nrows, rbeg + rows_per_slice);
+    const int nstages = rend > rbeg ? (rend - rbeg + TN_RS - 1) / TN_RS : 0;
+
+    f32x4 acc[NIT][NJT];
+#pragma unroll
+    for (int a = 0; a < NIT; ++a)
+#pragma unroll
+        for (int b = 0; b < NJT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs0 = 0.f, cs1 = 0.f;
+
+    // LDS-DMA of one stage: the A region is the contiguous image of rows [r0, r0+16) of A; the X
+    // region holds columns [jt0*16, +ldX) of the same rows of B.  A stage is NTI + NJT pieces of
+    // 1 KiB (64 lanes x 16 B), each entirely A or entirely X; wave w moves pieces w, w+4, ...
+    // The lane -> (row, column) map of every piece is stage-invariant and computed once here.
+    // Rows past the slice end are re-read from the last valid row (finite data) and masked out of
+    // the MFMAs below.
+    const int npieces = (UA + UX) >> 6;
+    int p_rr[TN_NP], p_off[TN_NP];          // row within the stage, element offset inside that row (incl. column base)
+#pragma unroll
+    for (int k = 0; k < TN_NP; ++k) {
+        const int e = (wave + 4 * k) * 64 + lane;
+        if (e < UA) {
+            p_rr[k] = e / (Mi >> 2);
+            p_off[k] = 4 * (e - p_rr[k] * (Mi >> 2));
+        } else {
+            const int f = e - UA;
+            p_rr[k] = f / x4;
+            p_off[k] = jt0 * 16 + 4 * min(f - p_rr[k] * x4, xv4 - 1);
+        }
+    }
+    auto issue = [&](int stage) {
+        const int r0 = rbeg + stage * TN_RS;
+        const int rmax = rend - 1 - r0;      // last valid row of the stage
+        float* buf = lds_t + (stage & 1) * bufsz;
+#pragma unroll
+        for (int k = 0; k < TN_NP; ++k) {
+            const int piece = wave + 4 * k;
+            if (piece < npieces) {
+                const bool isA = piece * 64 < UA;
+                const float* base = isA ? A : B;
+                const int ld = isA ? Mi : Nj;
+                const float* src = base + (size_t)(r0 + min(p_rr[k], rmax)) * ld + p_off[k];
+                __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    // LDS offsets of this lane's fragments: tile indices are clamped to the wave's / block's last tile
+    int aoff[NIT], xoff[NJT];
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) aoff[t] = (min(it0, NTI - 1) + min(t, nit - 1)) * 16 + i;
+#pragma unroll
+    for (int u = 0; u < NJT; ++u) xoff[u] = TN_RS * ldA + min(u, njt - 1) * 16 + i;
+
+    if (nstages > 0) issue(0);
+    for (int st = 0; st < nstages; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // stage st has landed for every wave; buffer (st+1)&1 is free again
+        if (st + 1 < nstages) issue(st + 1);
+        const float* cur = lds_t + (st & 1) * bufsz;
+        const int r0 = rbeg + st * TN_RS;
+        // fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks issue (register
+        // double buffer; sched_barrier pins "reads first" so the LDS latency is not exposed per tile)
+        float av[2][NIT], bv[2][NJT];
+        auto frag = [&](int ks, float (&a)[NIT], float (&b)[NJT]) {
+            const int rr = 4 * ks + q;
+            const bool valid = r0 + rr < rend;
+#pragma unroll
+            for (int u = 0; u < NJT; ++u) b[u] = cur[rr * ldX + xoff[u]];
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) { const float v = cur[rr * ldA + aoff[t]]; a[t] = valid ? v : 0.f; }
+        };
+        frag(0, av[0], bv[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) frag(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NIT; ++t)
+#pragma unroll
+                for (int u = 0; u < NJT; ++u) acc[t][u] = mfma16(av[ks & 1][t], bv[ks & 1][u], acc[t][u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (COLSUM && kb == 0) {                 // column sums of A (bias gradient), branch-free
+            const int c0 = min(tid, Mi - 1), c1 = min(tid + 256, Mi - 1);
+#pragma unroll
+            for (int rr = 0; rr < TN_RS; ++rr) {
+                const float m = (r0 + rr < rend) ? 1.f : 0.f;
+                cs0 = fmaf(m, cur[rr * ldA + c0], cs0);
+                cs1 = fmaf(m, cur[rr * ldA + c1], cs1);
+            }
+        }
+    }
+    float* out = slab + (size_t)slice * Mi * Nj;
+    if (has_tiles) {
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+            if (t < nit)
+#pragma unroll
+                for (int u = 0; u < NJT; ++u)
+                    if (u < njt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            out[(size_t)((it0 + t) * 16 + q * 4 + reg) * Nj + (jt0 + u) * 16 + i] = acc[t][u][reg];
+    }
+    if (COLSUM && kb == 0) {
+        if (tid < Mi) colsum[(size_t)slice * Mi + tid] = cs0;
+        if (tid + 256 < Mi) colsum[(size_t)slice * Mi + tid + 256] = cs1;
     }
 }
 

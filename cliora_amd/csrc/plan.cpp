@@ -141,6 +141,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.pi = take(BC * nb * Dp);
         f.po = take(BC * Dp);
         f.y = take(Rt * Dp);
+        f.x = take(Rt * Dp);
         f.sp = take(Rt);
         f.pp = take(Rt);
         f.nrmi = take(BC);
@@ -156,10 +157,11 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
         b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
         b.da = take(Rt * Dp); b.ds = take(Rt);
+        b.dz = take(Rt * Dp);
         b.dpi = take(BC * nb * Dp); b.dpo = take(BC * Dp);
         b.du = take(BL * Dp); b.dxp = take(padded ? BL * Dp : 0);
         // split-K slabs: at most 1024 wave-sized partial blocks of 80x80 per weight-gradient GEMM
-        b.slab_floats = (size_t)2048 * 80 * 80;
+        b.slab_floats = std::max((size_t)2048 * 80 * 80, (size_t)128 * (Dp * Dp + Dp));
         b.slab = take(b.slab_floats);
         b.gwcat = take(nb * Dp * Dp); b.gbcat = take(nb * Dp); b.gw1ro = take(Dp * Dp);
         b.gw2i = take(Dp * Dp); b.gb2i = take(Dp); b.gw2o = take(Dp * Dp); b.gb2o = take(Dp);

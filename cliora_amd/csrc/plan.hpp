@@ -40,6 +40,7 @@ struct FwdLayout {
     size_t t;                           // leaf tanh output (B*L x Dp)
     size_t pi, po;                      // projections of inside cells (B*C x nblk*Dp) / outside cells (B*C x Dp)
     size_t y;                           // per-pair compose output (R x Dp)
+    size_t x;                           // per-pair first-layer activation relu(PL+PR) (R x Dp)
     size_t sp, pp;                      // per-pair score / softmax weight (R)
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
     size_t att;                         // CLIORA: per-cell attention state (see kernels_vl)
@@ -49,6 +50,7 @@ struct FwdLayout {
 struct BwdLayout {
     size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C)
     size_t da, ds;                      // per-pair grads (R x Dp), (R)
+    size_t dz;                          // per-pair grad at the second pre-activation (R x Dp)
     size_t dpi, dpo;                    // grads of the projections
     size_t du, dxp;                     // leaf pre-activation grad, padded dx
     size_t slab;                        // split-K partial sums for the weight-gradient GEMMs
