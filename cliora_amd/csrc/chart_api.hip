@@ -176,6 +176,20 @@ static int launch_rows_ct(hipStream_t st, const float* W, int Kseg, int nseg, in
     return launch_rows_waves<CT, 1>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
 }
 
+// small-row variant (per-level cell GEMMs): 32 x (CT*16) blocks, reduction split over the 4 waves, no weight staging
+template <class AP, class EP>
+static int launch_rows_direct(hipStream_t st, const float* W, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const int nt = ncols / 16;
+    const int nrg = ((nrows + 15) / 16 + 1) / 2;
+    if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 5, AP, EP>), dim3(nrg * (nt / 5)), dim3(256), 0, st, W, K, nt / 5, nrows, ap, ep);
+    else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 4, AP, EP>), dim3(nrg * (nt / 4)), dim3(256), 0, st, W, K, nt / 4, nrows, ap, ep);
+    else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 2, AP, EP>), dim3(nrg * (nt / 2)), dim3(256), 0, st, W, K, nt / 2, nrows, ap, ep);
+    else hipLaunchKernelGGL((rows_gemm_ksplit<2, 1, AP, EP>), dim3(nrg * nt), dim3(256), 0, st, W, K, nt, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ksplit");
+    return CLIORA_OK;
+}
+
 // out[r][j] = sum_k A(r,k) W[j][k] for j < ncols (multiple of 16); k runs over nseg segments of Kseg (multiple of 16)
 template <class AP, class EP>
 static int launch_rows(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
@@ -391,12 +405,12 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
-    OKR(launch_rows(st, ws + f.wl, Dp, 1, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    OKR(launch_rows_direct(st, ws + f.wl, Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, ws + f.t, Dp, B * L, L, C, 0, Dp, p.normalize,
                        IH, ws + f.nrmi, IS);
     LAUNCHOK("unit_norm_rows");
     if (L > 1)
-        OKR(launch_rows(st, ws + f.wcat, Dp, 1, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
+        OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
     // ---- inside pass (diora.py:295-331) ----
@@ -416,7 +430,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            ws + f.nrmi);
         LAUNCHOK("cell_aggregate_fwd");
         if (level < L - 1)
-            OKR(launch_rows(st, ws + f.wcat, Dp, 1, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                             StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
 
@@ -426,7 +440,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            ws + f.nrmo, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows(st, ws + f.w1ro, Dp, 1, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_rows_direct(st, ws + f.w1ro, Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -443,7 +457,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                ws + f.nrmo);
             LAUNCHOK("cell_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows(st, ws + f.w1ro, Dp, 1, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1ro, Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
         }
     } else {
@@ -500,7 +514,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
             LAUNCHOK("cell_gather_bwd_out");
             if (level >= 1)
-                OKR(launch_rows(st, ws + f.w1roT, Dp, 1, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1roT, Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                                 StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
             if (level == L - 1) {
                 hipLaunchKernelGGL(root_bwd, dim3(1), dim3(256), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
@@ -538,7 +552,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows(st, ws + f.wcatT, Dp, nb, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcatT, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == 0) break;
         hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, Y, Sp, Pp, IS,
@@ -554,7 +568,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IH, ws + f.nrmi, p.normalize, ws + f.t, dU);
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
-        OKR(launch_rows(st, ws + f.wlT, Dp, 1, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+        OKR(launch_rows_direct(st, ws + f.wlT, Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     {
         // shared weights: inside and outside pair rows are one contiguous range -> one launch
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);

@@ -103,16 +103,30 @@ __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_
     const int row0 = g.rowbase + t * g.N;
     const int nv = g.Dp >> 2;
     float my_s = -INFINITY;
-    for (int n = 0; n < g.N; ++n) {
-        const int ar = arow[row0 + n], br = brow[row0 + n];
-        const float* qa = QA + (size_t)ar * ldA;
-        const float* hb = HB + (size_t)br * g.Dp;
-        float d = 0.f;
-        if (lane < nv) d = f4dot(ld4(qa + 4 * lane), ld4(hb + 4 * lane));
-        if (lane + 64 < nv) d += f4dot(ld4(qa + 4 * (lane + 64)), ld4(hb + 4 * (lane + 64)));
-        d = wave_sum(d);
-        const float s = d + SA[ar] + SB[br];
-        if (lane == n) my_s = s;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    for (int n0 = 0; n0 < g.N; n0 += 4) {        // four splits in flight: index loads, row loads, then the reductions
+        int ar[4], br[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = min(n0 + j, g.N - 1);
+            ar[j] = arow[row0 + n];
+            br[j] = brow[row0 + n];
+        }
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* qa = QA + (size_t)ar[j] * ldA;
+            const float* hb = HB + (size_t)br[j] * g.Dp;
+            float v = 0.f;
+            if (a0) v = f4dot(ld4(qa + 4 * lane), ld4(hb + 4 * lane));
+            if (a1) v += f4dot(ld4(qa + 4 * (lane + 64)), ld4(hb + 4 * (lane + 64)));
+            d[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = wave_sum(d[j]) + SA[ar[j]] + SB[br[j]];
+            if (lane == n0 + j) my_s = s;
+        }
     }
     const float m = wave_max(my_s);
     const float e = lane < g.N ? expf(my_s - m) : 0.f;
@@ -136,11 +150,19 @@ __global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const flo
     const int nv = g.Dp >> 2;
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
     float4 v0 = f4zero(), v1 = f4zero();
-    for (int n = 0; n < g.N; ++n) {
-        const float pn = Pp[row0 + n];
-        const float* y = Y + (size_t)(row0 + n) * g.Dp;
-        if (a0) v0 = f4fma(pn, ld4(y + 4 * lane), v0);
-        if (a1) v1 = f4fma(pn, ld4(y + 4 * (lane + 64)), v1);
+    for (int n0 = 0; n0 < g.N; n0 += 4) {        // four rows in flight; accumulation stays in split order
+        float pn[4];
+        float4 y0[4], y1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = min(n0 + j, g.N - 1);
+            pn[j] = (n0 + j < g.N) ? Pp[row0 + n] : 0.f;
+            const float* y = Y + (size_t)(row0 + n) * g.Dp;
+            y0[j] = a0 ? ld4(y + 4 * lane) : f4zero();
+            y1[j] = a1 ? ld4(y + 4 * (lane + 64)) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0 = f4fma(pn[j], y0[j], v0); v1 = f4fma(pn[j], y1[j], v1); }
     }
     const float nr = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
     const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
@@ -171,6 +193,46 @@ __device__ __forceinline__ float4 ld_ext(const float* base, int D, int col) {
     return v;
 }
 
+// One use list of one cell, four uses in flight at a time (index loads, then all row loads, then
+// the accumulation in list order -- the result does not depend on the batching):
+//   acc_da += DA[row];   acc_x += ds[row] * SRC[partner];   vS += ds[row]
+__device__ __forceinline__ void gather_uses(const UseTab& ut, int c, int b, int bC, const float* __restrict__ DA,
+                                            const float* __restrict__ DS, int Dp, const float* __restrict__ SRC, int ldsrc,
+                                            int col0, int col1, bool act0, bool act1,
+                                            float4& da0, float4& da1, float4& x0, float4& x1, float& vS) {
+    const int beg = ut.off[c], end = ut.off[c + 1];
+    for (int u0 = beg; u0 < end; u0 += 4) {
+        size_t r[4];
+        float ds[4], m[4];
+        const float* sp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int uu = min(u0 + j, end - 1);
+            m[j] = (u0 + j < end) ? 1.f : 0.f;
+            r[j] = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
+            sp[j] = SRC + (size_t)(bC + ut.partner[uu]) * ldsrc;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ds[j] = DS[r[j]] * m[j];
+        float4 a0[4], a1[4], s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0[j] = act0 ? ld4(DA + r[j] * Dp + col0) : f4zero();
+            s0[j] = act0 ? ld4(sp[j] + col0) : f4zero();
+            a1[j] = act1 ? ld4(DA + r[j] * Dp + col1) : f4zero();
+            s1[j] = act1 ? ld4(sp[j] + col1) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vS += ds[j];
+            da0 = f4fma(m[j], a0[j], da0);
+            da1 = f4fma(m[j], a1[j], da1);
+            x0 = f4fma(ds[j], s0[j], x0);
+            x1 = f4fma(ds[j], s1[j], x1);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
                                                           UseTab ina, UseTab inb, UseTab outa, int with_outside,
                                                           const float* __restrict__ DA, const float* __restrict__ DS,
@@ -185,49 +247,29 @@ __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, co
     const size_t crow = (size_t)b * g.C + c;
     const int Dp = g.Dp, nv = Dp >> 2;
     const int bC = b * g.C;
+    const bool act0 = lane < nv, act1 = lane + 64 < nv;
+    const int col0 = 4 * lane, col1 = 4 * (lane + 64);
     float vS = dS_ext ? dS_ext[crow] : 0.f;
-    for (int v = lane; v < ((nv + 63) & ~63); v += 64) {
-        const bool act = v < nv;
-        const int col = 4 * v;
-        float4 vh = (dH_ext && act) ? ld_ext(dH_ext + crow * D, D, col) : f4zero();
-        float4 dPL = f4zero(), dPR = f4zero(), dQL = f4zero(), dPLo = f4zero(), dQLo = f4zero();
-        for (int u = inb.off[c]; u < inb.off[c + 1]; ++u) {
-            const size_t r = (size_t)inb.row[u] + (size_t)b * inb.stride[u];
-            const float ds = DS[r];
-            if (v == lane) vS += ds;
-            if (act) {
-                vh = f4fma(ds, ld4(PI + (size_t)(bC + inb.partner[u]) * ldpi + 2 * Dp + col), vh);
-                dPR = f4add(dPR, ld4(DA + r * Dp + col));
-            }
-        }
-        for (int u = ina.off[c]; u < ina.off[c + 1]; ++u) {
-            const size_t r = (size_t)ina.row[u] + (size_t)b * ina.stride[u];
-            const float ds = DS[r];
-            if (v == lane) vS += ds;
-            if (act) {
-                dPL = f4add(dPL, ld4(DA + r * Dp + col));
-                dQL = f4fma(ds, ld4(IH + (size_t)(bC + ina.partner[u]) * Dp + col), dQL);
-            }
-        }
-        if (with_outside)
-            for (int u = outa.off[c]; u < outa.off[c + 1]; ++u) {
-                const size_t r = (size_t)outa.row[u] + (size_t)b * outa.stride[u];
-                const float ds = DS[r];
-                if (v == lane) vS += ds;
-                if (act) {
-                    dPLo = f4add(dPLo, ld4(DA + r * Dp + col));
-                    dQLo = f4fma(ds, ld4(OH + (size_t)(bC + outa.partner[u]) * Dp + col), dQLo);
-                }
-            }
-        if (act) {
-            float* o = dPI + crow * ldpi + col;
-            if (share) {
-                st4(o, f4add(dPL, dPLo)); st4(o + Dp, dPR); st4(o + 2 * Dp, f4add(dQL, dQLo));
-            } else {
-                st4(o, dPL); st4(o + Dp, dPR); st4(o + 2 * Dp, dQL); st4(o + 3 * Dp, dPLo); st4(o + 4 * Dp, dQLo);
-            }
-            st4(VH + crow * Dp + col, vh);
-        }
+    float4 vh0 = (dH_ext && act0) ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
+    float4 vh1 = (dH_ext && act1) ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
+    float4 dPL0 = f4zero(), dPL1 = f4zero(), dPR0 = f4zero(), dPR1 = f4zero(), dQL0 = f4zero(), dQL1 = f4zero();
+    float4 dPLo0 = f4zero(), dPLo1 = f4zero(), dQLo0 = f4zero(), dQLo1 = f4zero();
+    // right-child uses: partner = left child; dH += ds * QL(left);  dPR += DA
+    gather_uses(inb, c, b, bC, DA, DS, Dp, PI + 2 * Dp, ldpi, col0, col1, act0, act1, dPR0, dPR1, vh0, vh1, vS);
+    // left-child uses: partner = right child; dQL += ds * H(right);  dPL += DA
+    gather_uses(ina, c, b, bC, DA, DS, Dp, IH, Dp, col0, col1, act0, act1, dPL0, dPL1, dQL0, dQL1, vS);
+    // sibling uses in the outside pass: partner = parent (outside chart)
+    if (with_outside) gather_uses(outa, c, b, bC, DA, DS, Dp, OH, Dp, col0, col1, act0, act1, dPLo0, dPLo1, dQLo0, dQLo1, vS);
+    float* o = dPI + crow * ldpi;
+    if (act0) {
+        if (share) { st4(o + col0, f4add(dPL0, dPLo0)); st4(o + Dp + col0, dPR0); st4(o + 2 * Dp + col0, f4add(dQL0, dQLo0)); }
+        else { st4(o + col0, dPL0); st4(o + Dp + col0, dPR0); st4(o + 2 * Dp + col0, dQL0); st4(o + 3 * Dp + col0, dPLo0); st4(o + 4 * Dp + col0, dQLo0); }
+        st4(VH + crow * Dp + col0, vh0);
+    }
+    if (act1) {
+        if (share) { st4(o + col1, f4add(dPL1, dPLo1)); st4(o + Dp + col1, dPR1); st4(o + 2 * Dp + col1, f4add(dQL1, dQLo1)); }
+        else { st4(o + col1, dPL1); st4(o + Dp + col1, dPR1); st4(o + 2 * Dp + col1, dQL1); st4(o + 3 * Dp + col1, dPLo1); st4(o + 4 * Dp + col1, dQLo1); }
+        st4(VH + crow * Dp + col1, vh1);
     }
     if (lane == 0) dStot[crow] = vS;
 }
@@ -246,26 +288,15 @@ __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, c
     const size_t crow = (size_t)b * g.C + c;
     const int Dp = g.Dp, nv = Dp >> 2;
     const int bC = b * g.C;
+    const bool act0 = lane < nv, act1 = lane + 64 < nv;
+    const int col0 = 4 * lane, col1 = 4 * (lane + 64);
     float vS = dS_ext ? dS_ext[crow] : 0.f;
-    for (int v = lane; v < ((nv + 63) & ~63); v += 64) {
-        const bool act = v < nv;
-        const int col = 4 * v;
-        float4 vh = (dH_ext && act) ? ld_ext(dH_ext + crow * D, D, col) : f4zero();
-        float4 dPR = f4zero();
-        for (int u = outb.off[c]; u < outb.off[c + 1]; ++u) {
-            const size_t r = (size_t)outb.row[u] + (size_t)b * outb.stride[u];
-            const float ds = DS[r];
-            if (v == lane) vS += ds;
-            if (act) {
-                vh = f4fma(ds, ld4(PI + (size_t)(bC + outb.partner[u]) * ldpi + blk_qlo * Dp + col), vh);
-                dPR = f4add(dPR, ld4(DA + r * Dp + col));
-            }
-        }
-        if (act) {
-            st4(dPO + crow * Dp + col, dPR);
-            st4(VH + crow * Dp + col, vh);
-        }
-    }
+    float4 vh0 = (dH_ext && act0) ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
+    float4 vh1 = (dH_ext && act1) ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
+    float4 dPR0 = f4zero(), dPR1 = f4zero();
+    gather_uses(outb, c, b, bC, DA, DS, Dp, PI + (size_t)blk_qlo * Dp, ldpi, col0, col1, act0, act1, dPR0, dPR1, vh0, vh1, vS);
+    if (act0) { st4(dPO + crow * Dp + col0, dPR0); st4(VH + crow * Dp + col0, vh0); }
+    if (act1) { st4(dPO + crow * Dp + col1, dPR1); st4(VH + crow * Dp + col1, vh1); }
     if (lane == 0) dStot[crow] = vS;
 }
 
@@ -310,13 +341,21 @@ __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float*
     if (g.N == 0) return;
     const int row0 = g.rowbase + t * g.N;
     float dp = 0.f;
-    for (int n = 0; n < g.N; ++n) {
-        const float* y = Y + (size_t)(row0 + n) * Dp;
-        float d = 0.f;
-        if (a0) d = f4dot(v0, ld4(y + 4 * lane));
-        if (a1) d += f4dot(v1, ld4(y + 4 * (lane + 64)));
-        d = wave_sum(d);
-        if (lane == n) dp = d;
+    for (int n0 = 0; n0 < g.N; n0 += 4) {
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* y = Y + (size_t)(row0 + min(n0 + j, g.N - 1)) * Dp;
+            float v = 0.f;
+            if (a0) v = f4dot(v0, ld4(y + 4 * lane));
+            if (a1) v += f4dot(v1, ld4(y + 4 * (lane + 64)));
+            d[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = wave_sum(d[j]);
+            if (lane == n0 + j) dp = r;
+        }
     }
     const bool an = lane < g.N;
     const float pn = an ? Pp[row0 + lane] : 0.f;

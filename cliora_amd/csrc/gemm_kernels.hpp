@@ -148,6 +148,102 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------
+// rows_gemm_ksplit: same contract as rows_gemm_ws for SMALL row counts (the per-level cell
+// projections and their backward: a few hundred rows, 39 dependent levels per pass).  There the
+// weight-stationary kernel is all fixed cost (128 KiB of weights staged per workgroup for one
+// tile per wave), so this one keeps no weights in LDS and instead maximises parallelism:
+//   * a workgroup (4 waves) owns one (RT*16 rows) x (CT*16 cols) output block;
+//   * the four waves split the reduction (k) range between them and each streams its A and W
+//     fragments straight from global/L2 with a one-chunk register prefetch;
+//   * partial accumulators meet in LDS and the epilogue is shared out over the waves.
+// W: [ncols][K] row-major (K = whole reduction length, a multiple of 16).
+// ---------------------------------------------------------------------------------
+template <int RT, int CT, class AProd, class Epi>
+__global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int ncolblocks, int nrows,
+                                                        AProd ap, Epi epi) {
+    __shared__ float4 part[4][RT * CT][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int rg = blockIdx.x / ncolblocks, cb = blockIdx.x - rg * ncolblocks;
+    const int col0 = cb * (CT * 16);
+    const int tile0 = rg * RT;
+    const int nchunks = K >> 4;
+    const int cbase = nchunks / 4, crem = nchunks % 4;
+    const int ch0 = wave * cbase + min(wave, crem);
+    const int nch = cbase + (wave < crem ? 1 : 0);
+    using Raw = typename AProd::Raw;
+    using Ctx = decltype(ap.row(0));
+    Ctx ctx[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((tile0 + r) * 16 + i, nrows - 1));
+    const float* wrow = W + (size_t)(col0 + i) * K + 4 * q;
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // register ring of PD chunks: the loads of chunk n+PD are issued right after chunk n has been
+    // consumed, so PD-1 chunks of MFMA work (not one) stand between a load and its use -- the
+    // per-level launches are short and latency-bound, not bandwidth-bound
+    constexpr int PD = 4;
+    Raw ra[PD][RT];
+    float4 rw[PD][CT];
+    auto load = [&](int slot, int ch) {
+        const int k = 16 * (ch0 + ch);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) ra[slot][r] = ap.fetch(ctx[r], k + 4 * q);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) rw[slot][c] = *reinterpret_cast<const float4*>(wrow + (size_t)c * 16 * K + k);
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl)
+        if (sl < nch) load(sl, sl);
+    for (int base = 0; base < nch; base += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+            if (base + sl < nch) {
+                float4 a[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) a[r] = ap.finish(ctx[r], ra[sl][r]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[r][c] = mfma16(rw[sl][c].x, a[r].x, acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[r][c] = mfma16(rw[sl][c].y, a[r].y, acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[r][c] = mfma16(rw[sl][c].z, a[r].z, acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[r][c] = mfma16(rw[sl][c].w, a[r].w, acc[r][c]);
+                if (base + sl + PD < nch) load(sl, base + sl + PD);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            part[wave][r * CT + c][lane] = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
+    __syncthreads();
+    // wave w finishes output tiles w, w+4, ...: fixed summation order over the four k-slices
+    for (int t = wave; t < RT * CT; t += 4) {
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                     ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        const int r = t / CT, c = t - r * CT;
+        const int row = (tile0 + r) * 16 + i;
+        if (row < nrows) epi.store4(epi.row(row), col0 + c * 16 + 4 * q, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // tn_gemm:  C[i][j] = sum_r A(r,i) B(r,j),  i < Mi, j < Nj  (both multiples of 16*T)
 //   grid.x = (Mi/(TI*16)) * (Nj/(TJ*16)) blocks of C; grid.y*4 + wave = row slice.
 //   AProd/BProd: Ctx row(int r) const; float val(const Ctx&, int col) const;
