@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -301,6 +302,18 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
 #undef TN_CASE
 }
 
+// compose layer: weight-stationary kernel for the big levels, split-K kernel for the small ones
+static int g_compose_ksplit_rows = -1;
+template <class AP, class EP>
+static int launch_compose(hipStream_t st, const float* W, int Dp, int nrows, AP ap, EP ep) {
+    if (g_compose_ksplit_rows < 0) {
+        const char* e = getenv("CLIORA_COMPOSE_KSPLIT_ROWS");
+        g_compose_ksplit_rows = e ? atoi(e) : 5000;   // measured crossover on MI355X (r01 sweep: 0..30000)
+    }
+    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Dp, Dp, nrows, ap, ep);
+    return launch_rows(st, W, Dp, 1, Dp, nrows, ap, ep);
+}
+
 static int run_copies(hipStream_t st, const CopyTable& tab) {
     if (tab.n == 0) return CLIORA_OK;
     hipLaunchKernelGGL(copy2d_multi, dim3(64, tab.n), dim3(256), 0, st, tab);
@@ -422,7 +435,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("pair_scores_fwd");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-            OKR(launch_rows(st, ws + f.w2i, Dp, 1, Dp, nrows,
+            OKR(launch_compose(st, ws + f.w2i, Dp, nrows,
                             ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi, ws + f.x, Dp},
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
@@ -449,7 +462,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             LAUNCHOK("pair_scores_fwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                OKR(launch_rows(st, ws + f.w2o, Dp, 1, Dp, nrows,
+                OKR(launch_compose(st, ws + f.w2o, Dp, nrows,
                                 ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.x, Dp},
                                 StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
             }
@@ -526,7 +539,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("cell_scores_bwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-                OKR(launch_rows(st, ws + f.w2oT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+                OKR(launch_compose(st, ws + f.w2oT, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
                                 ComposeBwdE{Xp, DA, g.rowbase, Dp}));
             }
         }
@@ -560,7 +573,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         LAUNCHOK("cell_scores_bwd(in)");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-            OKR(launch_rows(st, ws + f.w2iT, Dp, 1, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+            OKR(launch_compose(st, ws + f.w2iT, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
                             ComposeBwdE{Xp, DA, g.rowbase, Dp}));
         }
     }

@@ -206,6 +206,10 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
                 float4 a[RT];
 #pragma unroll
                 for (int r = 0; r < RT; ++r) a[r] = ap.finish(ctx[r], ra[sl][r]);
+                if (AProd::kSide && (ch0 + base + sl) % ncolblocks == cb) {     // side output, shared out over the column blocks
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) ap.side(ctx[r], 16 * (ch0 + base + sl) + 4 * q, a[r]);
+                }
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
