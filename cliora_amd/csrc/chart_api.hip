@@ -154,6 +154,9 @@ static int launch_rows_inst(hipStream_t st, const float* W, int Kseg, int nseg, 
     int gx = (ntiles + WAVES - 1) / WAVES;
     const int cap = std::max(1, 256 / gy);
     if (gx > cap) gx = cap;
+    // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8
+    // the gy column blocks that re-read the same A rows share one XCD's L2 (speed only, never correctness)
+    if (gx >= 8) gx = (gx + 7) / 8 * 8 <= cap ? (gx + 7) / 8 * 8 : gx / 8 * 8;
     hipLaunchKernelGGL((rows_gemm_ws<CT, SC, WAVES, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, W, Kseg * nseg, Kseg, nseg,
                        nrows, ap, ep);
     LAUNCHOK("rows_gemm_ws");
@@ -183,10 +186,12 @@ static int launch_rows_direct(hipStream_t st, const float* W, int K, int ncols, 
     if (nrows <= 0) return CLIORA_OK;
     const int nt = ncols / 16;
     const int nrg = ((nrows + 15) / 16 + 1) / 2;
-    if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 5, AP, EP>), dim3(nrg * (nt / 5)), dim3(256), 0, st, W, K, nt / 5, nrows, ap, ep);
-    else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 4, AP, EP>), dim3(nrg * (nt / 4)), dim3(256), 0, st, W, K, nt / 4, nrows, ap, ep);
-    else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 2, AP, EP>), dim3(nrg * (nt / 2)), dim3(256), 0, st, W, K, nt / 2, nrows, ap, ep);
-    else hipLaunchKernelGGL((rows_gemm_ksplit<2, 1, AP, EP>), dim3(nrg * nt), dim3(256), 0, st, W, K, nt, nrows, ap, ep);
+    // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+    if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 5, nrows, ap, ep);
+    else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 4, nrows, ap, ep);
+    else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 2, AP, EP>), dim3(nrgp * (nt / 2)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 2, nrows, ap, ep);
+    else hipLaunchKernelGGL((rows_gemm_ksplit<2, 1, AP, EP>), dim3(nrgp * nt), dim3(256), 0, st, W, K, nrg, nrgp, nt, nrows, ap, ep);
     LAUNCHOK("rows_gemm_ksplit");
     return CLIORA_OK;
 }

@@ -159,13 +159,14 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
 // W: [ncols][K] row-major (K = whole reduction length, a multiple of 16).
 // ---------------------------------------------------------------------------------
 template <int RT, int CT, class AProd, class Epi>
-__global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int ncolblocks, int nrows,
+__global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int nrg, int nrgp, int ncolblocks, int nrows,
                                                         AProd ap, Epi epi) {
     __shared__ float4 part[4][RT * CT][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
-    const int rg = blockIdx.x / ncolblocks, cb = blockIdx.x - rg * ncolblocks;
+    const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;   // row group fastest: see the launcher (XCD L2 reuse)
+    if (rg >= nrg) return;
     const int col0 = cb * (CT * 16);
     const int tile0 = rg * RT;
     const int nchunks = K >> 4;
