@@ -53,6 +53,12 @@ def lib():
     L.cliora_chart_backward.restype = i32
     L.cliora_inside_pair_states.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.cliora_inside_pair_states.restype = i32
+    L.cliora_plan_vl_workspace_bytes.argtypes = [vp]
+    L.cliora_plan_vl_workspace_bytes.restype = sz
+    L.cliora_vl_scores_forward.argtypes = [vp] + [vp] * 5 + [i32, vp, vp, vp, sz, vp]
+    L.cliora_vl_scores_forward.restype = i32
+    L.cliora_vl_scores_backward.argtypes = [vp] + [vp] * 5 + [i32] + [vp] * 6 + [vp, sz, vp]
+    L.cliora_vl_scores_backward.restype = i32
     L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
     L.cliora_cky_decode.restype = i32
     L.cliora_prof_enable.argtypes = [i32, i32]

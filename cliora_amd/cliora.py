@@ -1,0 +1,184 @@
+"""MI355X-native drop-in for ``cliora.net.cliora.DioraMLP`` (cliora/net/cliora.py:205-488):
+the vision-language chart model.  Same constructor and
+``forward(x_span, x_word, obj_embed_span, obj_embed_word) -> None``; besides the six charts it
+leaves ``all_atten_score (B,B,C,R)``, ``vg_atten_score (B,B,L,R)`` and ``atten_score (B,L,R)``
+on the module (cliora.py:453-468).
+
+Two autograd nodes, both HIP behind the C ABI: the chart (with the AttentionHead residual at
+the leaves and in every inside aggregate, cliora.py:28-42, 71-80, 140-157) and the
+span-region / word-region scorers.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .diora import DioraBase, ComposeMLP, Bilinear, Chart, _ptr, _stream, _param_struct
+from .index import Index
+
+DROPOUT_P = 0.1   # AttentionHead: nn.Dropout(0.1), cliora.py:32
+
+
+class VLChartFunction(torch.autograd.Function):
+    """cliora_chart_forward / _backward with image regions (R > 0)."""
+
+    @staticmethod
+    def forward(ctx, plan, holder, run_outside, x_span, obj_span, drop_mask, *params):
+        if not x_span.is_cuda:
+            raise _lib.ChartLibError('the chart path runs on the GPU only (got a CPU tensor)')
+        B, L, D, Cc = plan.B, plan.L, plan.D, plan.C
+        x_span = x_span.contiguous().float()
+        obj_span = obj_span.contiguous().float()
+        drop_mask = drop_mask.contiguous().float() if drop_mask is not None else None
+        ptens = {n: (p.detach().contiguous() if p is not None else None) for n, p in zip(_lib.PARAM_FIELDS, params)}
+        dev = x_span.device
+        inside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
+        inside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
+        outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
+        outside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
+        inside_c = torch.zeros((B, Cc, D), device=dev, dtype=torch.float32)
+        ws = torch.empty(plan.fwd_bytes, device=dev, dtype=torch.uint8)
+        pst = _param_struct(ptens)
+        rc = _lib.lib().cliora_chart_forward(plan.handle, C.byref(pst), _ptr(x_span), _ptr(obj_span), _ptr(drop_mask),
+                                            _ptr(inside_h), _ptr(inside_s), _ptr(outside_h), _ptr(outside_s), _ptr(inside_c),
+                                            _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
+        _lib.check(rc, 'cliora_chart_forward')
+        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens, ctx.drop_mask = plan, int(run_outside), ws, ptens, drop_mask
+        ctx.save_for_backward(x_span, obj_span, inside_h, inside_s, outside_h, outside_s)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(inside_c)
+        holder.clear()
+        holder.append(ws)
+        return inside_h, inside_s, outside_h, outside_s, inside_c
+
+    @staticmethod
+    def backward(ctx, d_ih, d_is, d_oh, d_os, _d_ic):
+        plan = ctx.plan
+        x_span, obj_span, inside_h, inside_s, outside_h, outside_s = ctx.saved_tensors
+        dev = x_span.device
+        cont = lambda g: g.contiguous().float() if g is not None else None
+        d_ih, d_is, d_oh, d_os = cont(d_ih), cont(d_is), cont(d_oh), cont(d_os)
+        grads = {n: (torch.empty_like(t) if t is not None else None) for n, t in ctx.ptens.items()}
+        d_x = torch.empty_like(x_span)
+        d_obj = torch.empty_like(obj_span)
+        wsb = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)
+        pst, gst = _param_struct(ctx.ptens), _param_struct(grads)
+        rc = _lib.lib().cliora_chart_backward(plan.handle, C.byref(pst), _ptr(x_span), _ptr(obj_span), _ptr(ctx.drop_mask),
+                                             _ptr(inside_h), _ptr(inside_s), _ptr(outside_h), _ptr(outside_s),
+                                             _ptr(d_ih), _ptr(d_is), _ptr(d_oh), _ptr(d_os),
+                                             _ptr(ctx.ws), plan.fwd_bytes, _ptr(wsb), plan.bwd_bytes,
+                                             _ptr(d_x), _ptr(d_obj), C.byref(gst), ctx.run_outside, _stream())
+        _lib.check(rc, 'cliora_chart_backward')
+        return (None, None, None, d_x, d_obj, None) + tuple(grads[n] for n in _lib.PARAM_FIELDS)
+
+
+class VLScoreFunction(torch.autograd.Function):
+    """cliora_vl_scores_forward / _backward: the einsum('abx,cdx->acbd') scorers of cliora.py:453-466."""
+
+    @staticmethod
+    def forward(ctx, plan, training, inside_h, outside_h, obj_span, x_word, obj_word):
+        B, L, Cc, R = plan.B, plan.L, plan.C, plan.R
+        tens = [t.contiguous().float() for t in (inside_h, outside_h, obj_span, x_word, obj_word)]
+        dev = tens[0].device
+        all_att = torch.empty((B, B, Cc, R), device=dev, dtype=torch.float32)
+        vg = torch.empty((B, B, L, R), device=dev, dtype=torch.float32)
+        nbytes = _lib.lib().cliora_plan_vl_workspace_bytes(plan.handle)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_forward(plan.handle, *[_ptr(t) for t in tens], int(training), _ptr(all_att), _ptr(vg),
+                                                _ptr(ws), nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_forward')
+        ctx.plan, ctx.training, ctx.nbytes = plan, int(training), nbytes
+        ctx.save_for_backward(*tens)
+        ctx.set_materialize_grads(False)
+        return all_att, vg
+
+    @staticmethod
+    def backward(ctx, d_all, d_vg):
+        plan = ctx.plan
+        inside_h, outside_h, obj_span, x_word, obj_word = ctx.saved_tensors
+        dev = inside_h.device
+        cont = lambda g: g.contiguous().float() if g is not None else None
+        d_all, d_vg = cont(d_all), cont(d_vg)
+        d_sum = torch.empty_like(inside_h)
+        d_obj_span = torch.empty_like(obj_span)
+        d_x_word = torch.empty_like(x_word)
+        d_obj_word = torch.empty_like(obj_word)
+        ws = torch.empty(ctx.nbytes, device=dev, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_backward(plan.handle, _ptr(inside_h), _ptr(outside_h), _ptr(obj_span), _ptr(x_word),
+                                                 _ptr(obj_word), ctx.training, _ptr(d_all), _ptr(d_vg), _ptr(d_sum),
+                                                 _ptr(d_obj_span), _ptr(d_x_word), _ptr(d_obj_word), _ptr(ws), ctx.nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_backward')
+        return None, None, d_sum, d_sum, d_obj_span, d_x_word, d_obj_word
+
+
+class AttentionHead(nn.Module):
+    """Parameter-free; kept for the module tree and the dropout rate (cliora.py:28-42)."""
+
+    def __init__(self, q_dim, k_dim, v_dim, h_dim):
+        super().__init__()
+        self.h_dim = h_dim
+        self.dropout = nn.Dropout(DROPOUT_P)
+
+
+class VLComposeMLP(ComposeMLP):
+    pass
+
+
+class DioraMLP(DioraBase):
+    vision_language = True
+
+    def init_parameters(self):
+        self.atten_head = AttentionHead(self.size, self.size, self.size, self.size)
+        self.inside_score_func = Bilinear(self.size)
+        self.inside_compose_func = VLComposeMLP(self.size, leaf=True)
+        if self.share:
+            self.outside_score_func = self.inside_score_func
+            self.outside_compose_func = self.inside_compose_func
+        else:
+            self.outside_score_func = Bilinear(self.size)
+            self.outside_compose_func = VLComposeMLP(self.size)
+        self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
+        self.root_vector_out_c = None
+        self.dropout_mask = None      # tests inject a (B, C, R) pre-scaled mask here; None = draw one per forward
+
+    def get_chart_wrapper(self):
+        return self
+
+    def forward(self, x_span, x_word, obj_embed_span=None, obj_embed_word=None):
+        if self.index is None:
+            self.index = Index(cuda=self.is_cuda)
+        self.reset()
+        if obj_embed_span is None:
+            raise ValueError('the CLIORA module needs obj_embed_span (use cliora_amd.diora.DioraMLP for text only)')
+        B, L, D = x_span.shape
+        R = obj_embed_span.shape[1]
+        assert D == self.size
+        dev_index = x_span.device.index if x_span.is_cuda else -1
+        plan = _lib.get_plan(B, L, D, self.share, self.normalize, R, dev_index)
+        mask = None
+        if self.training:
+            mask = self.dropout_mask
+            if mask is None:   # same distribution as nn.Dropout(0.1) on the (.., R) probabilities
+                mask = F.dropout(torch.ones((B, plan.C, R), device=x_span.device), DROPOUT_P, True)
+        holder = []
+        ih, is_, oh, os_, ic = VLChartFunction.apply(plan, holder, bool(self.outside), x_span, obj_embed_span, mask,
+                                                     *self._param_tensors())
+        ch = Chart()
+        ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s, ch.inside_c = ih, is_, oh, os_, ic
+        ch.outside_c = torch.zeros_like(oh)
+        self.chart = ch
+        self._wss, self._plan, self._nchunks = holder, plan, 1
+        self.init_with_batch(ih[:, :L], ic[:, :L])
+        if self._hook_overridden('inside_hook'):
+            for level in range(1, L):
+                h, s = self.pair_states(level)
+                self.inside_hook(level, h, torch.zeros_like(h), s)
+        # cliora.py:453-468
+        all_att, vg = VLScoreFunction.apply(plan, self.training, ih, oh, obj_embed_span, x_word, obj_embed_word)
+        self.all_atten_score = all_att
+        self.vg_atten_score_word = vg
+        self.vg_atten_score = vg
+        self.atten_score = torch.diagonal(vg, 0, 0, 1).permute(2, 0, 1)
+        return None

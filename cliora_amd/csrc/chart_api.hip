@@ -12,6 +12,7 @@
 
 #include "../../include/cliora_chart.h"
 #include "chart_kernels.hpp"
+#include "vl_kernels.hpp"
 #include "gemm_kernels.hpp"
 #include "plan.hpp"
 
@@ -364,11 +365,12 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                     const float* drop_mask, float* inside_h, float* inside_s, float* outside_h,
                                     float* outside_s, float* inside_c, void* fwd_ws, size_t fwd_ws_bytes, int run_outside,
                                     void* stream) {
-    (void)obj_span; (void)drop_mask; (void)inside_c;
     if (!plan || !P || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
-    if (p.R != 0) return fail(CLIORA_EINVAL, "CLIORA (R > 0) plans are not implemented in this build");
+    const bool vl = p.R > 0;
+    if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
+    if (!vl && obj_span) return fail(CLIORA_EINVAL, "obj_span given to a text-only plan (R = 0)");
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
     hipStream_t st = (hipStream_t)stream;
     OKR(ensure_uploaded(plan, st));
@@ -382,6 +384,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     float* IS = inside_s;
     float* OS = outside_s;
     const float* X = padded ? ws + f.xp : x_span;
+    const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
     const float* w1o = p.share ? P->in_w1 : P->out_w1;
     if (!p.share && (!P->out_w1 || !P->out_b1 || !P->out_w2 || !P->out_b2 || !P->out_mat))
         return fail(CLIORA_EINVAL, "share=0 needs the out_* parameters");
@@ -419,14 +422,23 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         add_copy(t, ws + f.b2i, Dp, 1, Dp, P->in_b2, D, 1, D, 0, 0, 0);
         add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
+        if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
     OKR(launch_rows_direct(st, ws + f.wl, Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
-    hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, ws + f.t, Dp, B * L, L, C, 0, Dp, p.normalize,
-                       IH, ws + f.nrmi, IS);
-    LAUNCHOK("unit_norm_rows");
+    if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
+        LevelArgs g0 = level_args(p, 0, false);
+        hipLaunchKernelGGL(cell_attend_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, g0, L, (const float*)nullptr, (const float*)nullptr,
+                           ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
+                           inside_c, D, IS);
+        LAUNCHOK("cell_attend_fwd(leaves)");
+    } else {
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, ws + f.t, Dp, B * L, L, C, 0, Dp, p.normalize,
+                           IH, ws + f.nrmi, IS);
+        LAUNCHOK("unit_norm_rows");
+    }
     if (L > 1)
         OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
@@ -444,9 +456,16 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                             ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi, ws + f.x, Dp},
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
-        hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, IH,
-                           ws + f.nrmi);
-        LAUNCHOK("cell_aggregate_fwd");
+        if (vl) {   // cliora.py:140-157: aggregate, attention residual, second unit norm
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, L, ws + f.y, ws + f.pp, (const float*)nullptr,
+                               OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
+                               (float*)nullptr, D, IS);
+            LAUNCHOK("cell_attend_fwd");
+        } else {
+            hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, IH,
+                               ws + f.nrmi);
+            LAUNCHOK("cell_aggregate_fwd");
+        }
         if (level < L - 1)
             OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                             StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
@@ -498,11 +517,12 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                      const float* d_inside_s, const float* d_outside_h, const float* d_outside_s,
                                      void* fwd_ws, size_t fwd_ws_bytes, void* bwd_ws, size_t bwd_ws_bytes, float* d_x_span,
                                      float* d_obj_span, const cliora_params* G, int ran_outside, void* stream) {
-    (void)obj_span; (void)drop_mask; (void)d_obj_span; (void)P;
+    (void)P;
     if (!plan || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws || !bwd_ws || !G)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
-    if (p.R != 0) return fail(CLIORA_EINVAL, "CLIORA (R > 0) plans are not implemented in this build");
+    const bool vl = p.R > 0;
+    if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
     if (bwd_ws_bytes < p.bwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "backward workspace too small");
     if (!plan->uploaded) return fail(CLIORA_EINVAL, "backward called before forward");
@@ -523,6 +543,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
     const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po, *Xp = ws + f.x;
     float* DZ = wb + bw.dz;
+    const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
+    // CLIORA: the unit-norm / softmax backward of the inside cells works on u = unit(aggregate), not on h
+    const float* IHn = vl ? ws + f.att_u : IH;
+    const float* nrmIn = vl ? ws + f.att_nrmu : ws + f.nrmi;
 
     if (ran_outside) {
         for (int level = 0; level <= L - 1; ++level) {
@@ -572,8 +596,13 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         if (level <= L - 2)
             OKR(launch_rows_direct(st, ws + f.wcatT, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (vl) {
+            hipLaunchKernelGGL(cell_attend_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
+                               drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
+            LAUNCHOK("cell_attend_bwd");
+        }
         if (level == 0) break;
-        hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, Y, Sp, Pp, IS,
+        hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, Y, Sp, Pp, IS,
                            dStot, dG, DS);
         LAUNCHOK("cell_scores_bwd(in)");
         {
@@ -583,7 +612,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         }
     }
     // leaves
-    hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IH, ws + f.nrmi, p.normalize, ws + f.t, dU);
+    hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
         OKR(launch_rows_direct(st, ws + f.wlT, Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
@@ -601,10 +630,17 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                   wb + bw.gbcat));
     OKR(launch_tn(st, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
 
+    if (vl && d_obj_span) {
+        float* dO = padded ? wb + bw.dobjp : d_obj_span;
+        hipLaunchKernelGGL(obj_grad_reduce, dim3(B, (p.R + 3) / 4), dim3(256), 0, st, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo,
+                           wb + bw.dsc, dO);
+        LAUNCHOK("obj_grad_reduce");
+    }
     // ---- scatter packed gradients back to the reference parameter shapes ----
     {
         CopyTable t; t.n = 0;
         const size_t DD = (size_t)Dp * Dp;
+        if (vl && d_obj_span && padded) add_copy(t, d_obj_span, D, B * p.R, D, wb + bw.dobjp, Dp, B * p.R, D, 0, 0, 0);
         if (G->leaf_w) add_copy(t, G->leaf_w, D, D, D, wb + bw.gwl, Dp, D, D, 0, 0, 0);
         if (G->leaf_b) add_copy(t, G->leaf_b, D, 1, D, wb + bw.gbl, Dp, 1, D, 0, 0, 0);
         if (G->root_h) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
@@ -636,6 +672,144 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             if (G->out_b2) add_copy(t, G->out_b2, D, 1, D, wb + bw.gb2o, Dp, 1, D, 0, 0, 0);
         }
         OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ CLIORA span-region / word-region scorers
+extern "C" size_t cliora_plan_vl_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.vl.total * sizeof(float) : 0; }
+
+// C[i][j] = sum_r A(r,i) B(r,j) with different tile counts per side (register-only split-K kernel)
+template <int TI, int TJ, class AP, class BP>
+static int launch_tn_ij(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats, float* out) {
+    const int blocks = (Mi / (TI * 16)) * (Nj / (TJ * 16));
+    const size_t per_slice = (size_t)Mi * Nj;
+    int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 2048 / blocks));
+    nsl = std::min(nsl, (nrows + 15) / 16);
+    nsl = std::max(4, nsl / 4 * 4);
+    if ((size_t)nsl * per_slice > slab_floats) return fail(CLIORA_ENOMEM, "slab too small for the region-gradient GEMM");
+    int rps = (nrows + nsl - 1) / nsl;
+    rps = (rps + 3) / 4 * 4;
+    hipLaunchKernelGGL((tn_gemm<TI, TJ, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab,
+                       (float*)nullptr);
+    LAUNCHOK("tn_gemm(ij)");
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((per_slice + 255) / 256)), dim3(256), 0, st, slab, nsl, per_slice, out);
+    LAUNCHOK("slab_reduce");
+    return CLIORA_OK;
+}
+template <class AP, class BP>
+static int launch_tn_regions(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats, float* out) {
+    const int ti = (Mi / 16) % 4 == 0 ? 4 : ((Mi / 16) % 2 == 0 ? 2 : 1);
+    const int tj = pick_tiles(Nj / 16);
+#define RG_CASE(a, b) if (ti == a && tj == b) return launch_tn_ij<a, b>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out)
+    RG_CASE(4, 5); RG_CASE(4, 4); RG_CASE(4, 2); RG_CASE(4, 1);
+    RG_CASE(2, 5); RG_CASE(2, 4); RG_CASE(2, 2); RG_CASE(2, 1);
+    RG_CASE(1, 5); RG_CASE(1, 4); RG_CASE(1, 2); RG_CASE(1, 1);
+#undef RG_CASE
+    return fail(CLIORA_EINVAL, "unsupported region-gradient tile shape");
+}
+
+// reduction over the (padded) region axis: split it into LDS-sized segments
+static void region_segments(int NRp, int ncols, int* Kseg, int* nseg) {
+    const int ct = pick_tiles(ncols / 16);
+    for (int n = 1; n <= NRp / 16; ++n) {
+        if (NRp % n || (NRp / n) % 16) continue;
+        if ((size_t)ct * 16 * (NRp / n) * sizeof(float) <= 150 * 1024) { *Kseg = NRp / n; *nseg = n; return; }
+    }
+    *Kseg = 16; *nseg = NRp / 16;
+}
+
+struct VlViews { float *oall, *oallT, *wall, *wallT, *sump, *xwp, *xwn, *nrm, *gobj, *slab; };
+static VlViews vl_views(const Plan& p, void* ws) {
+    float* w = (float*)ws;
+    const auto& v = p.vl;
+    return VlViews{w + v.oall, w + v.oallT, w + v.wall, w + v.wallT, w + v.sump, w + v.xwp, w + v.xwn, w + v.nrm, w + v.gobj, w + v.slab};
+}
+
+extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
+                                        const float* x_word, const float* obj_word, int training, float* all_atten,
+                                        float* vg_atten, void* vl_ws, size_t vl_ws_bytes, void* stream) {
+    if (!plan || !inside_h || !outside_h || !obj_span || !all_atten || !vl_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.R <= 0) return fail(CLIORA_EINVAL, "the scorers need a CLIORA plan (R > 0)");
+    if (vl_ws_bytes < p.vl.total * sizeof(float)) return fail(CLIORA_ENOMEM, "VL workspace too small");
+    if (vg_atten && (!x_word || !obj_word)) return fail(CLIORA_EINVAL, "vg_atten needs x_word and obj_word");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
+    const bool padded = D != Dp;
+    const VlViews v = vl_views(p, vl_ws);
+    {
+        CopyTable t; t.n = 0;
+        add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
+        if (vg_atten) add_copy(t, v.wall, Dp, NRp, Dp, obj_word, D, B * R, D, 0, 0, 0);
+        if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
+        if (vg_atten && (padded || !training)) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
+    OKR(launch_rows(st, v.oall, Dp, 1, NRp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
+    if (vg_atten) {
+        if (training) {
+            const SumRowsA xw = SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
+            OKR(launch_rows(st, v.wall, Dp, 1, NRp, B * L, xw, ScoreStoreE{vg_atten, B, L, R, nullptr, 0}));
+        } else {   // eval: all_atten[:, :, :L] + unit(x_word) . obj_word   (cliora.py:462-464)
+            hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, v.xwp, Dp, B * L, B * L, 0, 0, Dp, p.normalize,
+                               v.xwn, v.nrm, v.nrm + B * L);
+            LAUNCHOK("unit_norm_rows(x_word)");
+            OKR(launch_rows(st, v.wall, Dp, 1, NRp, B * L, SumRowsA{v.xwn, nullptr, Dp}, ScoreStoreE{vg_atten, B, L, R, all_atten, C}));
+        }
+    }
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
+                                         const float* x_word, const float* obj_word, int training, const float* d_all,
+                                         const float* d_vg, float* d_sum_h, float* d_obj_span, float* d_x_word, float* d_obj_word,
+                                         void* vl_ws, size_t vl_ws_bytes, void* stream) {
+    if (!plan || !inside_h || !outside_h || !obj_span || !vl_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.R <= 0) return fail(CLIORA_EINVAL, "the scorers need a CLIORA plan (R > 0)");
+    if (vl_ws_bytes < p.vl.total * sizeof(float)) return fail(CLIORA_ENOMEM, "VL workspace too small");
+    if (!training && d_vg) return fail(CLIORA_EINVAL, "eval-mode vg_atten has no backward (the reference runs it under no_grad)");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
+    const bool padded = D != Dp;
+    const VlViews v = vl_views(p, vl_ws);
+    {   // transposed region matrices: W[j][k] = O[k][j], k padded with zero rows
+        CopyTable t; t.n = 0;
+        add_copy(t, v.oallT, NRp, Dp, NRp, obj_span, D, B * R, D, 0, 0, 1);
+        if (d_vg) add_copy(t, v.wallT, NRp, Dp, NRp, obj_word, D, B * R, D, 0, 0, 1);
+        if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
+        if (d_vg && padded) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
+    int Kseg = NRp, nseg = 1;
+    region_segments(NRp, Dp, &Kseg, &nseg);
+    if (d_sum_h) {
+        if (d_all) OKR(launch_rows(st, v.oallT, Kseg, nseg, Dp, B * C, ScoreGradA{d_all, B, C, R}, StoreAccE{d_sum_h, D, D, 0}));
+        else HIPOK(hipMemsetAsync(d_sum_h, 0, (size_t)B * C * D * sizeof(float), st));
+    }
+    if (d_obj_span) {
+        if (d_all) {
+            OKR(launch_tn_regions(st, B * C, NRp, Dp, ScoreGradA{d_all, B, C, R}, sumA, v.slab, p.vl.slab_floats, v.gobj));
+            CopyTable t; t.n = 0;
+            add_copy(t, d_obj_span, D, B * R, D, v.gobj, Dp, B * R, D, 0, 0, 0);
+            OKR(run_copies(st, t));
+        } else HIPOK(hipMemsetAsync(d_obj_span, 0, (size_t)B * R * D * sizeof(float), st));
+    }
+    if (d_x_word) {
+        if (d_vg) OKR(launch_rows(st, v.wallT, Kseg, nseg, Dp, B * L, ScoreGradA{d_vg, B, L, R}, StoreAccE{d_x_word, D, D, 0}));
+        else HIPOK(hipMemsetAsync(d_x_word, 0, (size_t)B * L * D * sizeof(float), st));
+    }
+    if (d_obj_word) {
+        if (d_vg) {
+            const SumRowsA xw = SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
+            OKR(launch_tn_regions(st, B * L, NRp, Dp, ScoreGradA{d_vg, B, L, R}, xw, v.slab, p.vl.slab_floats, v.gobj));
+            CopyTable t; t.n = 0;
+            add_copy(t, d_obj_word, D, B * R, D, v.gobj, Dp, B * R, D, 0, 0, 0);
+            OKR(run_copies(st, t));
+        } else HIPOK(hipMemsetAsync(d_obj_word, 0, (size_t)B * R * D * sizeof(float), st));
     }
     return CLIORA_OK;
 }

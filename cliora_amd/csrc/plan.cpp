@@ -146,9 +146,9 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.pp = take(Rt);
         f.nrmi = take(BC);
         f.nrmo = take(BC);
-        // CLIORA per-cell attention state: pre-attention unit vector u (Dp), probabilities after
-        // dropout (R, padded to 64), and two norms.
-        f.att = take(R > 0 ? BC * (Dp + 64 + 4) : 0);
+        f.att_u = take(R > 0 ? BC * Dp : 0);
+        f.att_pk = take(R > 0 ? BC * 64 : 0);
+        f.att_nrmu = take(R > 0 ? BC : 0);
         f.total = o;
     }
     {
@@ -166,8 +166,26 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.gwcat = take(nb * Dp * Dp); b.gbcat = take(nb * Dp); b.gw1ro = take(Dp * Dp);
         b.gw2i = take(Dp * Dp); b.gb2i = take(Dp); b.gw2o = take(Dp * Dp); b.gb2o = take(Dp);
         b.gwl = take(Dp * Dp); b.gbl = take(Dp); b.groot = take(Dp);
+        b.dctx = take(R > 0 ? BC * Dp : 0);
+        b.pmo = take(R > 0 ? BC * 64 : 0);
+        b.dsc = take(R > 0 ? BC * 64 : 0);
         b.dobjp = take(R > 0 ? (size_t)B * R * Dp : 0);
         b.total = o;
+    }
+    {
+        auto& v = p.vl;
+        size_t o = 0;
+        auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
+        v.NRp = ((B * R + 15) / 16) * 16;
+        const size_t NR = (size_t)v.NRp;
+        const size_t on = R > 0 ? 1 : 0;
+        v.oall = take(on * NR * Dp); v.oallT = take(on * NR * Dp);
+        v.wall = take(on * NR * Dp); v.wallT = take(on * NR * Dp);
+        v.sump = take(on * BC * Dp); v.xwp = take(on * BL * Dp); v.xwn = take(on * BL * Dp); v.nrm = take(on * 4 * BL);
+        v.gobj = take(on * NR * Dp);
+        v.slab_floats = on * (8 * (NR * Dp) + 64);
+        v.slab = take(v.slab_floats);
+        v.total = o;
     }
     return "";
 }

@@ -43,7 +43,7 @@ struct FwdLayout {
     size_t x;                           // per-pair first-layer activation relu(PL+PR) (R x Dp)
     size_t sp, pp;                      // per-pair score / softmax weight (R)
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
-    size_t att;                         // CLIORA: per-cell attention state (see kernels_vl)
+    size_t att_u, att_pk, att_nrmu;     // CLIORA per inside cell: u = unit(aggregate) (B*C x Dp), region probabilities (B*C x 64), |aggregate| (B*C)
     size_t total;
 };
 
@@ -55,7 +55,7 @@ struct BwdLayout {
     size_t du, dxp;                     // leaf pre-activation grad, padded dx
     size_t slab;                        // split-K partial sums for the weight-gradient GEMMs
     size_t gwcat, gbcat, gw1ro, gw2i, gb2i, gw2o, gb2o, gwl, gbl, groot;   // packed parameter grads
-    size_t dobjp;                       // CLIORA
+    size_t dctx, pmo, dsc, dobjp;       // CLIORA: d context (B*C x Dp), p*mask and d score per region (B*C x 64 each), d obj (B*R x Dp)
     size_t total;
     size_t slab_floats;
 };
@@ -76,6 +76,8 @@ struct Plan {
     std::vector<int32_t> arow, brow, trow;
     FwdLayout fwd;
     BwdLayout bwd;
+    // span-region scorer workspace (floats): padded/transposed region matrices, padded sum rows, slabs
+    struct VlLayout { size_t oall, oallT, wall, wallT, sump, xwp, xwn, nrm, gobj, slab, slab_floats, total; int NRp; } vl;
 
     // device copies (filled lazily by the HIP side)
     int32_t* d_tables = nullptr;

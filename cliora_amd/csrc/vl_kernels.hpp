@@ -1,0 +1,314 @@
+// CLIORA (vision-language) additions to the chart engine (gfx950).
+//
+//   AttentionHead.forward            cliora/net/cliora.py:28-42
+//       score_k = q . o_k  (k over the R image regions of the SAME sentence -- the reference
+//       computes all B x B sentence/image pairs and keeps the diagonal, :37-39),
+//       prob = softmax_k(score), dropout(0.1) in training, context = sum_k prob_k o_k
+//   VLComposeMLP.leaf_transform      cliora.py:71-80, 290-301   h = unit(unit(tanh(fc x)) + ctx), c = unit(ctx)
+//   inside_aggregate                 cliora.py:140-157          h = unit(unit(sum_n p_n y_n) + ctx)
+//   span-region / word-region scorers  cliora.py:453-468       einsum('abx,cdx->acbd', ...)
+//
+// One wavefront per chart cell; the R region vectors of the sentence (R x D, 58 kB at R=36, D=400)
+// are read from L2 twice per cell (scores, then context), four regions in flight.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chart_kernels.hpp"
+
+namespace cliora {
+
+constexpr int VL_MAXR = 64;     // regions per image (one per lane in the softmax)
+
+// ---------------------------------------------------------------------------------
+// Forward for the inside cells of one level (N > 0: aggregate the N splits first; N == 0: leaves,
+// source = tanh output T).  Writes H = unit(u + ctx), U = u, P = prob (before dropout), the two
+// norms, and for the leaves inside_c = unit(ctx).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const float* __restrict__ Y, const float* __restrict__ Pp,
+                                                       const float* __restrict__ T, const float* __restrict__ OBJ, int R,
+                                                       const float* __restrict__ mask, int normalize,
+                                                       float* __restrict__ H, float* __restrict__ nrmV, float* __restrict__ U,
+                                                       float* __restrict__ nrmU, float* __restrict__ PK, float* __restrict__ IC,
+                                                       int icD, float* __restrict__ S) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    float4 v0 = f4zero(), v1 = f4zero();
+    if (g.N == 0) {
+        const float* s = T + ((size_t)b * L + p) * Dp;
+        if (a0) v0 = ld4(s + c0);
+        if (a1) v1 = ld4(s + c1);
+        if (lane == 0) S[crow] = 0.f;
+    } else {
+        const int row0 = g.rowbase + t * g.N;
+        for (int n0 = 0; n0 < g.N; n0 += 4) {
+            float pn[4];
+            float4 y0[4], y1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = min(n0 + j, g.N - 1);
+                pn[j] = (n0 + j < g.N) ? Pp[row0 + n] : 0.f;
+                const float* y = Y + (size_t)(row0 + n) * Dp;
+                y0[j] = a0 ? ld4(y + c0) : f4zero();
+                y1[j] = a1 ? ld4(y + c1) : f4zero();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0 = f4fma(pn[j], y0[j], v0); v1 = f4fma(pn[j], y1[j], v1); }
+        }
+    }
+    // u = unit(v)
+    const float nu = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
+    const float du = normalize ? fmaxf(nu, UNIT_EPS) : 1.f;
+    const float4 u0 = make_float4(v0.x / du, v0.y / du, v0.z / du, v0.w / du);
+    const float4 u1 = make_float4(v1.x / du, v1.y / du, v1.z / du, v1.w / du);
+    // scores over the regions of this sentence
+    const float* ob = OBJ + (size_t)b * R * Dp;
+    float my_sc = -INFINITY;
+    for (int k0 = 0; k0 < R; k0 += 4) {
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* o = ob + (size_t)min(k0 + j, R - 1) * Dp;
+            float s = 0.f;
+            if (a0) s = f4dot(u0, ld4(o + c0));
+            if (a1) s += f4dot(u1, ld4(o + c1));
+            d[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = wave_sum(d[j]);
+            if (lane == k0 + j) my_sc = s;
+        }
+    }
+    const float mx = wave_max(my_sc);
+    const float e = lane < R ? expf(my_sc - mx) : 0.f;
+    const float pk = e / wave_sum(e);
+    const float pm = (mask && lane < R) ? pk * mask[crow * R + lane] : pk;   // pre-scaled dropout mask (0 or 1/(1-p))
+    if (lane < R) PK[crow * VL_MAXR + lane] = pk;
+    // context = sum_k pm_k o_k
+    float4 x0 = f4zero(), x1 = f4zero();
+    for (int k0 = 0; k0 < R; k0 += 4) {
+        float w[4];
+        float4 o0[4], o1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(k0 + j, R - 1);
+            const float pj = __shfl(pm, k);
+            w[j] = (k0 + j < R) ? pj : 0.f;
+            const float* o = ob + (size_t)k * Dp;
+            o0[j] = a0 ? ld4(o + c0) : f4zero();
+            o1[j] = a1 ? ld4(o + c1) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x0 = f4fma(w[j], o0[j], x0); x1 = f4fma(w[j], o1[j], x1); }
+    }
+    // h = unit(u + ctx)
+    const float4 w0 = f4add(u0, x0), w1 = f4add(u1, x1);
+    const float nw = sqrtf(wave_sum(f4dot(w0, w0) + f4dot(w1, w1)));
+    const float dw = normalize ? fmaxf(nw, UNIT_EPS) : 1.f;
+    if (a0) { st4(H + crow * Dp + c0, make_float4(w0.x / dw, w0.y / dw, w0.z / dw, w0.w / dw)); st4(U + crow * Dp + c0, u0); }
+    if (a1) { st4(H + crow * Dp + c1, make_float4(w1.x / dw, w1.y / dw, w1.z / dw, w1.w / dw)); st4(U + crow * Dp + c1, u1); }
+    if (lane == 0) { nrmU[crow] = nu; nrmV[crow] = nw; }
+    if (IC && g.N == 0) {               // leaves: c = unit(ctx)  (cliora.py:79, 299)
+        const float nc = sqrtf(wave_sum(f4dot(x0, x0) + f4dot(x1, x1)));
+        const float dc = normalize ? fmaxf(nc, UNIT_EPS) : 1.f;
+        float* ic = IC + crow * icD;
+        const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c0 + j < icD) ic[c0 + j] = xs[j] / dc;
+            if (a1 && c1 + j < icD) ic[c1 + j] = xs[4 + j] / dc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Backward of the attention residual for the cells of one level.  In: VH = dL/dH (complete).
+//   dv = normbwd(VH; H, |v|);  dctx = dv;  dpm_k = dctx . o_k;  dp = dpm * mask
+//   dsc_k = p_k (dp_k - sum_j p_j dp_j);  du = dv + sum_k dsc_k o_k
+// Out: VH := du (the unit-norm backward through u = unit(g) is done by the kernels that follow,
+// which are handed U / |g| instead of H / |v|), DCTX = dv, and per region PMo = p*mask, DSC = dsc
+// for the per-sentence reduction of d obj (obj_grad_reduce).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __restrict__ VH, const float* __restrict__ H,
+                                                       const float* __restrict__ nrmV, int normalize, const float* __restrict__ OBJ,
+                                                       int R, const float* __restrict__ mask, const float* __restrict__ PK,
+                                                       float* __restrict__ DCTX, float* __restrict__ PMo, float* __restrict__ DSC) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
+    if (a0) { v0 = ld4(VH + crow * Dp + c0); h0 = ld4(H + crow * Dp + c0); }
+    if (a1) { v1 = ld4(VH + crow * Dp + c1); h1 = ld4(H + crow * Dp + c1); }
+    unit_norm_bwd(v0, v1, h0, h1, nrmV[crow], normalize);        // v = dL/d(u + ctx)
+    const float* ob = OBJ + (size_t)b * R * Dp;
+    float dpm = 0.f;
+    for (int k0 = 0; k0 < R; k0 += 4) {
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* o = ob + (size_t)min(k0 + j, R - 1) * Dp;
+            float s = 0.f;
+            if (a0) s = f4dot(v0, ld4(o + c0));
+            if (a1) s += f4dot(v1, ld4(o + c1));
+            d[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = wave_sum(d[j]);
+            if (lane == k0 + j) dpm = s;
+        }
+    }
+    const bool ak = lane < R;
+    const float pk = ak ? PK[crow * VL_MAXR + lane] : 0.f;
+    const float mk = (mask && ak) ? mask[crow * R + lane] : 1.f;
+    const float dp = ak ? dpm * mk : 0.f;
+    const float mean = wave_sum(pk * dp);
+    const float dsc = pk * (dp - mean);
+    if (ak) { PMo[crow * VL_MAXR + lane] = pk * mk; DSC[crow * VL_MAXR + lane] = dsc; }
+    float4 u0 = v0, u1 = v1;
+    for (int k0 = 0; k0 < R; k0 += 4) {
+        float w[4];
+        float4 o0[4], o1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(k0 + j, R - 1);
+            const float dj = __shfl(dsc, k);
+            w[j] = (k0 + j < R) ? dj : 0.f;
+            const float* o = ob + (size_t)k * Dp;
+            o0[j] = a0 ? ld4(o + c0) : f4zero();
+            o1[j] = a1 ? ld4(o + c1) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { u0 = f4fma(w[j], o0[j], u0); u1 = f4fma(w[j], o1[j], u1); }
+    }
+    if (a0) { st4(DCTX + crow * Dp + c0, v0); st4(VH + crow * Dp + c0, u0); }
+    if (a1) { st4(DCTX + crow * Dp + c1, v1); st4(VH + crow * Dp + c1, u1); }
+}
+
+// d obj[b][k][:] = sum over the inside cells of sentence b of  pm[cell][k] * dctx[cell][:] + dsc[cell][k] * u[cell][:]
+// One workgroup per (sentence, 4 regions): wave w owns region 4*blockIdx.y + w; cells in chart order.
+__global__ __launch_bounds__(256) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
+                                                       const float* __restrict__ PMo, const float* __restrict__ DSC,
+                                                       float* __restrict__ dOBJ) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x, k = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (k >= R) return;
+    const int nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    float4 s0 = f4zero(), s1 = f4zero();
+    for (int cc = 0; cc < C; cc += 2) {
+        float pm[2], ds[2];
+        float4 d0[2], d1[2], u0[2], u1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t crow = (size_t)b * C + min(cc + j, C - 1);
+            const bool ok = cc + j < C;
+            pm[j] = ok ? PMo[crow * VL_MAXR + k] : 0.f;
+            ds[j] = ok ? DSC[crow * VL_MAXR + k] : 0.f;
+            d0[j] = a0 ? ld4(DCTX + crow * Dp + c0) : f4zero();
+            d1[j] = a1 ? ld4(DCTX + crow * Dp + c1) : f4zero();
+            u0[j] = a0 ? ld4(U + crow * Dp + c0) : f4zero();
+            u1[j] = a1 ? ld4(U + crow * Dp + c1) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s0 = f4fma(pm[j], d0[j], s0); s1 = f4fma(pm[j], d1[j], s1);
+            s0 = f4fma(ds[j], u0[j], s0); s1 = f4fma(ds[j], u1[j], s1);
+        }
+    }
+    float* o = dOBJ + ((size_t)b * R + k) * Dp;
+    if (a0) st4(o + c0, s0);
+    if (a1) st4(o + c1, s1);
+}
+
+// ---------------------------------------------------------------------------------
+// Functors for the span-region / word-region scorers  einsum('abx,cdx->acbd', Q, O)  (cliora.py:457-466)
+//   Q rows r = (sentence a, cell b), O rows = (image c, region d);  out[a][c][b][d]
+// ---------------------------------------------------------------------------------
+// A rows = sum of two charts (inside_h + outside_h), or a single matrix when Q1 == nullptr
+struct SumRowsA {
+    const float *Q0, *Q1; int ld;
+    struct Ctx { const float *p, *q; };
+    using Raw = Raw2;
+    __device__ Ctx row(int r) const { return Ctx{Q0 + (size_t)r * ld, Q1 ? Q1 + (size_t)r * ld : nullptr}; }
+    __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.p + k), c.q ? ld4(c.q + k) : f4zero()}; }
+    __device__ float4 finish(const Ctx&, const Raw& r) const { return f4add(r.u, r.v); }
+    static constexpr bool kSide = false;
+    __device__ void side(const Ctx&, int, float4) const {}
+    __device__ float val(const Ctx& c, int col) const { return c.p[col] + (c.q ? c.q[col] : 0.f); }
+};
+// out[((a*B + c)*Cq + b)*R + d] = v (+ add[...same index in a (B,B,Cadd,R) tensor])
+struct ScoreStoreE {
+    float* out; int B, Cq, R; const float* add; int Cadd;
+    struct RCtx { int a, b; };
+    __device__ RCtx row(int r) const { const int a = r / Cq; return RCtx{a, r - a * Cq}; }
+    __device__ void put(const RCtx& rc, int col, float v) const {
+        if (col >= B * R) return;
+        const int c = col / R, d = col - c * R;
+        const size_t o = (((size_t)rc.a * B + c) * Cq + rc.b) * R + d;
+        if (add) v += add[(((size_t)rc.a * B + c) * Cadd + rc.b) * R + d];
+        out[o] = v;
+    }
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
+        if ((R & 3) == 0 && col + 3 < B * R && !add) {
+            const int c = col / R, d = col - c * R;
+            st4(out + (((size_t)rc.a * B + c) * Cq + rc.b) * R + d, v);
+            return;
+        }
+        put(rc, col, v.x); put(rc, col + 1, v.y); put(rc, col + 2, v.z); put(rc, col + 3, v.w);
+    }
+};
+// A(r, k) = dScore[a][c][b][d] with r = (a, b), k = (c, d); k >= B*R reads as zero
+struct ScoreGradA {
+    const float* G; int B, Cq, R;
+    struct Ctx { const float* base; };
+    using Raw = float4;
+    __device__ Ctx row(int r) const { const int a = r / Cq, b = r - a * Cq; return Ctx{G + ((size_t)a * B * Cq + b) * R}; }
+    __device__ float val(const Ctx& c, int k) const {
+        if (k >= B * R) return 0.f;
+        const int cc = k / R, d = k - cc * R;
+        return c.base[(size_t)cc * Cq * R + d];
+    }
+    __device__ Raw fetch(const Ctx& c, int k) const {
+        if ((R & 3) == 0 && k + 3 < B * R) {
+            const int cc = k / R, d = k - cc * R;
+            return ld4(c.base + (size_t)cc * Cq * R + d);
+        }
+        return make_float4(val(c, k), val(c, k + 1), val(c, k + 2), val(c, k + 3));
+    }
+    __device__ float4 finish(const Ctx&, const Raw& v) const { return v; }
+    static constexpr bool kSide = false;
+    __device__ void side(const Ctx&, int, float4) const {}
+};
+// adds the optional second matrix row-wise:  out[r][col] = v (+ prev)   plain (rows x ld) store with accumulate flag
+struct StoreAccE {
+    float* out; int ld, ncols, accumulate;
+    struct RCtx { float* o; };
+    __device__ RCtx row(int r) const { return RCtx{out + (size_t)r * ld}; }
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
+        if ((ld & 3) == 0 && col + 3 < ncols) {
+            if (accumulate) v = f4add(v, ld4(rc.o + col));
+            st4(rc.o + col, v);
+            return;
+        }
+        const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (col + j < ncols) rc.o[col + j] = vs[j] + (accumulate ? rc.o[col + j] : 0.f);
+    }
+};
+
+}  // namespace cliora

@@ -85,9 +85,9 @@ int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t**
  * root init + outside pass (diora.py:283-398).
  *   x_span     (B,L,D)   in
  *   obj_span   (B,R,D)   in, CLIORA only (else NULL)
- *   drop_mask  CLIORA training only: pre-scaled dropout masks (0 or 1/(1-p)) for the
- *              AttentionHead (cliora.py:32,40), concatenated per call site: leaves
- *              (B,L,R) then inside levels 1..L-1 (B,L-level,R); NULL = no dropout (eval)
+ *   drop_mask  CLIORA training only: pre-scaled dropout mask (0 or 1/(1-p)) of the
+ *              AttentionHead (cliora.py:32,40) for every inside cell, laid out like the chart:
+ *              (B,C,R), leaves first; NULL = no dropout (eval)
  *   inside_h/outside_h (B,C,D), inside_s/outside_s (B,C)   out
  *   inside_c   (B,C,D)   out, CLIORA only (else NULL): unit(context) at the leaves, 0 above
  * For DioraMLP the c charts are identically zero (diora.py:70); the caller zero-fills
@@ -113,6 +113,25 @@ int cliora_chart_backward(cliora_plan* plan, const cliora_params* params,
                           void* bwd_workspace, size_t bwd_workspace_bytes,
                           float* d_x_span, float* d_obj_span, const cliora_params* grads,
                           int ran_outside, void* stream);
+
+/* CLIORA span-region / word-region scorers (cliora/net/cliora.py:453-468):
+ *   all_atten (B,B,C,R) = einsum('abx,cdx->acbd', inside_h + outside_h, obj_span)
+ *   training != 0:  vg_atten (B,B,L,R) = einsum('abx,cdx->acbd', x_word, obj_word)
+ *   training == 0:  vg_atten = all_atten[:, :, :L] + einsum(unit(x_word), obj_word)
+ * (atten_score is the a == c diagonal of vg_atten: a view, left to the caller.)
+ * Backward: d_sum_h (B,C,D) is the gradient w.r.t. (inside_h + outside_h) -- it goes to both
+ * charts; d_obj_span, d_obj_word (B,R,D), d_x_word (B,L,D; training mode only).  NULL cotangents
+ * are zero; NULL outputs are skipped. */
+size_t cliora_plan_vl_workspace_bytes(const cliora_plan* plan);
+int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h, const float* outside_h,
+                             const float* obj_span, const float* x_word, const float* obj_word,
+                             int training, float* all_atten, float* vg_atten,
+                             void* vl_workspace, size_t vl_workspace_bytes, void* stream);
+int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_h, const float* outside_h,
+                              const float* obj_span, const float* x_word, const float* obj_word,
+                              int training, const float* d_all_atten, const float* d_vg_atten,
+                              float* d_sum_h, float* d_obj_span, float* d_x_word, float* d_obj_word,
+                              void* vl_workspace, size_t vl_workspace_bytes, void* stream);
 
 /* Un-aggregated per-split tensors the reference hands to inside_hook (diora.py:295-334)
  * for `level`: scores = (B, L-level, level) laid out exactly like the reference's

@@ -251,7 +251,7 @@ def contrastive_loss(inside_s, outside_s, all_atten_score, margin=0.2, alpha=1.0
     d2 = diag.transpose(1, 2).expand_as(sc)
     lt = (margin + sc - d1).clamp(min=min_val)
     li = (margin + sc - d2).clamp(min=min_val)
-    eye = (torch.eye(B) > 0.5).unsqueeze(0).expand_as(sc)
+    eye = (torch.eye(B, device=sc.device) > 0.5).unsqueeze(0).expand_as(sc)
     lt = lt.masked_fill(eye, 0).mean(2)
     li = li.masked_fill(eye, 0).mean(1)
     vl = (lt + li).t()
@@ -263,7 +263,7 @@ def vg_loss(vg_atten_score, alpha=1.0):
     """VGLoss.forward, trainer.py:139-171 (variant V1)."""
     B, _, L, _ = vg_atten_score.shape
     logits = vg_atten_score.max(-1).values.sum(-1) / L
-    return alpha * F.cross_entropy(logits, torch.arange(B))
+    return alpha * F.cross_entropy(logits, torch.arange(B, device=logits.device))
 
 
 # --------------------------------------------------------------------------

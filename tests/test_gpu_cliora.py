@@ -1,0 +1,139 @@
+"""GPU parity of the CLIORA (vision-language) path against the golden vectors captured from
+cliora/net/cliora.py + trainer.py losses (tests/golden/cliora_small.npz) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_from_golden
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL = 1e-4
+GRAD_TOL = 2e-4
+OUTS = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s',
+        'all_atten_score', 'vg_atten_score', 'atten_score')
+
+
+def _module(g, share=True):
+    from cliora_amd.cliora import DioraMLP
+    P = params_from_golden(g)
+    m = DioraMLP(g['meta']['D'], outside=True, normalize='unit', compress=False, share=share)
+    sd = m.state_dict()
+    for k in sd:
+        sd[k] = P[k].clone()
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def _inputs(g, rg=False):
+    t = {k: torch.from_numpy(g[k].copy()).cuda() for k in ('x_span', 'x_word', 'obj_span', 'obj_word')}
+    if rg:
+        for v in t.values():
+            v.requires_grad_(True)
+    return t
+
+
+def _err(a, b):
+    a = a.detach().float().cpu().numpy()
+    return float(np.abs(a - np.asarray(b)).max())
+
+
+def _scale(b):
+    return max(1.0, float(np.abs(np.asarray(b)).max()))
+
+
+def test_cliora_eval_outputs_and_trees():
+    g = load_golden('cliora_small.npz')
+    m = _module(g).eval()
+    t = _inputs(g)
+    with torch.no_grad():
+        m(t['x_span'], t['x_word'], t['obj_span'], t['obj_word'])
+    for k in OUTS:
+        assert _err(getattr(m, k), g['eval__' + k]) <= OUT_TOL * _scale(g['eval__' + k]), k
+    assert [str(x) for x in m.cky()] == g['meta']['trees']
+
+
+def _chart_mask(g):
+    n = g['meta']['n_masks']
+    return torch.cat([torch.from_numpy(g['mask_%d' % i]) for i in range(n)], 1).cuda()   # (B, C, R): leaves, level 1, ...
+
+
+def test_cliora_train_with_recorded_dropout_and_grads():
+    from oracle import diora_ref as R
+    g = load_golden('cliora_small.npz')
+    m = _module(g).train()
+    m.dropout_mask = _chart_mask(g)
+    t = _inputs(g, rg=True)
+    m(t['x_span'], t['x_word'], t['obj_span'], t['obj_word'])
+    for k in ('inside_h', 'inside_s', 'outside_h', 'outside_s', 'all_atten_score', 'vg_atten_score', 'atten_score'):
+        assert _err(getattr(m, k), g['train__' + k]) <= OUT_TOL * _scale(g['train__' + k]), k
+    # the two VL losses of the reference (trainer.py:91-171), as torch ops on the native outputs
+    lc = R.contrastive_loss(m.inside_s, m.outside_s, m.all_atten_score, 0.2, 1.0)
+    lv = R.vg_loss(m.vg_atten_score, 1.0)
+    assert abs(float(lc) - float(g['train__contrastive_loss'])) <= 1e-4 * max(1.0, abs(float(g['train__contrastive_loss'])))
+    assert abs(float(lv) - float(g['train__vg_loss'])) <= 1e-4 * max(1.0, abs(float(g['train__vg_loss'])))
+    cot = {k[5:]: torch.from_numpy(v).cuda() for k, v in g.items() if k.startswith('cot__')}
+    (lc + lv + sum((getattr(m, k) * v).sum() for k, v in cot.items())).backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    for k, v in g.items():
+        if not k.startswith('grad__'):
+            continue
+        name = k[6:].replace('__', '.')
+        tt = t[name].grad if name in t else named[name].grad
+        assert tt is not None, k
+        assert _err(tt, v) <= GRAD_TOL * _scale(v), '%s err %.3e scale %.3e' % (k, _err(tt, v), _scale(v))
+
+
+@pytest.mark.parametrize('D,B,L,R,share', [(64, 3, 5, 36, True), (48, 2, 6, 10, False), (400, 2, 7, 36, True)])
+def test_cliora_against_oracle(D, B, L, R, share):
+    """Other shapes (Dp == D and Dp != D, R not a multiple of 4... of 16, unshared weights) vs the CPU oracle."""
+    from cliora_amd.cliora import DioraMLP
+    from oracle import diora_ref as Rf
+    torch.manual_seed(5)
+    P = Rf.init_params(D, share=share, seed=3)
+    gen = torch.Generator().manual_seed(4)
+    x_span, x_word = torch.randn(B, L, D, generator=gen), torch.randn(B, L, D, generator=gen)
+    obj_span, obj_word = 0.3 * torch.randn(B, R, D, generator=gen), 0.3 * torch.randn(B, R, D, generator=gen)
+    C = L * (L + 1) // 2
+    mask = torch.nn.functional.dropout(torch.ones(B, C, R), 0.1, True)
+    m = DioraMLP(D, share=share)
+    sd = m.state_dict()
+    for k in sd:
+        sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].clone()
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.dropout_mask = mask.cuda()
+    tg = {k: v.clone().cuda().requires_grad_(True) for k, v in dict(x_span=x_span, x_word=x_word, obj_span=obj_span, obj_word=obj_word).items()}
+    m(tg['x_span'], tg['x_word'], tg['obj_span'], tg['obj_word'])
+
+    # oracle with the same masks: replay them through F.dropout by patching it
+    for v in P.values():
+        v.requires_grad_(True)
+    tc = {k: v.clone().requires_grad_(True) for k, v in dict(x_span=x_span, x_word=x_word, obj_span=obj_span, obj_word=obj_word).items()}
+    off = [C - (L - lv) * (L - lv + 1) // 2 for lv in range(L)] + [C]
+    calls = {'i': 0}
+    orig = torch.nn.functional.dropout
+
+    def replay(x, p, training):
+        i = calls['i']
+        calls['i'] += 1
+        return x * mask[:, off[i]:off[i + 1]]
+    Rf.F.dropout = replay
+    try:
+        ref = Rf.diora_forward(P, tc['x_span'], tc['x_word'], tc['obj_span'], tc['obj_word'], share=share, training=True)
+    finally:
+        Rf.F.dropout = orig
+    keys = ('inside_h', 'inside_s', 'outside_h', 'outside_s', 'all_atten_score', 'vg_atten_score')
+    gen2 = torch.Generator().manual_seed(9)
+    cot = {k: torch.randn(ref[k].shape, generator=gen2) for k in keys}
+    sum((ref[k] * cot[k]).sum() for k in keys).backward()
+    torch.autograd.backward([getattr(m, k) for k in keys], [cot[k].cuda() for k in keys])
+    torch.cuda.synchronize()
+    for k in keys + ('inside_c', 'atten_score'):
+        assert _err(getattr(m, k), ref[k].detach().numpy()) <= OUT_TOL * _scale(ref[k].detach().numpy()), k
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        assert _err(named[k].grad, p.grad.numpy()) <= GRAD_TOL * _scale(p.grad.numpy()), k
+    for k in tg:
+        assert _err(tg[k].grad, tc[k].grad.numpy()) <= GRAD_TOL * _scale(tc[k].grad.numpy()), k
