@@ -719,11 +719,11 @@ static void region_segments(int NRp, int ncols, int* Kseg, int* nseg) {
     *Kseg = 16; *nseg = NRp / 16;
 }
 
-struct VlViews { float *oall, *oallT, *wall, *wallT, *sump, *xwp, *xwn, *nrm, *gobj, *slab; };
+struct VlViews { float *oall, *oallT, *wall, *wallT, *sump, *xwp, *xwn, *dxn, *nrm, *gobj, *slab; };
 static VlViews vl_views(const Plan& p, void* ws) {
     float* w = (float*)ws;
     const auto& v = p.vl;
-    return VlViews{w + v.oall, w + v.oallT, w + v.wall, w + v.wallT, w + v.sump, w + v.xwp, w + v.xwn, w + v.nrm, w + v.gobj, w + v.slab};
+    return VlViews{w + v.oall, w + v.oallT, w + v.wall, w + v.wallT, w + v.sump, w + v.xwp, w + v.xwn, w + v.dxn, w + v.nrm, w + v.gobj, w + v.slab};
 }
 
 extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
@@ -770,41 +770,53 @@ extern "C" int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_
     const Plan& p = plan->p;
     if (p.R <= 0) return fail(CLIORA_EINVAL, "the scorers need a CLIORA plan (R > 0)");
     if (vl_ws_bytes < p.vl.total * sizeof(float)) return fail(CLIORA_ENOMEM, "VL workspace too small");
-    if (!training && d_vg) return fail(CLIORA_EINVAL, "eval-mode vg_atten has no backward (the reference runs it under no_grad)");
     hipStream_t st = (hipStream_t)stream;
     const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
     const bool padded = D != Dp;
     const VlViews v = vl_views(p, vl_ws);
+    const bool eval_vg = !training && d_vg;      // eval: vg = all_atten[:, :, :L] + unit(x_word) . obj_word  (cliora.py:462-464)
     {   // transposed region matrices: W[j][k] = O[k][j], k padded with zero rows
         CopyTable t; t.n = 0;
         add_copy(t, v.oallT, NRp, Dp, NRp, obj_span, D, B * R, D, 0, 0, 1);
         if (d_vg) add_copy(t, v.wallT, NRp, Dp, NRp, obj_word, D, B * R, D, 0, 0, 1);
         if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
-        if (d_vg && padded) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
+        if (d_vg && (padded || eval_vg)) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }
+    if (eval_vg) {
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, v.xwp, Dp, B * L, B * L, 0, 0, Dp, p.normalize, v.xwn,
+                           v.nrm, v.nrm + B * L);
+        LAUNCHOK("unit_norm_rows(x_word)");
+    }
     const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
+    // gradient reaching all_atten: its own cotangent, plus (eval) the vg cotangent on the leaf cells
+    const ScoreGrad2A gall{d_all, eval_vg ? d_vg : nullptr, B, C, L, R};
+    const bool any_all = d_all || eval_vg;
     int Kseg = NRp, nseg = 1;
     region_segments(NRp, Dp, &Kseg, &nseg);
     if (d_sum_h) {
-        if (d_all) OKR(launch_rows(st, v.oallT, Kseg, nseg, Dp, B * C, ScoreGradA{d_all, B, C, R}, StoreAccE{d_sum_h, D, D, 0}));
+        if (any_all) OKR(launch_rows(st, v.oallT, Kseg, nseg, Dp, B * C, gall, StoreAccE{d_sum_h, D, D, 0}));
         else HIPOK(hipMemsetAsync(d_sum_h, 0, (size_t)B * C * D * sizeof(float), st));
     }
     if (d_obj_span) {
-        if (d_all) {
-            OKR(launch_tn_regions(st, B * C, NRp, Dp, ScoreGradA{d_all, B, C, R}, sumA, v.slab, p.vl.slab_floats, v.gobj));
+        if (any_all) {
+            OKR(launch_tn_regions(st, B * C, NRp, Dp, gall, sumA, v.slab, p.vl.slab_floats, v.gobj));
             CopyTable t; t.n = 0;
             add_copy(t, d_obj_span, D, B * R, D, v.gobj, Dp, B * R, D, 0, 0, 0);
             OKR(run_copies(st, t));
         } else HIPOK(hipMemsetAsync(d_obj_span, 0, (size_t)B * R * D * sizeof(float), st));
     }
     if (d_x_word) {
-        if (d_vg) OKR(launch_rows(st, v.wallT, Kseg, nseg, Dp, B * L, ScoreGradA{d_vg, B, L, R}, StoreAccE{d_x_word, D, D, 0}));
-        else HIPOK(hipMemsetAsync(d_x_word, 0, (size_t)B * L * D * sizeof(float), st));
+        if (d_vg && training) OKR(launch_rows(st, v.wallT, Kseg, nseg, Dp, B * L, ScoreGradA{d_vg, B, L, R}, StoreAccE{d_x_word, D, D, 0}));
+        else if (d_vg) {      // through unit(x_word)
+            OKR(launch_rows(st, v.wallT, Kseg, nseg, Dp, B * L, ScoreGradA{d_vg, B, L, R}, StoreAccE{v.dxn, Dp, Dp, 0}));
+            hipLaunchKernelGGL(rows_unit_bwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B * L, Dp, D, v.dxn, v.xwn, v.nrm, p.normalize, d_x_word);
+            LAUNCHOK("rows_unit_bwd");
+        } else HIPOK(hipMemsetAsync(d_x_word, 0, (size_t)B * L * D * sizeof(float), st));
     }
     if (d_obj_word) {
         if (d_vg) {
-            const SumRowsA xw = SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
+            const SumRowsA xw = eval_vg ? SumRowsA{v.xwn, nullptr, Dp} : SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
             OKR(launch_tn_regions(st, B * L, NRp, Dp, ScoreGradA{d_vg, B, L, R}, xw, v.slab, p.vl.slab_floats, v.gobj));
             CopyTable t; t.n = 0;
             add_copy(t, d_obj_word, D, B * R, D, v.gobj, Dp, B * R, D, 0, 0, 0);

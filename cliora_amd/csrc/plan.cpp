@@ -181,7 +181,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         const size_t on = R > 0 ? 1 : 0;
         v.oall = take(on * NR * Dp); v.oallT = take(on * NR * Dp);
         v.wall = take(on * NR * Dp); v.wallT = take(on * NR * Dp);
-        v.sump = take(on * BC * Dp); v.xwp = take(on * BL * Dp); v.xwn = take(on * BL * Dp); v.nrm = take(on * 4 * BL);
+        v.sump = take(on * BC * Dp); v.xwp = take(on * BL * Dp); v.xwn = take(on * BL * Dp); v.dxn = take(on * BL * Dp); v.nrm = take(on * 4 * BL);
         v.gobj = take(on * NR * Dp);
         v.slab_floats = on * (8 * (NR * Dp) + 64);
         v.slab = take(v.slab_floats);

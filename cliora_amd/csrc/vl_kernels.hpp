@@ -293,6 +293,56 @@ struct ScoreGradA {
     static constexpr bool kSide = false;
     __device__ void side(const Ctx&, int, float4) const {}
 };
+// A(r, k) = dAll[a][c][b][d] + (b < L2 ? dVg[a][c][b][d] : 0): eval-mode vg_atten = all_atten[:, :, :L] + ...
+struct ScoreGrad2A {
+    const float* G1; const float* G2; int B, C1, C2, R;
+    struct Ctx { const float *b1, *b2; };
+    using Raw = Raw2;
+    __device__ Ctx row(int r) const {
+        const int a = r / C1, b = r - a * C1;
+        return Ctx{G1 ? G1 + ((size_t)a * B * C1 + b) * R : nullptr, (G2 && b < C2) ? G2 + ((size_t)a * B * C2 + b) * R : nullptr};
+    }
+    __device__ float one(const float* base, int Cq, int k) const {
+        if (!base || k >= B * R) return 0.f;
+        const int cc = k / R, d = k - cc * R;
+        return base[(size_t)cc * Cq * R + d];
+    }
+    __device__ float val(const Ctx& c, int k) const { return one(c.b1, C1, k) + one(c.b2, C2, k); }
+    __device__ float4 four(const float* base, int Cq, int k) const {
+        if (base && (R & 3) == 0 && k + 3 < B * R) {
+            const int cc = k / R, d = k - cc * R;
+            return ld4(base + (size_t)cc * Cq * R + d);
+        }
+        return make_float4(one(base, Cq, k), one(base, Cq, k + 1), one(base, Cq, k + 2), one(base, Cq, k + 3));
+    }
+    __device__ Raw fetch(const Ctx& c, int k) const { return Raw{four(c.b1, C1, k), four(c.b2, C2, k)}; }
+    __device__ float4 finish(const Ctx&, const Raw& r) const { return f4add(r.u, r.v); }
+    static constexpr bool kSide = false;
+    __device__ void side(const Ctx&, int, float4) const {}
+};
+
+// out[r][:D] = unit-norm backward of V[r] through Hn[r] = X[r] / max(|X[r]|, eps)
+__global__ __launch_bounds__(256) void rows_unit_bwd(int nrows, int Dp, int D, const float* __restrict__ V, const float* __restrict__ Hn,
+                                                     const float* __restrict__ nrm, int normalize, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
+    if (a0) { v0 = ld4(V + (size_t)r * Dp + c0); h0 = ld4(Hn + (size_t)r * Dp + c0); }
+    if (a1) { v1 = ld4(V + (size_t)r * Dp + c1); h1 = ld4(Hn + (size_t)r * Dp + c1); }
+    unit_norm_bwd(v0, v1, h0, h1, nrm[r], normalize);
+    float* o = out + (size_t)r * D;
+    const float vs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (a0 && c0 + j < D) o[c0 + j] = vs[j];
+        if (a1 && c1 + j < D) o[c1 + j] = vs[4 + j];
+    }
+}
+
 // adds the optional second matrix row-wise:  out[r][col] = v (+ prev)   plain (rows x ld) store with accumulate flag
 struct StoreAccE {
     float* out; int ld, ncols, accumulate;

@@ -1,0 +1,175 @@
+"""Minimal training harness around the native chart modules: the callers either side of the path.
+
+The reference's CLI cannot run on the GPU box (torchvision / h5py / datasets absent), so this
+module restates -- as plain torch ops, they are not on the HIP path -- what sits around
+``self.diora(...)`` in cliora/net/trainer.py: ``Embed`` (:204-224), ``ImageEncoder``
+(net/utils.py:37-55), the three losses (:25-171), ``Net.forward`` (:272-304) and the update rule
+of ``Trainer._step`` / ``gradient_update`` (:450-455, 483-501: backward, clip_grad_norm_ 5.0,
+Adam).  Module and parameter names follow the reference so that its checkpoints
+(``trainer.py:383-398``) load by key.  Pinned by tests/golden/net_*.npz.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .diora import DioraMLP as TextDiora
+from .cliora import DioraMLP as VLDiora
+
+
+def _normal_(module):
+    for p in module.parameters():
+        if p.requires_grad:
+            p.data.normal_()
+
+
+class Embed(nn.Module):
+    """Two bias-free projections of the word embedding: span input and word input."""
+
+    def __init__(self, embeddings, input_size, size):
+        super().__init__()
+        self.input_size, self.size, self.embeddings = input_size, size, embeddings
+        self.mat = nn.Parameter(torch.empty(size, input_size))
+        self.mat1 = nn.Parameter(torch.empty(size, input_size))
+        _normal_(self)
+
+    def forward(self, tokens):
+        B, L = tokens.shape
+        e = self.embeddings(tokens.reshape(-1))
+        return (e @ self.mat.t()).view(B, L, -1), (e @ self.mat1.t()).view(B, L, -1)
+
+
+class ImageEncoder(nn.Module):
+    """Two linear maps of the region features; zero-initialised like the reference (utils.py:45-50)."""
+
+    def __init__(self, input_size, size):
+        super().__init__()
+        self.fc, self.fc_vis = nn.Linear(input_size, size), nn.Linear(input_size, size)
+        for p in self.parameters():
+            p.data.zero_()
+
+    def forward(self, obj_feats):
+        x = obj_feats.float()
+        return self.fc(x), self.fc_vis(x)
+
+
+class ReconstructionSoftmaxLoss(nn.Module):
+    name = 'reconstruct_softmax_loss'
+
+    def __init__(self, embeddings, input_size, size, k_neg=3):
+        super().__init__()
+        self.k_neg, self.embeddings = k_neg, embeddings
+        self.mat = nn.Parameter(torch.empty(size, input_size))
+        _normal_(self)
+
+    def forward(self, tokens, neg_samples, diora):
+        B, L = tokens.shape
+        pos = self.embeddings(tokens) @ self.mat.t()                     # B,L,D
+        neg = self.embeddings(neg_samples) @ self.mat.t()                # K,D
+        cell = diora.outside_h[:, :L]                                    # B,L,D  leaf outside vectors
+        logits = torch.cat([(pos * cell).sum(-1, keepdim=True), cell @ neg.t()], -1).view(B * L, -1)
+        return F.cross_entropy(logits, torch.zeros(B * L, dtype=torch.long, device=logits.device))
+
+
+class ContrastiveLoss(nn.Module):
+    name = 'contrastive_loss'
+
+    def __init__(self, margin=1.0, alpha_contr=0.01):
+        super().__init__()
+        self.margin, self.alpha, self.floor = margin, alpha_contr, 1e-8
+
+    def forward(self, diora):
+        ins, outs = diora.inside_s.squeeze(-1), diora.outside_s.squeeze(-1)
+        B, C = ins.shape
+        sc = diora.all_atten_score.max(-1).values.permute(2, 0, 1)       # C,B(text),B(image)
+        pos = torch.diagonal(sc, 0, 1, 2).unsqueeze(-1)                  # C,B,1
+        off_diag = ~torch.eye(B, dtype=torch.bool, device=sc.device)
+        txt = (self.margin + sc - pos).clamp(min=self.floor) * off_diag
+        img = (self.margin + sc - pos.transpose(1, 2)).clamp(min=self.floor) * off_diag
+        per_span = (txt.mean(2) + img.mean(1)).t()                       # B,C
+        marginal = torch.exp(ins + outs - ins[:, -1:])
+        return (marginal * per_span)[:, :C // 2].sum(-1).mean() * self.alpha
+
+
+class VGLoss(nn.Module):
+    name = 'vg_loss'
+
+    def __init__(self, alpha_vg=0.1):
+        super().__init__()
+        self.alpha = alpha_vg
+
+    def forward(self, vg_atten_score):
+        B, _, L, _ = vg_atten_score.shape
+        logits = vg_atten_score.max(-1).values.sum(-1) / L
+        return self.alpha * F.cross_entropy(logits, torch.arange(B, device=logits.device))
+
+
+class Net(nn.Module):
+    def __init__(self, embed, image_encoder, diora, obj_feats, loss_funcs=()):
+        super().__init__()
+        self.obj_feats = obj_feats
+        if obj_feats:
+            self.img_encoder = image_encoder
+        self.embed, self.diora = embed, diora
+        self.loss_func_names = [m.name for m in loss_funcs]
+        for m in loss_funcs:
+            setattr(self, m.name, m)
+
+    def forward(self, tokens, obj_feats=None, neg_samples=None, compute_loss=True):
+        x_span, x_word = self.embed(tokens)
+        o_span = o_word = None
+        if self.obj_feats:
+            o_span, o_word = self.img_encoder(obj_feats)
+        self.diora(x_span, x_word, o_span, o_word)
+        if not compute_loss:
+            return {'total_loss': torch.ones(1, 1, device=x_span.device)}
+        ret, parts = {}, []
+        for name in self.loss_func_names:
+            fn = getattr(self, name)
+            if 'reconstruct' in name:
+                v = fn(tokens, neg_samples, self.diora)
+            elif 'contrastive' in name:
+                v = fn(self.diora)
+            else:
+                v = fn(self.diora.vg_atten_score)
+            ret[name] = v
+            parts.append(v.view(1, 1))
+        ret['total_loss'] = torch.cat(parts, 1)
+        return ret
+
+
+def build_net(size, embeddings, obj_feats=False, img_dim=2048, k_neg=100, share=True, normalize='unit',
+              vg_loss=False, use_contr=False, vl_margin=0.2, alpha_contr=1.0, alpha_vg=1.0):
+    """What trainer.py:504-582 assembles, on the native chart modules."""
+    embed = Embed(embeddings, embeddings.weight.shape[1], size)
+    enc = ImageEncoder(img_dim, size)
+    diora = (VLDiora if obj_feats else TextDiora)(size, outside=True, normalize=normalize, compress=False, share=share)
+    losses = [ReconstructionSoftmaxLoss(embeddings, embeddings.weight.shape[1], size, k_neg=k_neg)]
+    if vg_loss:
+        losses.append(VGLoss(alpha_vg))
+    if obj_feats and use_contr:
+        losses.append(ContrastiveLoss(vl_margin, alpha_contr))
+    if obj_feats:
+        embeddings.weight.requires_grad = False              # trainer.py:541
+    return Net(embed, enc, diora, obj_feats, losses)
+
+
+class Trainer(object):
+    def __init__(self, net, lr=2e-3, reducer=None):
+        self.net = net
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8)
+        self.reducer = reducer                               # cliora_amd.parallel.FlatGradAllReduce or None
+
+    def step(self, batch_map, train=True, compute_loss=True):
+        self.net.train(train)
+        with torch.set_grad_enabled(train):
+            out = self.net(batch_map['sentences'], batch_map.get('obj_feats'), batch_map.get('neg_samples'), compute_loss)
+        total = out['total_loss'].mean(dim=0).sum()
+        if train:
+            self.optimizer.zero_grad()
+            total.backward()
+            if self.reducer is not None:
+                self.reducer.all_reduce_mean()
+            torch.nn.utils.clip_grad_norm_(self.params, 5.0)
+            self.optimizer.step()
+        return {'total_loss': float(total)}

@@ -1,0 +1,56 @@
+"""Whole training step on the GPU: Embed -> native chart -> losses -> backward -> clip -> Adam, against
+the values captured from the reference's Net / Trainer (tests/golden/net_*.npz, trainer.py:243-304, 450-501)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(g, vl):
+    from cliora_amd import harness as H
+    m = g['meta']
+    emb = torch.nn.Embedding(m['V'], 32)
+    net = H.build_net(m['D'], emb, obj_feats=vl, img_dim=48, k_neg=m['K'], vg_loss=vl, use_contr=vl,
+                      vl_margin=0.2, alpha_contr=1.0, alpha_vg=1.0)
+    sd = net.state_dict()
+    for k in sd:
+        sd[k] = torch.from_numpy(g['param__' + k.replace('.', '__')].copy())
+    net.load_state_dict(sd)
+    return net.cuda()
+
+
+def _batch(g):
+    return dict(sentences=torch.from_numpy(g['sentences']).cuda(), neg_samples=torch.from_numpy(g['neg_samples']).cuda(),
+                obj_feats=torch.from_numpy(g['obj_feats']).cuda())
+
+
+@pytest.mark.parametrize('name,vl', [('net_diora.npz', False), ('net_cliora.npz', True)])
+def test_net_losses_grads_and_three_adam_steps(name, vl):
+    from cliora_amd import harness as H
+    g = load_golden(name)
+    net = _build(g, vl).eval()             # fixtures were captured with dropout off
+    bm = _batch(g)
+    out = net(bm['sentences'], bm['obj_feats'], bm['neg_samples'])
+    ref = g['total_loss']
+    assert np.abs(out['total_loss'].detach().cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    out['total_loss'].mean(0).sum().backward()
+    for k, p in net.named_parameters():
+        gk = 'grad__' + k.replace('.', '__')
+        if gk in g and p.grad is not None:
+            err = float((p.grad.cpu() - torch.from_numpy(g[gk])).abs().max())
+            assert err <= 2e-4 * max(1.0, float(np.abs(g[gk]).max())), (k, err)
+    # Trainer._step x3 (dropout kept off as in the fixture)
+    net.zero_grad()
+    tr = H.Trainer(net, lr=g['meta']['lr'])
+    net.train = lambda mode=True: torch.nn.Module.train(net, False)
+    for s in range(3):
+        r = tr.step(bm, train=True)
+        assert abs(r['total_loss'] - g['step_losses'][s]) <= 2e-4 * max(1.0, abs(g['step_losses'][s]))
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        want = g['after3__' + k.replace('.', '__')]
+        assert float((p.detach().cpu() - torch.from_numpy(want)).abs().max()) <= 5e-4 * max(1.0, float(np.abs(want).max())), k

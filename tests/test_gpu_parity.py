@@ -215,3 +215,25 @@ def test_cpu_tensor_fails_loudly():
     m = DioraMLP(16)
     with pytest.raises(ChartLibError):
         m(torch.randn(2, 4, 16), None)
+
+
+def test_length_40_chart():
+    """L=40 (the reference's --train_filter_length cap, BASELINE config 5 shape with the MLP composition):
+    820 cells, 31 980 pairs per sentence; first sentence against the oracle, plus properties on all."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    D, B, L = 400, 4, 40
+    P, x, cot = synth.diora_case(D, B, L, 77)
+    m = _module_from_params(P, D, True, 'unit')
+    outs, xg = _run_gpu(m, x, cot)
+    with torch.no_grad():
+        ref = R.diora_forward(P, x[:1], x[:1], keep_pairs=True)
+    for k in CHARTS:
+        assert _err(outs[k][:1], ref[k]) <= OUT_TOL * _scale(ref[k]), k
+    assert float((outs['inside_h'].norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert float((outs['outside_h'].norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
+    with torch.no_grad():
+        m(x.cuda(), x.cuda())
+    assert str(m.cky()[0]) == str(R.cky_trees(ref['pair_s_in'], 1, L)[0])
