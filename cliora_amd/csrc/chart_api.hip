@@ -447,7 +447,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(pair_scores_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
                            IH, IS, IS, ws + f.sp, ws + f.pp, IS);
         LAUNCHOK("pair_scores_fwd");
         {
@@ -481,7 +481,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
-            hipLaunchKernelGGL(pair_scores_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, dv.arow, dv.brow,
+            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow,
                                ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS, ws + f.sp, ws + f.pp, OS);
             LAUNCHOK("pair_scores_fwd(out)");
             {
@@ -552,7 +552,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         for (int level = 0; level <= L - 1; ++level) {
             const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
             const int ncell = B * g.Lc, nrows = ncell * g.N;
-            hipLaunchKernelGGL(cell_gather_bwd_out, dim3(cells_grid(ncell)), dim3(256), 0, st, g, D, d_outside_h,
+            hipLaunchKernelGGL(cell_gather_bwd_out, dim3(ncell), dim3(256), 0, st, g, D, d_outside_h,
                                level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
             LAUNCHOK("cell_gather_bwd_out");
             if (level >= 1)
@@ -563,7 +563,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                 LAUNCHOK("root_bwd");
                 break;
             }
-            hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, Y, Sp, Pp,
+            hipLaunchKernelGGL(cell_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, Y, Sp, Pp,
                                OS, dStot, dG, DS);
             LAUNCHOK("cell_scores_bwd(out)");
             {
@@ -589,7 +589,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     for (int level = L - 1; level >= 0; --level) {
         const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(cell_gather_bwd_in, dim3(cells_grid(ncell)), dim3(256), 0, st, g, D, d_inside_h,
+        hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, st, g, D, d_inside_h,
                            level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside,
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
@@ -602,7 +602,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("cell_attend_bwd");
         }
         if (level == 0) break;
-        hipLaunchKernelGGL(cell_scores_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, Y, Sp, Pp, IS,
+        hipLaunchKernelGGL(cell_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, Y, Sp, Pp, IS,
                            dStot, dG, DS);
         LAUNCHOK("cell_scores_bwd(in)");
         {

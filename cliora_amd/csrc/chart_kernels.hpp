@@ -96,19 +96,20 @@ __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_
                                                        const float* __restrict__ QA, int ldA, const float* __restrict__ HB,
                                                        const float* SA, const float* SB,
                                                        float* __restrict__ Sp, float* __restrict__ Pp, float* Sout) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
+    // one workgroup (4 waves) per target cell: wave w scores the splits n = w, w+4, ... (all of them
+    // in flight together for L <= 16, four at a time beyond), wave 0 then does the softmax
+    __shared__ float sh_s[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int row0 = g.rowbase + t * g.N;
     const int nv = g.Dp >> 2;
-    float my_s = -INFINITY;
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
-    for (int n0 = 0; n0 < g.N; n0 += 4) {        // four splits in flight: index loads, row loads, then the reductions
+    for (int n0 = wave; n0 < g.N; n0 += 16) {
         int ar[4], br[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + j, g.N - 1);
+            const int n = min(n0 + 4 * j, g.N - 1);
             ar[j] = arow[row0 + n];
             br[j] = brow[row0 + n];
         }
@@ -125,9 +126,12 @@ __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = wave_sum(d[j]) + SA[ar[j]] + SB[br[j]];
-            if (lane == n0 + j) my_s = s;
+            if (lane == 0 && n0 + 4 * j < g.N) sh_s[n0 + 4 * j] = s;
         }
     }
+    __syncthreads();
+    if (wave != 0) return;
+    const float my_s = lane < g.N ? sh_s[lane] : -INFINITY;
     const float m = wave_max(my_s);
     const float e = lane < g.N ? expf(my_s - m) : 0.f;
     const float pn = e / wave_sum(e);
@@ -193,22 +197,22 @@ __device__ __forceinline__ float4 ld_ext(const float* base, int D, int col) {
     return v;
 }
 
-// One use list of one cell, four uses in flight at a time (index loads, then all row loads, then
-// the accumulation in list order -- the result does not depend on the batching):
+// One use list of one cell.  The four waves of the cell's workgroup take the uses u = w, w+4, ...
+// of the list, four in flight each (index loads, then all row loads, then the accumulation):
 //   acc_da += DA[row];   acc_x += ds[row] * SRC[partner];   vS += ds[row]
-__device__ __forceinline__ void gather_uses(const UseTab& ut, int c, int b, int bC, const float* __restrict__ DA,
+__device__ __forceinline__ void gather_uses(const UseTab& ut, int c, int b, int bC, int wave, const float* __restrict__ DA,
                                             const float* __restrict__ DS, int Dp, const float* __restrict__ SRC, int ldsrc,
                                             int col0, int col1, bool act0, bool act1,
                                             float4& da0, float4& da1, float4& x0, float4& x1, float& vS) {
     const int beg = ut.off[c], end = ut.off[c + 1];
-    for (int u0 = beg; u0 < end; u0 += 4) {
+    for (int u0 = beg + wave; u0 < end; u0 += 16) {
         size_t r[4];
         float ds[4], m[4];
         const float* sp[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int uu = min(u0 + j, end - 1);
-            m[j] = (u0 + j < end) ? 1.f : 0.f;
+            const int uu = min(u0 + 4 * j, end - 1);
+            m[j] = (u0 + 4 * j < end) ? 1.f : 0.f;
             r[j] = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
             sp[j] = SRC + (size_t)(bC + ut.partner[uu]) * ldsrc;
         }
@@ -233,15 +237,27 @@ __device__ __forceinline__ void gather_uses(const UseTab& ut, int c, int b, int 
     }
 }
 
+// fixed-order sum of the four waves' partial float4 pairs through LDS; every wave gets the total
+constexpr int GATHER_SLOTS = 10;
+__device__ __forceinline__ void wg_sum_pairs(float4 (*sh)[GATHER_SLOTS][64], int wave, int lane, int nslots, float4* v) {
+    for (int k = 0; k < nslots; ++k) sh[wave][k][lane] = v[k];
+    __syncthreads();
+    for (int k = 0; k < nslots; ++k) {
+        const float4 a = sh[0][k][lane], b = sh[1][k][lane], c = sh[2][k][lane], d = sh[3][k][lane];
+        v[k] = f4add(f4add(f4add(a, b), c), d);
+    }
+}
+
 __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
                                                           UseTab ina, UseTab inb, UseTab outa, int with_outside,
                                                           const float* __restrict__ DA, const float* __restrict__ DS,
                                                           const float* __restrict__ PI, int ldpi, int share,
                                                           const float* __restrict__ IH, const float* __restrict__ OH,
                                                           float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ dStot) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
+    __shared__ float4 sh[4][GATHER_SLOTS][64];
+    __shared__ float sh_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
@@ -249,29 +265,51 @@ __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, co
     const int bC = b * g.C;
     const bool act0 = lane < nv, act1 = lane + 64 < nv;
     const int col0 = 4 * lane, col1 = 4 * (lane + 64);
-    float vS = dS_ext ? dS_ext[crow] : 0.f;
-    float4 vh0 = (dH_ext && act0) ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
-    float4 vh1 = (dH_ext && act1) ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
-    float4 dPL0 = f4zero(), dPL1 = f4zero(), dPR0 = f4zero(), dPR1 = f4zero(), dQL0 = f4zero(), dQL1 = f4zero();
+    float vS = 0.f;
+    // slots: 0,1 vh | 2,3 dPL | 4,5 dPR | 6,7 dQL | 8,9 (outside-pass uses) handled below
+    float4 v[GATHER_SLOTS];
+#pragma unroll
+    for (int k = 0; k < GATHER_SLOTS; ++k) v[k] = f4zero();
     float4 dPLo0 = f4zero(), dPLo1 = f4zero(), dQLo0 = f4zero(), dQLo1 = f4zero();
     // right-child uses: partner = left child; dH += ds * QL(left);  dPR += DA
-    gather_uses(inb, c, b, bC, DA, DS, Dp, PI + 2 * Dp, ldpi, col0, col1, act0, act1, dPR0, dPR1, vh0, vh1, vS);
+    gather_uses(inb, c, b, bC, wave, DA, DS, Dp, PI + 2 * Dp, ldpi, col0, col1, act0, act1, v[4], v[5], v[0], v[1], vS);
     // left-child uses: partner = right child; dQL += ds * H(right);  dPL += DA
-    gather_uses(ina, c, b, bC, DA, DS, Dp, IH, Dp, col0, col1, act0, act1, dPL0, dPL1, dQL0, dQL1, vS);
+    gather_uses(ina, c, b, bC, wave, DA, DS, Dp, IH, Dp, col0, col1, act0, act1, v[2], v[3], v[6], v[7], vS);
     // sibling uses in the outside pass: partner = parent (outside chart)
-    if (with_outside) gather_uses(outa, c, b, bC, DA, DS, Dp, OH, Dp, col0, col1, act0, act1, dPLo0, dPLo1, dQLo0, dQLo1, vS);
+    if (with_outside) gather_uses(outa, c, b, bC, wave, DA, DS, Dp, OH, Dp, col0, col1, act0, act1, dPLo0, dPLo1, dQLo0, dQLo1, vS);
+    if (share) {                       // shared weights: sibling uses feed the same PL / QL blocks
+        v[2] = f4add(v[2], dPLo0); v[3] = f4add(v[3], dPLo1); v[6] = f4add(v[6], dQLo0); v[7] = f4add(v[7], dQLo1);
+        wg_sum_pairs(sh, wave, lane, 8, v);
+    } else {
+        v[8] = dPLo0; v[9] = dPLo1;
+        wg_sum_pairs(sh, wave, lane, 10, v);
+    }
+    vS = wave == 0 ? vS : vS;          // every lane of a wave holds the same vS
+    if (lane == 0) sh_s[wave] = vS;
+    float4 q0 = f4zero(), q1 = f4zero();
+    if (!share) {                      // the fifth block (dQLo) goes through LDS in a second round
+        __syncthreads();
+        float4 w2[2] = {dQLo0, dQLo1};
+        wg_sum_pairs(sh, wave, lane, 2, w2);
+        q0 = w2[0]; q1 = w2[1];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float vs = ((sh_s[0] + sh_s[1]) + sh_s[2]) + sh_s[3] + (dS_ext ? dS_ext[crow] : 0.f);
     float* o = dPI + crow * ldpi;
     if (act0) {
-        if (share) { st4(o + col0, f4add(dPL0, dPLo0)); st4(o + Dp + col0, dPR0); st4(o + 2 * Dp + col0, f4add(dQL0, dQLo0)); }
-        else { st4(o + col0, dPL0); st4(o + Dp + col0, dPR0); st4(o + 2 * Dp + col0, dQL0); st4(o + 3 * Dp + col0, dPLo0); st4(o + 4 * Dp + col0, dQLo0); }
-        st4(VH + crow * Dp + col0, vh0);
+        const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
+        st4(o + col0, v[2]); st4(o + Dp + col0, v[4]); st4(o + 2 * Dp + col0, v[6]);
+        if (!share) { st4(o + 3 * Dp + col0, v[8]); st4(o + 4 * Dp + col0, q0); }
+        st4(VH + crow * Dp + col0, f4add(v[0], e));
     }
     if (act1) {
-        if (share) { st4(o + col1, f4add(dPL1, dPLo1)); st4(o + Dp + col1, dPR1); st4(o + 2 * Dp + col1, f4add(dQL1, dQLo1)); }
-        else { st4(o + col1, dPL1); st4(o + Dp + col1, dPR1); st4(o + 2 * Dp + col1, dQL1); st4(o + 3 * Dp + col1, dPLo1); st4(o + 4 * Dp + col1, dQLo1); }
-        st4(VH + crow * Dp + col1, vh1);
+        const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
+        st4(o + col1, v[3]); st4(o + Dp + col1, v[5]); st4(o + 2 * Dp + col1, v[7]);
+        if (!share) { st4(o + 3 * Dp + col1, v[9]); st4(o + 4 * Dp + col1, q1); }
+        st4(VH + crow * Dp + col1, f4add(v[1], e));
     }
-    if (lane == 0) dStot[crow] = vS;
+    if (lane == 0) dStot[crow] = vs;
 }
 
 //   outside cell c (as parent in the outside pass):
@@ -280,9 +318,10 @@ __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, c
                                                            UseTab outb, const float* __restrict__ DA, const float* __restrict__ DS,
                                                            const float* __restrict__ PI, int ldpi, int blk_qlo,
                                                            float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ dStot) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
+    __shared__ float4 sh[4][GATHER_SLOTS][64];
+    __shared__ float sh_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
@@ -290,14 +329,25 @@ __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, c
     const int bC = b * g.C;
     const bool act0 = lane < nv, act1 = lane + 64 < nv;
     const int col0 = 4 * lane, col1 = 4 * (lane + 64);
-    float vS = dS_ext ? dS_ext[crow] : 0.f;
-    float4 vh0 = (dH_ext && act0) ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
-    float4 vh1 = (dH_ext && act1) ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
-    float4 dPR0 = f4zero(), dPR1 = f4zero();
-    gather_uses(outb, c, b, bC, DA, DS, Dp, PI + (size_t)blk_qlo * Dp, ldpi, col0, col1, act0, act1, dPR0, dPR1, vh0, vh1, vS);
-    if (act0) { st4(dPO + crow * Dp + col0, dPR0); st4(VH + crow * Dp + col0, vh0); }
-    if (act1) { st4(dPO + crow * Dp + col1, dPR1); st4(VH + crow * Dp + col1, vh1); }
-    if (lane == 0) dStot[crow] = vS;
+    float vS = 0.f;
+    float4 v[GATHER_SLOTS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = f4zero();
+    gather_uses(outb, c, b, bC, wave, DA, DS, Dp, PI + (size_t)blk_qlo * Dp, ldpi, col0, col1, act0, act1, v[2], v[3], v[0], v[1], vS);
+    wg_sum_pairs(sh, wave, lane, 4, v);
+    if (lane == 0) sh_s[wave] = vS;
+    __syncthreads();
+    if (wave != 0) return;
+    const float vs = ((sh_s[0] + sh_s[1]) + sh_s[2]) + sh_s[3] + (dS_ext ? dS_ext[crow] : 0.f);
+    if (act0) {
+        const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
+        st4(dPO + crow * Dp + col0, v[2]); st4(VH + crow * Dp + col0, f4add(v[0], e));
+    }
+    if (act1) {
+        const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
+        st4(dPO + crow * Dp + col1, v[3]); st4(VH + crow * Dp + col1, f4add(v[1], e));
+    }
+    if (lane == 0) dStot[crow] = vs;
 }
 
 // unit-norm backward for one row held as two float4 per lane: H = g / max(||g||, eps)
@@ -325,9 +375,11 @@ __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float*
                                                        const float* __restrict__ Y, const float* __restrict__ Sp, const float* __restrict__ Pp,
                                                        const float* __restrict__ Schart, const float* __restrict__ dStot,
                                                        float* __restrict__ dG, float* __restrict__ DS) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
+    // one workgroup (4 waves) per target cell; every wave does the (cheap) unit-norm backward of the
+    // row, wave w then takes the dot products with the split outputs n = w, w+4, ...
+    __shared__ float sh_dp[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const int Dp = g.Dp, nv = Dp >> 2;
@@ -336,16 +388,17 @@ __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float*
     if (a0) { v0 = ld4(VH + crow * Dp + 4 * lane); h0 = ld4(H + crow * Dp + 4 * lane); }
     if (a1) { v1 = ld4(VH + crow * Dp + 4 * (lane + 64)); h1 = ld4(H + crow * Dp + 4 * (lane + 64)); }
     unit_norm_bwd(v0, v1, h0, h1, nrm[crow], normalize);
-    if (a0) st4(dG + crow * Dp + 4 * lane, v0);
-    if (a1) st4(dG + crow * Dp + 4 * (lane + 64), v1);
+    if (wave == 0) {
+        if (a0) st4(dG + crow * Dp + 4 * lane, v0);
+        if (a1) st4(dG + crow * Dp + 4 * (lane + 64), v1);
+    }
     if (g.N == 0) return;
     const int row0 = g.rowbase + t * g.N;
-    float dp = 0.f;
-    for (int n0 = 0; n0 < g.N; n0 += 4) {
+    for (int n0 = wave; n0 < g.N; n0 += 16) {
         float d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* y = Y + (size_t)(row0 + min(n0 + j, g.N - 1)) * Dp;
+            const float* y = Y + (size_t)(row0 + min(n0 + 4 * j, g.N - 1)) * Dp;
             float v = 0.f;
             if (a0) v = f4dot(v0, ld4(y + 4 * lane));
             if (a1) v += f4dot(v1, ld4(y + 4 * (lane + 64)));
@@ -354,10 +407,13 @@ __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float*
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float r = wave_sum(d[j]);
-            if (lane == n0 + j) dp = r;
+            if (lane == 0 && n0 + 4 * j < g.N) sh_dp[n0 + 4 * j] = r;
         }
     }
+    __syncthreads();
+    if (wave != 0) return;
     const bool an = lane < g.N;
+    const float dp = an ? sh_dp[lane] : 0.f;
     const float pn = an ? Pp[row0 + lane] : 0.f;
     const float sn = an ? Sp[row0 + lane] : 0.f;
     const float mean = wave_sum(pn * dp);
