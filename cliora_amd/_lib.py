@@ -14,7 +14,8 @@ NORM = {'none': 0, 'unit': 1}
 KCLASS = {'compose_fwd': 0, 'compose_bwd': 1, 'wgrad': 2}
 
 PARAM_FIELDS = ('leaf_w', 'leaf_b', 'in_w1', 'in_b1', 'in_w2', 'in_b2', 'in_mat',
-                'out_w1', 'out_b1', 'out_w2', 'out_b2', 'out_mat', 'root_h')
+                'out_w1', 'out_b1', 'out_w2', 'out_b2', 'out_mat', 'root_h',
+                'lstm_w', 'lstm_u', 'lstm_b', 'root_c')
 
 
 class Params(C.Structure):
@@ -39,6 +40,12 @@ def lib():
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     L.cliora_plan_create.argtypes = [i32] * 6 + [C.POINTER(vp)]
     L.cliora_plan_create.restype = i32
+    L.cliora_plan_create_ex.argtypes = [i32] * 7 + [C.POINTER(vp)]
+    L.cliora_plan_create_ex.restype = i32
+    L.cliora_lstm_forward.argtypes = [vp, C.POINTER(Params)] + [vp] * 7 + [vp, sz, i32, vp]
+    L.cliora_lstm_forward.restype = i32
+    L.cliora_lstm_backward.argtypes = [vp, C.POINTER(Params)] + [vp] * 13 + [vp, sz, vp, sz, vp, C.POINTER(Params), i32, vp]
+    L.cliora_lstm_backward.restype = i32
     L.cliora_plan_destroy.argtypes = [vp]
     L.cliora_plan_destroy.restype = None
     L.cliora_plan_fwd_workspace_bytes.argtypes = [vp]
@@ -79,13 +86,14 @@ def check(rc, what):
 class Plan:
     """Owns one cliora_plan (chart shape + device index tables)."""
 
-    def __init__(self, B, L, D, share=True, normalize='unit', R=0):
-        self.key = (B, L, D, bool(share), normalize, R)
+    def __init__(self, B, L, D, share=True, normalize='unit', R=0, arch=0):
+        self.key = (B, L, D, bool(share), normalize, R, arch)
+        self.arch = arch
         self.B, self.L, self.D, self.share, self.normalize, self.R = B, L, D, bool(share), normalize, R
         self.C = L * (L + 1) // 2
         self.Dp = (D + 15) // 16 * 16
         h = C.c_void_p()
-        check(lib().cliora_plan_create(B, L, D, int(bool(share)), NORM[normalize], R, C.byref(h)), 'cliora_plan_create')
+        check(lib().cliora_plan_create_ex(B, L, D, int(bool(share)), NORM[normalize], R, arch, C.byref(h)), 'cliora_plan_create_ex')
         self.handle = h
         self.fwd_bytes = lib().cliora_plan_fwd_workspace_bytes(h)
         self.bwd_bytes = lib().cliora_plan_bwd_workspace_bytes(h)
@@ -111,13 +119,13 @@ class Plan:
 _plans = {}
 
 
-def get_plan(B, L, D, share, normalize, R, device_index):
-    key = (B, L, D, bool(share), normalize, R, device_index)
+def get_plan(B, L, D, share, normalize, R, device_index, arch=0):
+    key = (B, L, D, bool(share), normalize, R, device_index, arch)
     pl = _plans.get(key)
     if pl is None:
         if len(_plans) > 64:
             _plans.clear()
-        pl = _plans[key] = Plan(B, L, D, share, normalize, R)
+        pl = _plans[key] = Plan(B, L, D, share, normalize, R, arch)
     return pl
 
 

@@ -8,7 +8,7 @@ static inline int ncells(int L) { return L * (L + 1) / 2; }
 
 static size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
 
-std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R) {
+std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch) {
     if (B < 1 || L < 1 || D < 1) return "B, L, D must be positive";
     if (D > 512) return "D > 512 is not supported by the weight-stationary kernels";
     if (L > 64) return "L > 64 is not supported (one split per lane in the score kernels)";
@@ -16,9 +16,17 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
     if (normalize != 0 && normalize != 1) return "normalize must be 0 (none) or 1 (unit)";
     p.B = B; p.L = L; p.D = D; p.Dp = (D + 15) / 16 * 16; p.C = ncells(L);
     p.share = share ? 1 : 0; p.normalize = normalize; p.R = R;
-    p.nblk = p.share ? 3 : 5;
-    p.blk_plo = p.share ? 0 : 3;
-    p.blk_qlo = p.share ? 2 : 4;
+    if (arch != 0 && arch != 1) return "arch must be 0 (MLP) or 1 (TreeLSTM)";
+    if (arch == 1 && (!share || R != 0)) return "TreeLSTM plans need share=1 and R=0";
+    p.arch = arch;
+    if (arch == 0) {
+        p.nblk = p.share ? 3 : 5; p.npo = 1; p.nleaf = 1; p.off_pr = 1; p.off_ql = 2;
+        p.blk_plo = p.share ? 0 : 3;
+        p.blk_qlo = p.share ? 2 : 4;
+    } else {   // [PL (5 gates: u,i,o,f0,f1) | PR (5) | QL]
+        p.nblk = 11; p.npo = 5; p.nleaf = 3; p.off_pr = 5; p.off_ql = 10;
+        p.blk_plo = 0; p.blk_qlo = 10;
+    }
     p.P_in = (L - 1) * L * (L + 1) / 6;
     p.P_out = (L - 1) * L * (L + 1) / 3;
     p.R_in = (long long)B * p.P_in;
@@ -120,15 +128,16 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
 
     // ---- workspace layouts -----------------------------------------------------
     const size_t Dp = p.Dp, nb = p.nblk, BC = (size_t)B * C, BL = (size_t)B * L;
+    const size_t npo = p.npo, nlf = p.nleaf, lstm = arch == 1 ? 1 : 0;
     const size_t Rt = (size_t)(p.R_in + p.R_out);
     const bool padded = (p.D != p.Dp);
     {
         FwdLayout& f = p.fwd;
         size_t o = 0;
         auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
-        f.wl = take(Dp * Dp); f.bl = take(Dp); f.wlT = take(Dp * Dp);
+        f.wl = take(nlf * Dp * Dp); f.bl = take(nlf * Dp); f.wlT = take(nlf * Dp * Dp);
         f.wcat = take(nb * Dp * Dp); f.bcat = take(nb * Dp); f.wcatT = take(nb * Dp * Dp);
-        f.w1ro = take(Dp * Dp); f.w1roT = take(Dp * Dp);
+        f.w1ro = take(npo * Dp * Dp); f.w1roT = take(npo * Dp * Dp);
         f.w2i = take(Dp * Dp); f.b2i = take(Dp); f.w2iT = take(Dp * Dp);
         if (p.share) { f.w2o = f.w2i; f.b2o = f.b2i; f.w2oT = f.w2iT; }
         else { f.w2o = take(Dp * Dp); f.b2o = take(Dp); f.w2oT = take(Dp * Dp); }
@@ -137,15 +146,17 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.ihp = take(padded ? BC * Dp : 0);
         f.ohp = take(padded ? BC * Dp : 0);
         f.objp = take((padded && R > 0) ? (size_t)B * R * Dp : 0);
-        f.t = take(BL * Dp);
+        f.t = take(BL * nlf * Dp);
         f.pi = take(BC * nb * Dp);
-        f.po = take(BC * Dp);
+        f.po = take(BC * npo * Dp);
         f.y = take(Rt * Dp);
         f.x = take(Rt * Dp);
         f.sp = take(Rt);
         f.pp = take(Rt);
         f.nrmi = take(BC);
         f.nrmo = take(BC);
+        f.icp = take(lstm * BC * Dp); f.ocp = take(lstm * BC * Dp);
+        f.nrmic = take(lstm * BC); f.nrmoc = take(lstm * BC); f.rootc = take(lstm * Dp);
         f.att_u = take(R > 0 ? BC * Dp : 0);
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
@@ -156,16 +167,17 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         size_t o = 0;
         auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
         b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
-        b.da = take(Rt * Dp); b.ds = take(Rt);
+        b.da = take(Rt * (lstm ? 5 : 1) * Dp); b.ds = take(Rt);
         b.dz = take(Rt * Dp);
-        b.dpi = take(BC * nb * Dp); b.dpo = take(BC * Dp);
-        b.du = take(BL * Dp); b.dxp = take(padded ? BL * Dp : 0);
+        b.dcb = take(lstm * Rt * Dp); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);
+        b.dpi = take(BC * nb * Dp); b.dpo = take(BC * npo * Dp);
+        b.du = take(BL * nlf * Dp); b.dxp = take(padded ? BL * Dp : 0);
         // split-K slabs: at most 1024 wave-sized partial blocks of 80x80 per weight-gradient GEMM
         b.slab_floats = std::max((size_t)2048 * 80 * 80, (size_t)128 * (Dp * Dp + Dp));
         b.slab = take(b.slab_floats);
-        b.gwcat = take(nb * Dp * Dp); b.gbcat = take(nb * Dp); b.gw1ro = take(Dp * Dp);
+        b.gwcat = take(nb * Dp * Dp); b.gbcat = take(nb * Dp); b.gw1ro = take(npo * Dp * Dp);
         b.gw2i = take(Dp * Dp); b.gb2i = take(Dp); b.gw2o = take(Dp * Dp); b.gb2o = take(Dp);
-        b.gwl = take(Dp * Dp); b.gbl = take(Dp); b.groot = take(Dp);
+        b.gwl = take(nlf * Dp * Dp); b.gbl = take(nlf * Dp); b.groot = take(Dp);
         b.dctx = take(R > 0 ? BC * Dp : 0);
         b.pmo = take(R > 0 ? BC * 64 : 0);
         b.dsc = take(R > 0 ? BC * 64 : 0);

@@ -43,6 +43,7 @@ struct FwdLayout {
     size_t x;                           // per-pair first-layer activation relu(PL+PR) (R x Dp)
     size_t sp, pp;                      // per-pair score / softmax weight (R)
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
+    size_t icp, ocp, nrmic, nrmoc, rootc;   // TreeLSTM: cell-state charts (B*C x Dp), their norms, padded root c
     size_t att_u, att_pk, att_nrmu;     // CLIORA per inside cell: u = unit(aggregate) (B*C x Dp), region probabilities (B*C x 64), |aggregate| (B*C)
     size_t total;
 };
@@ -50,7 +51,8 @@ struct FwdLayout {
 struct BwdLayout {
     size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C)
     size_t da, ds;                      // per-pair grads (R x Dp), (R)
-    size_t dz;                          // per-pair grad at the second pre-activation (R x Dp)
+    size_t dz;                          // per-pair grad at the second pre-activation (R x Dp); TreeLSTM: d c_a per pair
+    size_t dcb, vc, dgc, grootc;        // TreeLSTM: d c_b per pair (R x Dp), cell-state grads per cell (B*C x Dp) x2, d root c
     size_t dpi, dpo;                    // grads of the projections
     size_t du, dxp;                     // leaf pre-activation grad, padded dx
     size_t slab;                        // split-K partial sums for the weight-gradient GEMMs
@@ -62,6 +64,9 @@ struct BwdLayout {
 
 struct Plan {
     int B, L, D, Dp, C, share, normalize, R;
+    int arch;                 // 0 = DioraMLP, 1 = DioraTreeLSTM (composition of cliora/net/vg.py:28-76, commented out upstream)
+    int npo, nleaf;           // Dp-wide blocks per outside-cell projection (1 | 5) and per leaf pre-activation (1 | 3)
+    int off_pr, off_ql;       // block index of PR and QL inside an inside-cell projection row (1,2 | 5,10)
     int nblk;                 // projection blocks per inside cell: PL, PR, QL (+ PLo, QLo when not shared)
     int blk_plo, blk_qlo;     // which block the outside pass reads for sibling PL / QL
     int P_in, P_out;          // span pairs per sentence
@@ -92,7 +97,7 @@ struct Plan {
 };
 
 // Builds every host table and the workspace layouts.  Returns "" or an error message.
-std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R);
+std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch = 0);
 
 // Flattens all int32 tables into one array (to upload once); fills p.dev offsets.
 std::vector<int32_t> flatten_tables(Plan& p);

@@ -57,6 +57,9 @@ typedef struct cliora_params {
     float *in_w1, *in_b1, *in_w2, *in_b2, *in_mat;
     float *out_w1, *out_b1, *out_w2, *out_b2, *out_mat;
     float *root_h;
+    /* DioraTreeLSTM only (composition of cliora/net/vg.py:28-76, shared inside/outside):
+     * lstm_w (3D,D) leaf, lstm_u (5D,2D), lstm_b (5D), root_c (D) = root_vector_out_c */
+    float *lstm_w, *lstm_u, *lstm_b, *root_c;
 } cliora_params;
 
 /* A plan fixes (batch B, length L, size D, share, normalize, number of image
@@ -67,6 +70,8 @@ typedef struct cliora_params {
  * device memory; do it outside the step loop (the reference caches the same
  * tables in Index, cliora/net/utils.py:67-134). */
 int cliora_plan_create(int B, int L, int D, int share, int normalize, int R, cliora_plan** out);
+/* arch: 0 = DioraMLP (as above), 1 = DioraTreeLSTM (needs share = 1, R = 0) */
+int cliora_plan_create_ex(int B, int L, int D, int share, int normalize, int R, int arch, cliora_plan** out);
 void cliora_plan_destroy(cliora_plan* plan);
 
 /* Bytes the caller must provide.  fwd workspace: written by forward, must stay
@@ -113,6 +118,25 @@ int cliora_chart_backward(cliora_plan* plan, const cliora_params* params,
                           void* bwd_workspace, size_t bwd_workspace_bytes,
                           float* d_x_span, float* d_obj_span, const cliora_params* grads,
                           int ran_outside, void* stream);
+
+/* DioraTreeLSTM (BASELINE config 5).  PARITY UNPINNED: the reference ships this composition only
+ * as commented-out text (cliora/net/vg.py:28-76); what is implemented is that text on the
+ * DioraBase skeleton (cliora/net/diora.py:283-398), constant = 1 inside / 0 outside (diora.py:174),
+ * root_vector_out_c a parameter (the hint at diora.py:470-471).  Same conventions as
+ * cliora_chart_forward / _backward; here the cell-state charts inside_c / outside_c (B,C,D) are
+ * real outputs with cotangents.  Uses lstm_w, lstm_u, lstm_b, in_mat, root_h, root_c of `params`. */
+int cliora_lstm_forward(cliora_plan* plan, const cliora_params* params, const float* x_span,
+                        float* inside_h, float* inside_c, float* inside_s,
+                        float* outside_h, float* outside_c, float* outside_s,
+                        void* fwd_workspace, size_t fwd_workspace_bytes, int run_outside, void* stream);
+int cliora_lstm_backward(cliora_plan* plan, const cliora_params* params, const float* x_span,
+                         const float* inside_h, const float* inside_c, const float* inside_s,
+                         const float* outside_h, const float* outside_c, const float* outside_s,
+                         const float* d_inside_h, const float* d_inside_c, const float* d_inside_s,
+                         const float* d_outside_h, const float* d_outside_c, const float* d_outside_s,
+                         void* fwd_workspace, size_t fwd_workspace_bytes,
+                         void* bwd_workspace, size_t bwd_workspace_bytes,
+                         float* d_x_span, const cliora_params* grads, int ran_outside, void* stream);
 
 /* CLIORA span-region / word-region scorers (cliora/net/cliora.py:453-468):
  *   all_atten (B,B,C,R) = einsum('abx,cdx->acbd', inside_h + outside_h, obj_span)

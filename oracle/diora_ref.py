@@ -69,6 +69,40 @@ def init_params(D, share=True, seed=0, compress=False):
     return P
 
 
+def init_params_treelstm(D, seed=0):
+    """DioraTreeLSTM parameters ~ N(0,1) (shared inside/outside functions), in module order:
+    root_vector_out_h, root_vector_out_c, inside_score_func.mat, inside_compose_func.{W (3D,D), U (5D,2D), B (5D)}.
+    RECONSTRUCTION: the class exists in the reference only as commented-out text (cliora/net/vg.py:28-76)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    return {
+        'root_vector_out_h': rn(D), 'root_vector_out_c': rn(D),
+        'inside_score_func.mat': rn(D, D),
+        'inside_compose_func.W': rn(3 * D, D), 'inside_compose_func.U': rn(5 * D, 2 * D), 'inside_compose_func.B': rn(5 * D),
+    }
+
+
+def treelstm_leaf(P, x):
+    """vg.py:50-61 (commented): [u,i,o] = chunk3(x W^T + B[:3D]); c = sigmoid(i) tanh(u); h = sigmoid(o) tanh(c)."""
+    D = x.shape[-1]
+    act = torch.matmul(x, P['inside_compose_func.W'].t()) + P['inside_compose_func.B'][:3 * D]
+    a = torch.chunk(act, 3, dim=-1)
+    u, i, o = torch.tanh(a[0]), torch.sigmoid(a[1]), torch.sigmoid(a[2])
+    c = i * u
+    return o * torch.tanh(c), c
+
+
+def treelstm_compose(P, hs, cs, constant=1.0):
+    """vg.py:63-76 (commented): [u,i,o,f0,f1] = chunk5([a;b] U^T + B);
+    c = sigmoid(f0+const) c_a + sigmoid(f1+const) c_b + sigmoid(i) tanh(u); h = sigmoid(o) tanh(c)."""
+    act = torch.matmul(torch.cat(hs, 1), P['inside_compose_func.U'].t()) + P['inside_compose_func.B']
+    a = torch.chunk(act, 5, dim=1)
+    u, i, o = torch.tanh(a[0]), torch.sigmoid(a[1]), torch.sigmoid(a[2])
+    f0, f1 = torch.sigmoid(a[3] + constant), torch.sigmoid(a[4] + constant)
+    c = f0 * cs[0] + f1 * cs[1] + i * u
+    return o * torch.tanh(c), c
+
+
 def _side(P, side, share):
     pre = 'inside' if (share or side == 'inside') else 'outside'
     return dict(
@@ -108,7 +142,7 @@ def _idx(a):
 
 
 def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outside=True,
-                  normalize='unit', share=True, training=False, keep_pairs=False):
+                  normalize='unit', share=True, training=False, keep_pairs=False, arch='mlp'):
     """DioraBase.forward for DioraMLP: diora.py:424-450 (text) / cliora.py:438-468 (VL).
 
     Returns a dict with the six charts, and -- when ``keep_pairs`` -- the
@@ -118,15 +152,25 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
     B, L, D = x_span.shape
     vl = obj_span is not None
     nrm = _normalizer(normalize)
-    Win, Wout = _side(P, 'inside', share), _side(P, 'outside', share)
+    lstm = arch == 'treelstm'           # RECONSTRUCTION (parity unpinned): vg.py:28-76 on the DioraBase skeleton
+    if lstm:
+        assert share and not vl
+        Win = Wout = dict(M=P['inside_score_func.mat'])
+    else:
+        Win, Wout = _side(P, 'inside', share), _side(P, 'outside', share)
     off = CL.level_offsets(L)
     ch = Charts(B, L, D)
     pair_s_in, pair_s_out = {}, {}
 
     # ---- leaves: diora.py:58-63,283-292 / cliora.py:71-80,290-301
-    h = torch.tanh(F.linear(x_span, P['inside_compose_func.leaf_fc.weight'],
-                            P['inside_compose_func.leaf_fc.bias']))
-    if vl:
+    if lstm:
+        h, c = treelstm_leaf(P, x_span)
+    else:
+        h = torch.tanh(F.linear(x_span, P['inside_compose_func.leaf_fc.weight'],
+                                P['inside_compose_func.leaf_fc.bias']))
+    if lstm:
+        pass
+    elif vl:
         h = nrm(h)
         cxt = attention_head(h, obj_span, obj_span, training)
         h = h + cxt
@@ -145,7 +189,7 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
         lh, rh = g(ch.inside_h, lidx, D), g(ch.inside_h, ridx, D)
         lc, rc = g(ch.inside_c, lidx, D), g(ch.inside_c, ridx, D)
         ls, rs = g(ch.inside_s, lidx, 1), g(ch.inside_s, ridx, 1)
-        ph, pc = compose_mlp(Win, lh, rh)
+        ph, pc = treelstm_compose(P, [lh, rh], [lc, rc], 1.0) if lstm else compose_mlp(Win, lh, rh)
         s = (bilinear(Win['M'], lh, rh) + ls + rs).view(B, Lc, N, 1)
         p = torch.softmax(s, dim=2)
         h_agg = torch.sum(ph.view(B, Lc, N, -1) * p, 2)
@@ -165,7 +209,10 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
     # ---- outside pass: diora.py:337-398
     if outside:
         rh_ = nrm(P['root_vector_out_h'].view(1, 1, D).expand(B, 1, D))
-        rc_ = nrm(torch.full((B, 1, D), 0, dtype=torch.float32))
+        if lstm:      # diora.py:346-350 with a root_vector_out_c parameter (the commented hint at diora.py:470-471)
+            rc_ = nrm(P['root_vector_out_c'].view(1, 1, D).expand(B, 1, D))
+        else:
+            rc_ = nrm(torch.full((B, 1, D), 0, dtype=torch.float32))
         ch.outside_h[:, -1:] = rh_
         ch.outside_c[:, -1:] = rc_
         for level in range(L - 2, -1, -1):
@@ -176,7 +223,10 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
             par_h, sib_h = gp(ch.outside_h, D), gs(ch.inside_h, D)
             par_c, sib_c = gp(ch.outside_c, D), gs(ch.inside_c, D)
             par_s, sib_s = gp(ch.outside_s, 1), gs(ch.inside_s, 1)
-            ph, pc = compose_mlp(Wout, sib_h, par_h)           # order [sibling, parent] :366-368
+            if lstm:   # outside_compose passes constant=0 (diora.py:174)
+                ph, pc = treelstm_compose(P, [sib_h, par_h], [sib_c, par_c], 0.0)
+            else:
+                ph, pc = compose_mlp(Wout, sib_h, par_h)       # order [sibling, parent] :366-368
             s = (bilinear(Wout['M'], sib_h, par_h) + sib_s + par_s).view(B, -1, Lc, 1)
             p = torch.softmax(s, dim=1)
             N = s.shape[1]

@@ -266,6 +266,59 @@ def net_case(name, D, B, L, V, K, seed, vl):
     save(name, **arrs)
 
 
+def treelstm_case(name, D, B, L, seed):
+    """RECONSTRUCTION, not tested reference behaviour: the TreeLSTM class exists in the reference only as
+    commented-out text (cliora/net/vg.py:28-76).  Here that text is un-commented IN MEMORY, executed, and
+    plugged into the live DioraBase skeleton (cliora/net/diora.py:205-450) the way the original DIORA did
+    (inside/outside functions shared, root_vector_out_c a parameter: the hint at diora.py:470-471).
+    Only inputs and outputs are stored."""
+    import torch.nn as nn
+    src = open('/root/reference/cliora/net/vg.py').read().split('\n')[27:76]
+    code = '\n'.join(l[2:] if l.startswith('# ') else l.lstrip('#') for l in src)
+    ns = {'nn': nn, 'torch': torch}
+    exec(code, ns)
+    TreeLSTM = ns['TreeLSTM']
+
+    class DioraTreeLSTM(ref_diora.DioraBase):
+        def init_parameters(self):
+            self.inside_score_func = ref_diora.Bilinear(self.size)
+            self.inside_compose_func = TreeLSTM(self.size, leaf=True)
+            self.outside_score_func = self.inside_score_func
+            self.outside_compose_func = self.inside_compose_func
+            self.root_vector_out_h = nn.Parameter(torch.FloatTensor(self.size))
+            self.root_vector_out_c = nn.Parameter(torch.FloatTensor(self.size))
+
+    torch.manual_seed(seed)
+    net = DioraTreeLSTM(D, outside=True, normalize='unit', compress=False, share=True)
+    seeded_params(net, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    C = L * (L + 1) // 2
+    x = torch.randn(B, L, D, generator=g).requires_grad_(True)
+    keys = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+    cot = {k: torch.randn((B, C, 1 if k.endswith('_s') else D), generator=g) for k in keys}
+    net.train()
+    net(x, x)
+    sum((getattr(net, k) * v).sum() for k, v in cot.items()).backward()
+    arrs = dict(x_span=x.detach().numpy())
+    arrs.update(state_np(net, 'param__'))
+    arrs.update({'cot__' + k: v.numpy() for k, v in cot.items()})
+    arrs.update({k: getattr(net, k).detach().numpy().copy() for k in keys})
+    seen = set()
+    for k, p in net.named_parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            arrs['grad__' + k.replace('.', '__')] = p.grad.numpy().copy()
+    arrs['grad__x_span'] = x.grad.numpy().copy()
+    net.eval()
+    attach_hooks(net)
+    with torch.no_grad():
+        net(x.detach(), x.detach())
+    trees, spans = run_cky(net, B, L)
+    arrs['meta'] = np.array(json.dumps(dict(META, D=D, B=B, L=L, seed=seed, reconstruction=True,
+                                            trees=[tree_to_str(t) for t in trees])))
+    save(name, **arrs)
+
+
 if __name__ == '__main__':
     index_tables()
     diora_case('diora_c1.npz', D=50, B=8, L=10, seed=1234)                       # BASELINE config 1
@@ -276,3 +329,4 @@ if __name__ == '__main__':
     cliora_case('cliora_small.npz', D=50, B=4, L=8, seed=21)                     # config 3 shape, small
     net_case('net_diora.npz', D=40, B=4, L=6, V=97, K=10, seed=31, vl=False)
     net_case('net_cliora.npz', D=40, B=4, L=6, V=97, K=10, seed=33, vl=True)
+    treelstm_case('treelstm_recon.npz', D=24, B=3, L=7, seed=41)

@@ -1,0 +1,75 @@
+"""DioraTreeLSTM on the GPU vs the reconstruction fixture and the CPU oracle.  PARITY UNPINNED: the
+reference holds this composition only as commented-out text (cliora/net/vg.py:28-76); see
+cliora_amd/treelstm.py and tests/golden/make_golden.py::treelstm_case."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, params_from_golden
+
+pytestmark = pytest.mark.gpu
+KEYS = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+
+
+def _module(P, D):
+    from cliora_amd.treelstm import DioraTreeLSTM
+    m = DioraTreeLSTM(D)
+    sd = m.state_dict()
+    for k in sd:
+        sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].detach().clone()
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def _err(a, b):
+    return float(np.abs(a.detach().float().cpu().numpy() - np.asarray(b)).max())
+
+
+def _scale(b):
+    return max(1.0, float(np.abs(np.asarray(b)).max()))
+
+
+def test_treelstm_reconstruction_fixture():
+    g = load_golden('treelstm_recon.npz')
+    meta = g['meta']
+    m = _module(params_from_golden(g), meta['D'])
+    x = torch.from_numpy(g['x_span']).cuda().requires_grad_(True)
+    m(x, x)
+    for k in KEYS:
+        assert _err(getattr(m, k), g[k]) <= 1e-4 * _scale(g[k]), k
+    torch.autograd.backward([getattr(m, k) for k in KEYS], [torch.from_numpy(g['cot__' + k]).cuda() for k in KEYS])
+    named = dict(m.named_parameters())
+    for k, v in g.items():
+        if k.startswith('grad__'):
+            name = k[6:].replace('__', '.')
+            t = x.grad if name == 'x_span' else named[name].grad
+            assert _err(t, v) <= 2e-4 * _scale(v), '%s %.3e' % (k, _err(t, v))
+    m.eval()
+    with torch.no_grad():
+        m(x.detach(), x.detach())
+    assert [str(t) for t in m.cky()] == meta['trees']
+
+
+@pytest.mark.parametrize('D,B,L', [(400, 2, 12), (64, 4, 9)])
+def test_treelstm_against_oracle(D, B, L):
+    from oracle import diora_ref as R
+    P = R.init_params_treelstm(D, seed=6)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(B, L, D, generator=gen)
+    m = _module(P, D)
+    xg = x.clone().cuda().requires_grad_(True)
+    m(xg, xg)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, arch='treelstm')
+    C = L * (L + 1) // 2
+    cot = {k: torch.randn(B, C, 1 if k.endswith('_s') else D, generator=gen) for k in KEYS}
+    sum((ref[k] * cot[k]).sum() for k in KEYS).backward()
+    torch.autograd.backward([getattr(m, k) for k in KEYS], [cot[k].cuda() for k in KEYS])
+    for k in KEYS:
+        assert _err(getattr(m, k), ref[k].detach().numpy()) <= 1e-4 * _scale(ref[k].detach().numpy()), k
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        assert _err(named[k].grad, p.grad.numpy()) <= 2e-4 * _scale(p.grad.numpy()), k
+    assert _err(xg.grad, xc.grad.numpy()) <= 2e-4 * _scale(xc.grad.numpy())

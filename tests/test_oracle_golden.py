@@ -209,3 +209,24 @@ def test_net_losses_and_adam_steps(golden, name, vl):
         opt.step()
     for k in train_keys:
         close(P[k], g['after3__' + k.replace('.', '__')], tol=2e-4, what='after3 ' + k)
+
+
+def test_treelstm_reconstruction_matches_commented_reference_code(golden):
+    """TreeLSTM is PARITY-UNPINNED: the reference ships it only as commented-out text (vg.py:28-76).
+    The fixture was made by executing that text against the live DioraBase; the oracle's own
+    restatement must reproduce it."""
+    g = golden('treelstm_recon.npz')
+    m = g['meta']
+    assert m['reconstruction']
+    P = {k: v.requires_grad_(True) for k, v in params_from_golden(g).items() if not k.startswith('outside_')}
+    x = torch.from_numpy(g['x_span']).requires_grad_(True)
+    out = R.diora_forward(P, x, x, arch='treelstm', training=True, keep_pairs=True)
+    keys = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+    for k in keys:
+        close(out[k], g[k], what=k)
+    sum((out[k] * torch.from_numpy(g['cot__' + k])).sum() for k in keys).backward()
+    for k, v in g.items():
+        if k.startswith('grad__') and k != 'grad__x_span':
+            close(P[k[6:].replace('__', '.')].grad, v, tol=2e-5, what=k)
+    close(x.grad, g['grad__x_span'], tol=2e-5, what='grad x')
+    assert [str(t) for t in R.cky_trees(out['pair_s_in'], m['B'], m['L'])] == m['trees']
