@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='sentences per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the gradient all-reduce even at world size 1 (self-test of the N>1 path)')
     args = ap.parse_args()
 
     import torch
@@ -92,8 +93,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
@@ -107,7 +112,7 @@ def main():
     x = torch.randn(B, L, D, generator=g).to(dev)
     cots = [torch.randn(B, C, w, generator=g).to(dev) for w in (D, 1, D, 1)]
     params = [p for p in model.parameters() if p.requires_grad]
-    reducer = FlatGradAllReduce(params) if world > 1 else None
+    reducer = FlatGradAllReduce(params) if use_dist else None
     keys = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
 
     def step():
@@ -120,7 +125,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -138,7 +143,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -188,7 +193,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -90,6 +90,74 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
     };
     if (nseg == 1) { stage(0); __syncthreads(); }
 
+    if (nseg == 1) {
+        // Single weight segment (the compose layer): no barrier in the loop, and the wave pipelines
+        // ACROSS its tiles -- the row indices of the next tile are fetched during the second-to-last
+        // stage of the current one and its first A stage during the last, so a tile starts with its
+        // operands already in flight instead of paying two dependent load latencies.
+        const int stride = gridDim.x * WAVES;
+        int tile = blockIdx.x * WAVES + wave;
+        if (tile >= ntiles) return;
+        const int nstages = Kseg / (16 * SC);
+        auto rowof = [&](int t) { const int r = t * 16 + i; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
+        auto ctx = ap.row(rowof(tile));
+        auto ctxn = ctx;
+        Raw cur[SC], nxt[SC];
+#pragma unroll
+        for (int j = 0; j < SC; ++j) cur[j] = ap.fetch(ctx, 16 * j + 4 * q);
+        while (true) {
+            const int ntile = tile + stride;
+            const bool has_next = ntile < ntiles;
+            f32x4 acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int stg = 0; stg < nstages; ++stg) {
+                const int ks = stg * 16 * SC;
+                if (stg + 1 < nstages) {
+#pragma unroll
+                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctx, ks + 16 * (SC + j) + 4 * q);
+                    if (has_next && (stg + 2 == nstages || nstages == 1)) ctxn = ap.row(rowof(ntile));
+                } else if (has_next) {
+                    if (nstages == 1) ctxn = ap.row(rowof(ntile));
+#pragma unroll
+                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctxn, 16 * j + 4 * q);
+                }
+#pragma unroll
+                for (int j = 0; j < SC; ++j) {
+                    const float4 a = ap.finish(ctx, cur[j]);
+                    // optional side output of the A fragment (materialises x / dz for the weight-gradient
+                    // GEMM): each column block writes its 1/gridDim.y share of the k-chunks
+                    if (AProd::kSide && ((ks >> 4) + j) % (int)gridDim.y == (int)blockIdx.y) ap.side(ctx, ks + 16 * j + 4 * q, a);
+                    float4 b[CT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(bbase + c * 16 * ldb + ks + 16 * j);
+                    // k-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA
+                    // has a 40-cycle dependent latency against a 32-cycle issue interval)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].x, a.x, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].y, a.y, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].z, a.z, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma16(b[c].w, a.w, acc[c]);
+                }
+#pragma unroll
+                for (int j = 0; j < SC; ++j) cur[j] = nxt[j];
+            }
+            if (tile * 16 + i < nrows) {
+                const auto rc = epi.row(tile * 16 + i);
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    epi.store4(rc, col0 + c * 16 + 4 * q, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
+            }
+            if (!has_next) break;
+            ctx = ctxn;
+            tile = ntile;
+        }
+        return;
+    }
+
     for (int tile0 = blockIdx.x * WAVES; tile0 < ntiles; tile0 += gridDim.x * WAVES) {
         const int tile = tile0 + wave;
         const bool active = tile < ntiles;       // inactive waves still take part in the barriers
