@@ -330,3 +330,47 @@ if __name__ == '__main__':
     net_case('net_diora.npz', D=40, B=4, L=6, V=97, K=10, seed=31, vl=False)
     net_case('net_cliora.npz', D=40, B=4, L=6, V=97, K=10, seed=33, vl=True)
     treelstm_case('treelstm_recon.npz', D=24, B=3, L=7, seed=41)
+    sampler_case('sampler_batches.npz')
+
+
+def sampler_case(name):
+    """Bucketed batching (cliora/data/dataloader.py:11-113) and rank partition (batch_iterator.py:53-66)
+    on a synthetic corpus.  h5py is absent here; the module only needs it at import time."""
+    sys.modules.setdefault('h5py', types.ModuleType('h5py'))
+    from cliora.data.dataloader import FixedLengthBatchSampler
+    from cliora.data.batch_iterator import BatchIterator
+
+    class DS:          # what the sampler touches: len(ds) and ds.dataset[i]
+        def __init__(self, sents):
+            self.dataset = sents
+
+        def __len__(self):
+            return len(self.dataset)
+
+    rs = np.random.RandomState(5)
+    lengths = rs.randint(3, 41, size=600)
+    sents = [[0] * int(n) for n in lengths]
+    arrs = dict(lengths=lengths.astype(np.int32))
+    cases = [dict(batch_size=16, include_partial=False, maxlen=None, length_to_size=None, seed=11),
+             dict(batch_size=16, include_partial=True, maxlen=30, length_to_size=None, seed=3),
+             dict(batch_size=32, include_partial=True, maxlen=None, length_to_size={10: 16, 25: 4}, seed=7)]
+    for ci, c in enumerate(cases):
+        s = FixedLengthBatchSampler(DS(sents), c['batch_size'], include_partial=c['include_partial'],
+                                    rng=np.random.RandomState(c['seed']), maxlen=c['maxlen'], length_to_size=c['length_to_size'])
+        flat, sizes = [], []
+        for _epoch in range(2):                      # the rng carries over between epochs
+            for b in s:
+                flat += list(b)
+                sizes.append(len(b))
+        arrs['case%d_flat' % ci] = np.array(flat, dtype=np.int32)
+        arrs['case%d_sizes' % ci] = np.array(sizes, dtype=np.int32)
+    # rank partition of tensors and lists
+    bi = BatchIterator.__new__(BatchIterator)
+    t = torch.arange(22).view(11, 2)
+    lst = list(range(100, 111))
+    for world in (2, 4):
+        for rank in range(world):
+            arrs['part_t_%d_%d' % (world, rank)] = bi.partition(t, rank, range(world)).numpy()
+            arrs['part_l_%d_%d' % (world, rank)] = np.array(bi.partition(lst, rank, range(world)), dtype=np.int32)
+    arrs['meta'] = np.array(json.dumps(dict(META, cases=[{k: (v if not isinstance(v, dict) else {str(a): b for a, b in v.items()}) for k, v in c.items()} for c in cases])))
+    save(name, **arrs)
