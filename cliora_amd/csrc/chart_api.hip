@@ -153,6 +153,17 @@ static int pick_tiles(int ntiles16) {
     return 1;
 }
 
+// Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
+// gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
+static int g_split_bf16 = -1;
+static bool split_bf16() {
+    if (g_split_bf16 < 0) {
+        const char* e = getenv("CLIORA_MFMA");
+        g_split_bf16 = (e && !strcmp(e, "f32")) ? 0 : 1;
+    }
+    return g_split_bf16 == 1;
+}
+
 template <int CT, int SC, int WAVES, class AP, class EP>
 static int launch_rows_inst(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
     const size_t lds = (size_t)CT * 16 * (Kseg + WS_LDS_PAD) * sizeof(float);
@@ -163,12 +174,14 @@ static int launch_rows_inst(hipStream_t st, const float* W, int Kseg, int nseg, 
     }
     const int ntiles = (nrows + 15) / 16;
     const int gy = ncols / (16 * CT);
-    int gx = (ntiles + WAVES - 1) / WAVES;
+    // one workgroup per CU (the weight block fills LDS): take the fewest passes over the row tiles the chip allows,
+    // then the smallest grid that still does it in that many passes
     const int cap = std::max(1, 256 / gy);
-    if (gx > cap) gx = cap;
+    const int passes = (ntiles + WAVES * cap - 1) / (WAVES * cap);
+    int gx = (ntiles + WAVES * passes - 1) / (WAVES * passes);
     // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8
     // the gy column blocks that re-read the same A rows share one XCD's L2 (speed only, never correctness)
-    if (gx >= 8) gx = (gx + 7) / 8 * 8 <= cap ? (gx + 7) / 8 * 8 : gx / 8 * 8;
+    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;
     hipLaunchKernelGGL((rows_gemm_ws<CT, SC, WAVES, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, W, Kseg * nseg, Kseg, nseg,
                        nrows, ap, ep);
     LAUNCHOK("rows_gemm_ws");
@@ -281,15 +294,29 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
     int rps = (nrows + nsl - 1) / nsl;
     rps = (rps + TN_RS - 1) / TN_RS * TN_RS;
     nsl = (nrows + rps - 1) / rps;
-    const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPOK(hipFuncSetAttribute((const void*)tn_gemm_dma<NIT, NJT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
     float* csl = slab + (size_t)nsl * Dp * Dp;
-    hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
-    LAUNCHOK("tn_gemm_dma");
+    const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float);
+    if (split_bf16() && lds3 <= 160 * 1024 && (Dp + NJT * 16) / 32 <= TN3_NP) {
+        static bool attr3_done = false;
+        if (!attr3_done) {
+            HIPOK(hipFuncSetAttribute((const void*)tn_gemm_dma3<NIT, NJT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3_done = true;
+        }
+        rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
+        nsl = (nrows + rps - 1) / rps;
+        csl = slab + (size_t)nsl * Dp * Dp;
+        hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds3, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
+        LAUNCHOK("tn_gemm_dma3");
+    } else {
+        const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIPOK(hipFuncSetAttribute((const void*)tn_gemm_dma<NIT, NJT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
+        LAUNCHOK("tn_gemm_dma");
+    }
     const size_t n = (size_t)Dp * Dp;
     hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
     LAUNCHOK("slab_reduce");
@@ -319,16 +346,73 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
 #undef TN_CASE
 }
 
+template <int CT, int WAVES, int PD, class AP, class EP>
+static int launch_rows3_pd(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    const size_t lds = (size_t)CT * 16 * S * sizeof(uint32_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPOK(hipFuncSetAttribute((const void*)rows_gemm_ws3<CT, WAVES, PD, AP, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int ntiles = (nrows + 15) / 16;
+    const int gy = ncols / (16 * CT);
+    // same grid rule as the fp32 kernel: fewest passes over the row tiles, then the smallest grid that does it
+    const int cap = std::max(1, 256 / gy);
+    const int passes = (ntiles + WAVES * cap - 1) / (WAVES * cap);
+    int gx = (ntiles + WAVES * passes - 1) / (WAVES * passes);
+    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;
+    hipLaunchKernelGGL((rows_gemm_ws3<CT, WAVES, PD, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, Wimg, S, K, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ws3");
+    return CLIORA_OK;
+}
+
+template <int CT, int WAVES, class AP, class EP>
+static int launch_rows3_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    // four k-steps of row operands in flight per wave; deeper rings (6, 7) measured the same on MI355X
+    return launch_rows3_pd<CT, WAVES, 4>(st, Wimg, S, K, ncols, nrows, ap, ep);
+}
+
+// out[r][j] = sum_k A(r,k) W[j][k] in split-bf16 arithmetic; Wimg = split_weight_image of W ([ncols][K], S dwords per row)
+template <class AP, class EP>
+static int launch_rows3(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const size_t budget = 150 * 1024;
+    const int nt = ncols / 16;
+    const long long ntiles = (nrows + 15) / 16;
+    for (int ct : {5, 4, 2, 1}) {
+        if (nt % ct) continue;
+        if ((size_t)ct * 16 * S * sizeof(uint32_t) > budget) continue;
+        const bool two = ntiles * (nt / ct) > 1536;      // two waves per SIMD once the launch fills the chip
+        switch (ct) {
+#define WS3_CASE(c) case c: return two ? launch_rows3_inst<c, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<c, 4>(st, Wimg, S, K, ncols, nrows, ap, ep)
+            WS3_CASE(5); WS3_CASE(4); WS3_CASE(2);
+            default: return two ? launch_rows3_inst<1, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<1, 4>(st, Wimg, S, K, ncols, nrows, ap, ep);
+#undef WS3_CASE
+        }
+    }
+    return fail(CLIORA_EINVAL, "weight block does not fit LDS");
+}
+
 // compose layer: weight-stationary kernel for the big levels, split-K kernel for the small ones
 static int g_compose_ksplit_rows = -1;
 template <class AP, class EP>
-static int launch_compose(hipStream_t st, const float* W, int Dp, int nrows, AP ap, EP ep) {
+static int launch_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int nrows, AP ap, EP ep) {
     if (g_compose_ksplit_rows < 0) {
         const char* e = getenv("CLIORA_COMPOSE_KSPLIT_ROWS");
         g_compose_ksplit_rows = e ? atoi(e) : 5000;   // measured crossover on MI355X (r01 sweep: 0..30000)
     }
     if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Dp, Dp, nrows, ap, ep);
+    if (split_bf16()) return launch_rows3(st, reinterpret_cast<const uint32_t*>(Wimg), S3, Dp, Dp, nrows, ap, ep);
     return launch_rows(st, W, Dp, 1, Dp, nrows, ap, ep);
+}
+
+// split-bf16 LDS images of up to four [Dp][Dp] weight matrices already in the workspace
+static int build_weight_images(hipStream_t st, int n, const float* const* src, float* const* dst, int Dp, int Kp, int S) {
+    SplitImageTab tab{};
+    for (int k = 0; k < n; ++k) { tab.src[k] = src[k]; tab.dst[k] = reinterpret_cast<uint32_t*>(dst[k]); }
+    hipLaunchKernelGGL(split_weight_image, dim3((S + 255) / 256, Dp, n), dim3(256), 0, st, tab, Dp, Dp, Kp, S);
+    LAUNCHOK("split_weight_image");
+    return CLIORA_OK;
 }
 
 static int run_copies(hipStream_t st, const CopyTable& tab) {
@@ -436,6 +520,11 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
         if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
         OKR(run_copies(st, t));
+        if (split_bf16()) {
+            const float* src[4] = {ws + f.w2i, ws + f.w2iT, ws + f.w2o, ws + f.w2oT};
+            float* dst[4] = {ws + f.w2i3, ws + f.w2iT3, ws + f.w2o3, ws + f.w2oT3};
+            OKR(build_weight_images(st, p.share ? 2 : 4, src, dst, Dp, f.Kp3, f.S3));
+        }
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
@@ -464,7 +553,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("pair_scores_fwd");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-            OKR(launch_compose(st, ws + f.w2i, Dp, nrows,
+            OKR(launch_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, nrows,
                             ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi, ws + f.x, Dp},
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
@@ -498,7 +587,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             LAUNCHOK("pair_scores_fwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                OKR(launch_compose(st, ws + f.w2o, Dp, nrows,
+                OKR(launch_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, nrows,
                                 ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.x, Dp},
                                 StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
             }
@@ -581,7 +670,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("cell_scores_bwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-                OKR(launch_compose(st, ws + f.w2oT, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+                OKR(launch_compose(st, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
                                 ComposeBwdE{Xp, DA, g.rowbase, Dp}));
             }
         }
@@ -620,7 +709,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         LAUNCHOK("cell_scores_bwd(in)");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-            OKR(launch_compose(st, ws + f.w2iT, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+            OKR(launch_compose(st, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
                             ComposeBwdE{Xp, DA, g.rowbase, Dp}));
         }
     }

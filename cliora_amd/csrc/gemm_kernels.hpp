@@ -21,6 +21,7 @@
 // chunk; A and B use the same permutation, the sum over k is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace cliora {
 
@@ -212,6 +213,170 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
             for (int c = 0; c < CT; ++c)
                 epi.store4(rc, col0 + c * 16 + 4 * q, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") arithmetic: an fp32 value v is carried as hi = bf16(v) and lo = bf16(v - hi)
+// (both round-to-nearest, v_cvt_pk_bf16_f32), and a product a*b is accumulated in fp32 as
+// a_hi*b_hi + a_lo*b_hi + a_hi*b_lo on v_mfma_f32_16x16x32_bf16.  The dropped terms are below
+// 2^-16 of |a*b| per product (fp32 itself keeps 2^-24), the accumulator stays fp32, and bf16 has the
+// fp32 exponent range, so there is no scaling to manage.  Three such MFMAs cover k = 32 in 48 cycles
+// where the fp32-input MFMA takes 256: the matrix core stops being the limit of the compose layer.
+//
+// v_mfma_f32_16x16x32_bf16 operand maps: A[i = lane&15][k = 8*(lane>>4) + j], B[k = 8*(lane>>4) + j][n = lane&15],
+// j = 0..7 in the lane's four operand registers; D as for the fp32 form.  Which k of the 32-deep step a slot holds is
+// free as long as both operands agree (the sum over k is unchanged): see split_weight_image.
+// ---------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ f32x4 mfma32bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // a -> low half, b -> high half
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, r);
+}
+// eight consecutive-k fp32 values -> hi and lo operand registers
+__device__ __forceinline__ void split_bf16x8(const float4 a, const float4 b, u32x4& hi, u32x4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t h = pack_bf16(v[2 * p], v[2 * p + 1]);
+        hi[p] = h;
+        lo[p] = pack_bf16(v[2 * p] - __uint_as_float(h << 16), v[2 * p + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
+
+// Weight image for rows_gemm_ws3: row j (one output column) = [Kp/2 dwords of hi pairs | Kp/2 dwords of lo pairs | 4 pad
+// dwords], Kp = K rounded up to 32, zero beyond K.  The row stride S = Kp + 4 dwords makes S/4 odd, so the sixteen
+// 16-byte fragment reads of one MFMA operand (rows j..j+15, same k) fall in sixteen different 16-byte bank groups.
+// grid = (ceil(S/256), nrows, nmat); the matrices are [nrows][ldw] fp32 and are laid out one after the other.
+struct SplitImageTab { const float* src[4]; uint32_t* dst[4]; };
+__global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab, int ldw, int K, int Kp, int S) {
+    const float* W = tab.src[blockIdx.z] + (size_t)blockIdx.y * ldw;
+    uint32_t* img = tab.dst[blockIdx.z] + (size_t)blockIdx.y * S;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= S) return;
+    const int half = Kp >> 1;
+    if (p >= Kp) { img[p] = 0u; return; }
+    // operand dword pr of the row = k-step pr/16, lane group g = (pr%16)/4, register q = pr%4, holding the k pair
+    // 32*step + 4g + 2q (q < 2) or 32*step + 16 + 4g + 2(q-2): a lane's eight k are two runs of four, 16 apart, so
+    // that the row operand's two 16-byte fetches per k-step each read 64 contiguous bytes of a row across g
+    const int pr = p < half ? p : p - half;
+    const int stp = pr >> 4, g = (pr >> 2) & 3, q = pr & 3;
+    const int k0 = 32 * stp + 4 * g + (q < 2 ? 2 * q : 16 + 2 * (q - 2));
+    const float v0 = k0 < K ? W[k0] : 0.f, v1 = k0 + 1 < K ? W[k0 + 1] : 0.f;
+    const uint32_t h = pack_bf16(v0, v1);
+    img[p] = p < half ? h : pack_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+}
+
+// ---------------------------------------------------------------------------------
+// rows_gemm_ws3: rows_gemm_ws (single weight segment) in split-bf16 arithmetic.
+//   Wimg   : split_weight_image() of the [ncols][K] weight; block blockIdx.y's CT*16 image rows are one
+//            contiguous piece and are copied to LDS as they are (LDS-DMA, lane-linear)
+//   a wave walks 16-row tiles; per 32-deep k-step a lane fetches its row's 8 consecutive k through the
+//   same AProd functors as the fp32 kernel (two fetches), splits them once, and issues 3*CT MFMAs.
+//   PD k-steps of operand loads are in flight per wave (register ring); the ring runs on across the wave's
+//   tiles, so the next tile's first loads are issued while the current tile's last steps compute.
+// ---------------------------------------------------------------------------------
+template <int CT, int WAVES, int PD, class AProd, class Epi>
+__global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __restrict__ Wimg, int S, int K, int nrows, AProd ap, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    constexpr int T = WAVES * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int Kp = S - 4, half = Kp >> 1;
+    const int col0 = blockIdx.y * (CT * 16);
+    {
+        const uint32_t* src = Wimg + (size_t)col0 * S;
+        const int n16 = CT * 16 * S / 4;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        for (int e0 = wv * 64; e0 < n16; e0 += T) {
+            const int e = e0 + lane;
+            if (e < n16)
+                __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)e * 4),
+                                                 (__attribute__((address_space(3))) void*)(lds_img + e0 * 4), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int ntiles = (nrows + 15) >> 4;
+    const int stride = gridDim.x * WAVES;
+    int tile = blockIdx.x * WAVES + wave;
+    if (tile >= ntiles) return;
+    const int nsteps = Kp >> 5;
+    const int nsteps_p = (nsteps + PD - 1) / PD * PD;     // the ring's slot of k-step s is s % PD in every tile
+    const uint32_t* wfrag = lds_img + i * S + 4 * g;
+    using Raw = typename AProd::Raw;
+    auto rowof = [&](int t) { const int r = t * 16 + i; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
+    // a lane's k at step s: 32s + 4g .. +3 and 32s + 16 + 4g .. +3 (the image's permutation); K is a multiple of 16,
+    // so the first run is always inside the row and the second is inside for every lane or for none
+    Raw ra[PD][2];
+    auto issue = [&](int slot, const decltype(ap.row(0))& c, int s) {
+        const int k = 32 * s + 4 * g;
+        ra[slot][0] = ap.fetch(c, k);
+        if (32 * s + 16 < K) ra[slot][1] = ap.fetch(c, k + 16);
+    };
+    auto ctx = ap.row(rowof(tile));
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl)
+        if (sl < nsteps) issue(sl, ctx, sl);
+    while (true) {
+        const int ntile = tile + stride;
+        const bool has_next = ntile < ntiles;
+        auto ctxn = ctx;
+        if (has_next) ctxn = ap.row(rowof(ntile));
+        f32x4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < nsteps_p; base += PD) {
+#pragma unroll
+            for (int sl = 0; sl < PD; ++sl) {
+                const int st = base + sl;
+                if (st < nsteps) {
+                    const bool second = 32 * st + 16 < K;
+                    const float4 a0 = ap.finish(ctx, ra[sl][0]);
+                    const float4 a1 = second ? ap.finish(ctx, ra[sl][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    // optional side output of the fp32 row fragment (x / dz for the weight-gradient GEMM),
+                    // shared out over the column blocks by k-step
+                    if (AProd::kSide && st % (int)gridDim.y == (int)blockIdx.y) {
+                        const int k = 32 * st + 4 * g;
+                        ap.side(ctx, k, a0);
+                        if (second) ap.side(ctx, k + 16, a1);
+                    }
+                    u32x4 xh, xl;
+                    split_bf16x8(a0, a1, xh, xl);
+                    u32x4 wh[CT], wl[CT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        wh[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st);
+                        wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
+                    }
+                    // term by term over the CT accumulators: dependent MFMAs are CT issues apart
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], xh, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xl, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xh, acc[c]);
+                }
+                const int nst = st + PD;
+                if (nst < nsteps) issue(sl, ctx, nst);
+                else if (has_next && nst >= nsteps_p && sl < nsteps) issue(sl, ctxn, sl);   // nst - nsteps_p == sl: the next tile's k-step sl
+            }
+        }
+        if (tile * 16 + i < nrows) {
+            const auto rc = epi.row(tile * 16 + i);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                epi.store4(rc, col0 + c * 16 + 4 * g, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
+        }
+        if (!has_next) break;
+        ctx = ctxn;
+        tile = ntile;
     }
 }
 
@@ -528,6 +693,148 @@ __global__ __launch_bounds__(256) void tn_gemm_dma(const float* __restrict__ A, 
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg)
                             out[(size_t)((it0 + t) * 16 + q * 4 + reg) * Nj + (jt0 + u) * 16 + i] = acc[t][u][reg];
+    }
+    if (COLSUM && kb == 0) {
+        if (tid < Mi) colsum[(size_t)slice * Mi + tid] = cs0;
+        if (tid + 256 < Mi) colsum[(size_t)slice * Mi + tid + 256] = cs1;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// tn_gemm_dma3: tn_gemm_dma in split-bf16 arithmetic (see the bf16x3 note above).
+//   Same blocks, slices, slab and LDS-DMA staging, but a stage is 32 pair rows = ONE k-step of
+//   v_mfma_f32_16x16x32_bf16.  The fp32 stage in LDS is turned into operands on the way to the registers:
+//   a lane's eight k of a fragment are rows g, 4+g, ..., 28+g of the stage (g = lane>>4; any assignment works
+//   as long as both operands use it, and this one keeps the 32-lane halves of a ds_read_b32 on rows that are
+//   one apart = 16 banks apart for the 400- and 144-float row lengths), read as eight dwords and split once.
+//   The nine column fragments are kept for the whole step; row fragment t+1 is assembled while the 3*NJT
+//   MFMAs of row t issue.
+// ---------------------------------------------------------------------------------
+constexpr int TN3_RS = 32;
+constexpr int TN3_NP = 20;      // LDS-DMA pieces per wave per stage, upper bound: (Mi + NJT*16) / 32
+template <int NIT, int NJT, bool COLSUM>
+__global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A, const float* __restrict__ B, int nrows,
+                                                    int rows_per_slice, int Mi, int Nj, int nkb,
+                                                    float* __restrict__ slab, float* __restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) float lds_t[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.x % nkb, slice = blockIdx.x / nkb;
+    const int NTI = Mi >> 4, NTJ = Nj >> 4;
+    const int jbase = NTJ / nkb, jrem = NTJ % nkb;
+    const int jt0 = kb * jbase + min(kb, jrem);
+    const int njt = jbase + (kb < jrem ? 1 : 0);            // j-tiles of this block (<= NJT)
+    const int ibase = NTI / 4, irem = NTI % 4;
+    const int it0 = wave * ibase + min(wave, irem);
+    const int nit = max(1, ibase + (wave < irem ? 1 : 0));  // i-tiles of this wave (<= NIT)
+    const bool has_tiles = ibase + (wave < irem ? 1 : 0) > 0;
+    const int ldA = Mi, ldX = NJT * 16;
+    const int UA = TN3_RS * (Mi >> 2), UX = TN3_RS * (ldX >> 2);
+    const int bufsz = TN3_RS * (ldA + ldX);
+    const int x4 = ldX >> 2, xv4 = njt * 4;
+
+    const int rbeg = slice * rows_per_slice;
+    const int rend = min(nrows, rbeg + rows_per_slice);
+    const int nstages = rend > rbeg ? (rend - rbeg + TN3_RS - 1) / TN3_RS : 0;
+
+    f32x4 acc[NIT][NJT];
+#pragma unroll
+    for (int a = 0; a < NIT; ++a)
+#pragma unroll
+        for (int b = 0; b < NJT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs0 = 0.f, cs1 = 0.f;
+
+    const int npieces = (UA + UX) >> 6;
+    int p_rr[TN3_NP], p_off[TN3_NP];
+#pragma unroll
+    for (int k = 0; k < TN3_NP; ++k) {
+        const int e = (wave + 4 * k) * 64 + lane;
+        if (e < UA) {
+            p_rr[k] = e / (Mi >> 2);
+            p_off[k] = 4 * (e - p_rr[k] * (Mi >> 2));
+        } else {
+            const int f = e - UA;
+            p_rr[k] = f / x4;
+            p_off[k] = jt0 * 16 + 4 * min(f - p_rr[k] * x4, xv4 - 1);
+        }
+    }
+    auto issue = [&](int stage) {
+        const int r0 = rbeg + stage * TN3_RS;
+        const int rmax = rend - 1 - r0;      // last valid row of the stage: rows past it re-read it (finite) and are masked below
+        float* buf = lds_t + (stage & 1) * bufsz;
+#pragma unroll
+        for (int k = 0; k < TN3_NP; ++k) {
+            const int piece = wave + 4 * k;
+            if (piece < npieces) {
+                const bool isA = piece * 64 < UA;
+                const float* base = isA ? A : B;
+                const int ld = isA ? Mi : Nj;
+                const float* src = base + (size_t)(r0 + min(p_rr[k], rmax)) * ld + p_off[k];
+                __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    int aoff[NIT], xoff[NJT];
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) aoff[t] = g * ldA + (min(it0, NTI - 1) + min(t, nit - 1)) * 16 + i;
+#pragma unroll
+    for (int u = 0; u < NJT; ++u) xoff[u] = TN3_RS * ldA + g * ldX + min(u, njt - 1) * 16 + i;
+
+    if (nstages > 0) issue(0);
+    for (int st = 0; st < nstages; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // stage st has landed for every wave; buffer (st+1)&1 is free again
+        if (st + 1 < nstages) issue(st + 1);
+        const float* cur = lds_t + (st & 1) * bufsz;
+        const int r0 = rbeg + st * TN3_RS;
+        const int nvalid = rend - r0;    // rows of this stage that exist (>= 32 except in the slice's last stage)
+        auto frag = [&](int off, int ld, bool mask, u32x4& hi, u32x4& lo) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = cur[off + 4 * j * ld];
+                if (mask && 4 * j + g >= nvalid) v[j] = 0.f;
+            }
+            split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+        };
+        const bool tail = nvalid < TN3_RS;    // uniform
+        u32x4 bh[NJT], bl[NJT];
+#pragma unroll
+        for (int u = 0; u < NJT; ++u) frag(xoff[u], ldX, false, bh[u], bl[u]);
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            u32x4 ah, al;
+            frag(aoff[t], ldA, tail, ah, al);
+#pragma unroll
+            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(al, bh[u], acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(ah, bl[u], acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(ah, bh[u], acc[t][u]);
+        }
+        if (COLSUM && kb == 0) {                 // column sums of A (bias gradient), branch-free
+            const int c0 = min(tid, Mi - 1), c1 = min(tid + 256, Mi - 1);
+#pragma unroll 8
+            for (int rr = 0; rr < TN3_RS; ++rr) {
+                const float m = (rr < nvalid) ? 1.f : 0.f;
+                cs0 = fmaf(m, cur[rr * ldA + c0], cs0);
+                cs1 = fmaf(m, cur[rr * ldA + c1], cs1);
+            }
+        }
+    }
+    float* out = slab + (size_t)slice * Mi * Nj;
+    if (has_tiles) {
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+            if (t < nit)
+#pragma unroll
+                for (int u = 0; u < NJT; ++u)
+                    if (u < njt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            out[(size_t)((it0 + t) * 16 + g * 4 + reg) * Nj + (jt0 + u) * 16 + i] = acc[t][u][reg];
     }
     if (COLSUM && kb == 0) {
         if (tid < Mi) colsum[(size_t)slice * Mi + tid] = cs0;

@@ -34,6 +34,8 @@ struct FwdLayout {
     size_t w1ro, w1roT;                 // outside-cell projection W1[:, D:] of the outside compose
     size_t w2i, b2i, w2iT;              // second compose layer, inside weights
     size_t w2o, b2o, w2oT;              // outside weights (alias of inside when shared)
+    size_t w2i3, w2iT3, w2o3, w2oT3;    // split-bf16 LDS images of the four (Dp rows x S3 dwords each; see split_weight_image)
+    int Kp3, S3;                        // image geometry: k rounded up to 32, row stride in dwords
     size_t rootp;                       // root vector, padded
     size_t xp, ihp, ohp;                // padded copies (only when D != Dp; else unused)
     size_t objp;                        // padded obj (CLIORA, D != Dp)
