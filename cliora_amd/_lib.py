@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libcliora_chart.so')
+LIB_PATH = os.environ.get('CLIORA_CHART_LIB') or os.path.join(HERE, 'libcliora_chart.so')   # override: kernel experiments only
 
 NORM = {'none': 0, 'unit': 1}
 KCLASS = {'compose_fwd': 0, 'compose_bwd': 1, 'wgrad': 2}

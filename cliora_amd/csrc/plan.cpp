@@ -141,7 +141,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.w2i = take(Dp * Dp); f.b2i = take(Dp); f.w2iT = take(Dp * Dp);
         if (p.share) { f.w2o = f.w2i; f.b2o = f.b2i; f.w2oT = f.w2iT; }
         else { f.w2o = take(Dp * Dp); f.b2o = take(Dp); f.w2oT = take(Dp * Dp); }
-        f.Kp3 = (int)((Dp + 31) / 32 * 32); f.S3 = f.Kp3 + 4;
+        f.Kp3 = (int)((Dp + 31) / 32 * 32); f.S3 = f.Kp3 + 8;
         f.w2i3 = take(Dp * f.S3); f.w2iT3 = take(Dp * f.S3);
         if (p.share) { f.w2o3 = f.w2i3; f.w2oT3 = f.w2iT3; }
         else { f.w2o3 = take(Dp * f.S3); f.w2oT3 = take(Dp * f.S3); }

@@ -1,3 +1,3 @@
 #!/bin/bash
 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -2
-for m in f32 bf16x3; do echo "mode $m"; CLIORA_MFMA=$m CLIORA_COMPOSE_KSPLIT_ROWS=1500 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['classes'])"; done
+for t in 1500; do CLIORA_COMPOSE_KSPLIT_ROWS=$t python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['classes'])"; done
