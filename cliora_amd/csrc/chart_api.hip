@@ -295,17 +295,20 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
     rps = (rps + TN_RS - 1) / TN_RS * TN_RS;
     nsl = (nrows + rps - 1) / rps;
     float* csl = slab + (size_t)nsl * Dp * Dp;
-    const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float);
+    const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float) + (size_t)NJT * 2048;   // two fp32 stages + the split column fragments
     if (split_bf16() && lds3 <= 160 * 1024 && (Dp + NJT * 16) / 32 <= TN3_NP) {
         static bool attr3_done = false;
         if (!attr3_done) {
             HIPOK(hipFuncSetAttribute((const void*)tn_gemm_dma3<NIT, NJT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr3_done = true;
         }
+        // whole groups of 8 slices (one per XCD), all resident at once: one workgroup per CU, no second round
+        const int nsl_cap = std::max(1, 256 / (8 * nkb)) * 8;
+        if (nsl > nsl_cap) { nsl = nsl_cap; rps = (nrows + nsl - 1) / nsl; }
         rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
         nsl = (nrows + rps - 1) / rps;
         csl = slab + (size_t)nsl * Dp * Dp;
-        hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds3, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
+        hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(256), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
         LAUNCHOK("tn_gemm_dma3");
     } else {
         const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);

@@ -746,13 +746,18 @@ constexpr int TN3_RS = 32;
 constexpr int TN3_NP = 20;      // LDS-DMA pieces per wave per stage, upper bound: (Mi + NJT*16) / 32
 template <int NIT, int NJT, bool COLSUM>
 __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A, const float* __restrict__ B, int nrows,
-                                                    int rows_per_slice, int Mi, int Nj, int nkb,
+                                                    int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
                                                     float* __restrict__ slab, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) float lds_t[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int kb = blockIdx.x % nkb, slice = blockIdx.x / nkb;
+    // workgroups are dealt round-robin over the 8 XCDs by block id: the nkb column blocks of a slice re-read the same
+    // A rows, so they get ids that are equal mod 8 and close together -- one XCD's L2 then serves the re-reads
+    // (grid = 8 * nkb * ceil(nslices / 8); ids whose slice does not exist leave at once)
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
+    const int kb = wq % nkb, slice = (wq / nkb) * 8 + xcd;
+    if (slice >= nslices) return;
     const int NTI = Mi >> 4, NTJ = Nj >> 4;
     const int jbase = NTJ / nkb, jrem = NTJ % nkb;
     const int jt0 = kb * jbase + min(kb, jrem);
@@ -808,11 +813,9 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
         }
     };
 
-    int aoff[NIT], xoff[NJT];
+    int aoff[NIT];
 #pragma unroll
     for (int t = 0; t < NIT; ++t) aoff[t] = g * ldA + (min(it0, NTI - 1) + min(t, nit - 1)) * 16 + i;
-#pragma unroll
-    for (int u = 0; u < NJT; ++u) xoff[u] = TN3_RS * ldA + g * ldX + min(u, njt - 1) * 16 + i;
 
     if (nstages > 0) issue(0);
     for (int st = 0; st < nstages; ++st) {
@@ -822,29 +825,66 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
         const float* cur = lds_t + (st & 1) * bufsz;
         const int r0 = rbeg + st * TN3_RS;
         const int nvalid = rend - r0;    // rows of this stage that exist (>= 32 except in the slice's last stage)
-        auto frag = [&](int off, int ld, bool mask, u32x4& hi, u32x4& lo) {
+        auto frag = [&](int off, int ld, u32x4& hi, u32x4& lo) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = cur[off + 4 * j * ld];
-                if (mask && 4 * j + g >= nvalid) v[j] = 0.f;
-            }
+            for (int j = 0; j < 8; ++j) v[j] = cur[off + 4 * j * ld];
             split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
         };
-        const bool tail = nvalid < TN3_RS;    // uniform
+        // the slice's last stage may be short: its missing A rows (DMA re-read the last valid row there) are zeroed
+        // in LDS, so the operand reads below need no mask
+        if (nvalid < TN3_RS) {
+            float* cw = lds_t + (st & 1) * bufsz;
+            for (int e = nvalid * ldA + tid; e < TN3_RS * ldA; e += 256) cw[e] = 0.f;
+        }
+        // the NJT column fragments are the same for all four waves: each wave splits its share once and leaves the
+        // operand registers of all 64 lanes in LDS ([fragment][hi|lo][lane] x 16 B, read back conflict-free)
+        u32x4* bconv = reinterpret_cast<u32x4*>(lds_t + 2 * bufsz);
+        for (int u = wave; u < NJT; u += 4) {
+            u32x4 h, l;
+            frag(TN3_RS * ldA + g * ldX + min(u, njt - 1) * 16 + i, ldX, h, l);
+            bconv[(2 * u) * 64 + lane] = h;
+            bconv[(2 * u + 1) * 64 + lane] = l;
+        }
+        __syncthreads();
         u32x4 bh[NJT], bl[NJT];
 #pragma unroll
-        for (int u = 0; u < NJT; ++u) frag(xoff[u], ldX, false, bh[u], bl[u]);
+        for (int u = 0; u < NJT; ++u) { bh[u] = bconv[(2 * u) * 64 + lane]; bl[u] = bconv[(2 * u + 1) * 64 + lane]; }
+        // three-deep pipeline over the wave's row tiles: LDS reads of tile t+2, split of tile t+1 and the 3*NJT MFMAs of
+        // tile t are issued interleaved (sched_group_barrier), so neither the LDS latency nor the split is exposed
+        float raw[2][8];
+        u32x4 ah[2], al[2];
+        auto loadraw = [&](int t, float (&r)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = cur[aoff[t] + 4 * j * ldA];
+        };
+        auto conv = [&](const float (&r)[8], u32x4& hi, u32x4& lo) {
+            split_bf16x8(make_float4(r[0], r[1], r[2], r[3]), make_float4(r[4], r[5], r[6], r[7]), hi, lo);
+        };
+        loadraw(0, raw[0]);
+        conv(raw[0], ah[0], al[0]);
+        if (NIT > 1) loadraw(1, raw[1]);
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
-            u32x4 ah, al;
-            frag(aoff[t], ldA, tail, ah, al);
+            if (t + 1 < NIT) conv(raw[(t + 1) & 1], ah[(t + 1) & 1], al[(t + 1) & 1]);
+            if (t + 2 < NIT) loadraw(t + 2, raw[t & 1]);
 #pragma unroll
-            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(al, bh[u], acc[t][u]);
+            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(al[t & 1], bh[u], acc[t][u]);
 #pragma unroll
-            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(ah, bl[u], acc[t][u]);
+            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(ah[t & 1], bl[u], acc[t][u]);
 #pragma unroll
-            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(ah, bh[u], acc[t][u]);
+            for (int u = 0; u < NJT; ++u) acc[t][u] = mfma32bf(ah[t & 1], bh[u], acc[t][u]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // 1 VALU
+            }
+#pragma unroll
+            for (int k = 8; k < 3 * NJT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
         }
         if (COLSUM && kb == 0) {                 // column sums of A (bias gradient), branch-free
             const int c0 = min(tid, Mi - 1), c1 = min(tid + 256, Mi - 1);
