@@ -74,6 +74,8 @@ def lib():
     L.cliora_prof_read.restype = i32
     L.cliora_last_error.restype = C.c_char_p
     L.cliora_version.restype = C.c_char_p
+    L.cliora_set_mfma_mode.argtypes = [i32]
+    L.cliora_set_mfma_mode.restype = i32
     _lib = L
     return L
 
@@ -137,3 +139,13 @@ def prof_read(kclass, stream=0):
     ms, n = C.c_double(), C.c_longlong()
     check(lib().cliora_prof_read(KCLASS[kclass], C.byref(ms), C.byref(n), C.c_void_p(stream)), 'cliora_prof_read')
     return ms.value, n.value
+
+
+MFMA_MODES = {'f32': 0, 'bf16x3': 1}
+
+
+def set_mfma_mode(mode):
+    """Arithmetic of the compose-layer GEMMs and their weight gradient: 'bf16x3' (default; three bf16 MFMAs per
+    product, fp32 accumulate) or 'f32' (fp32-input MFMA, the reference's arithmetic).  Returns the previous mode."""
+    prev = lib().cliora_set_mfma_mode(MFMA_MODES[mode])
+    return 'f32' if prev == 0 else 'bf16x3'

@@ -153,6 +153,21 @@ static int pick_tiles(int ntiles16) {
     return 1;
 }
 
+static int image_stride(int K);
+// The per-cell projection GEMMs (leaf, PL/PR/QL and their backward) stay on the exact fp32-input MFMA by default: their
+// outputs feed the split scores, where the 2^-18 operand rounding of the split shows up as ~1e-4 absolute on scores of
+// magnitude ~15 (measured, tools/accuracy.py), and they are latency-bound, so the split buys little (~3 % of a step).
+// CLIORA_PROJ_MFMA=bf16x3 turns it on for experiments.
+static const float* proj_img(const float* ws, size_t off);
+static int g_split_proj = -1;
+static bool split_bf16_proj() {
+    if (g_split_proj < 0) {
+        const char* e = getenv("CLIORA_PROJ_MFMA");
+        g_split_proj = (e && !strcmp(e, "bf16x3")) ? 1 : 0;
+    }
+    return g_split_proj == 1;
+}
+static const float* proj_img(const float* ws, size_t off) { return split_bf16_proj() ? ws + off : nullptr; }
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
 static int g_split_bf16 = -1;
@@ -207,12 +222,22 @@ static int launch_rows_ct(hipStream_t st, const float* W, int Kseg, int nseg, in
 
 // small-row variant (per-level cell GEMMs): 32 x (CT*16) blocks, reduction split over the 4 waves, no weight staging
 template <class AP, class EP>
-static int launch_rows_direct(hipStream_t st, const float* W, int K, int ncols, int nrows, AP ap, EP ep) {
+static int launch_rows_direct(hipStream_t st, const float* W, const float* Wimg, int K, int ncols, int nrows, AP ap, EP ep) {
     if (nrows <= 0) return CLIORA_OK;
     const int nt = ncols / 16;
     const int nrg = ((nrows + 15) / 16 + 1) / 2;
     // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
     const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+    if (Wimg && split_bf16()) {      // split-bf16 arithmetic on the weight's image
+        const uint32_t* I = reinterpret_cast<const uint32_t*>(Wimg);
+        const int S = image_stride(K);
+        if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 5, nrows, ap, ep);
+        else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 4, nrows, ap, ep);
+        else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 2, AP, EP>), dim3(nrgp * (nt / 2)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 2, nrows, ap, ep);
+        else hipLaunchKernelGGL((rows_gemm_ksplit3<2, 1, AP, EP>), dim3(nrgp * nt), dim3(256), 0, st, I, S, K, nrg, nrgp, nt, nrows, ap, ep);
+        LAUNCHOK("rows_gemm_ksplit3");
+        return CLIORA_OK;
+    }
     if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 5, nrows, ap, ep);
     else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 4, nrows, ap, ep);
     else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 2, AP, EP>), dim3(nrgp * (nt / 2)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 2, nrows, ap, ep);
@@ -404,21 +429,31 @@ template <class AP, class EP>
 static int launch_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int nrows, AP ap, EP ep) {
     if (g_compose_ksplit_rows < 0) {
         const char* e = getenv("CLIORA_COMPOSE_KSPLIT_ROWS");
-        g_compose_ksplit_rows = e ? atoi(e) : 5000;   // measured crossover on MI355X (r01 sweep: 0..30000)
+        g_compose_ksplit_rows = e ? atoi(e) : 1500;   // measured crossover on MI355X (r01 sweeps: 5000 for the fp32 kernels, 1500 with the split-bf16 ones)
     }
-    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Dp, Dp, nrows, ap, ep);
+    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Wimg, Dp, Dp, nrows, ap, ep);
     if (split_bf16()) return launch_rows3(st, reinterpret_cast<const uint32_t*>(Wimg), S3, Dp, Dp, nrows, ap, ep);
     return launch_rows(st, W, Dp, 1, Dp, nrows, ap, ep);
 }
 
-// split-bf16 LDS images of up to four [Dp][Dp] weight matrices already in the workspace
-static int build_weight_images(hipStream_t st, int n, const float* const* src, float* const* dst, int Dp, int Kp, int S) {
+// split-bf16 images (see split_weight_image) of weight matrices already in the workspace
+struct ImageList {
     SplitImageTab tab{};
-    for (int k = 0; k < n; ++k) { tab.src[k] = src[k]; tab.dst[k] = reinterpret_cast<uint32_t*>(dst[k]); }
-    hipLaunchKernelGGL(split_weight_image, dim3((S + 255) / 256, Dp, n), dim3(256), 0, st, tab, Dp, Dp, Kp, S);
+    int n = 0, max_rows = 0, max_S = 0;
+    void add(const float* src, float* dst, int nrows, int ldw, int K) {
+        tab.src[n] = src; tab.dst[n] = reinterpret_cast<uint32_t*>(dst); tab.nrows[n] = nrows; tab.ldw[n] = ldw; tab.K[n] = K;
+        max_rows = std::max(max_rows, nrows);
+        max_S = std::max(max_S, (K + 31) / 32 * 32 + WS3_PAD);
+        ++n;
+    }
+};
+static int build_weight_images(hipStream_t st, const ImageList& l) {
+    if (l.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(split_weight_image, dim3((l.max_S + 255) / 256, l.max_rows, l.n), dim3(256), 0, st, l.tab);
     LAUNCHOK("split_weight_image");
     return CLIORA_OK;
 }
+static int image_stride(int K) { return (K + 31) / 32 * 32 + WS3_PAD; }
 
 static int run_copies(hipStream_t st, const CopyTable& tab) {
     if (tab.n == 0) return CLIORA_OK;
@@ -525,15 +560,21 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
         if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
         OKR(run_copies(st, t));
-        if (split_bf16()) {
-            const float* src[4] = {ws + f.w2i, ws + f.w2iT, ws + f.w2o, ws + f.w2oT};
-            float* dst[4] = {ws + f.w2i3, ws + f.w2iT3, ws + f.w2o3, ws + f.w2oT3};
-            OKR(build_weight_images(st, p.share ? 2 : 4, src, dst, Dp, f.Kp3, f.S3));
+        {   // built in either arithmetic mode (one small launch): the backward call may run under the other one
+            ImageList im;
+            im.add(ws + f.w2i, ws + f.w2i3, Dp, Dp, Dp); im.add(ws + f.w2iT, ws + f.w2iT3, Dp, Dp, Dp);
+            if (!p.share) { im.add(ws + f.w2o, ws + f.w2o3, Dp, Dp, Dp); im.add(ws + f.w2oT, ws + f.w2oT3, Dp, Dp, Dp); }
+            if (split_bf16_proj()) {
+                im.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); im.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
+                im.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); im.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+                im.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); im.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
+            }
+            OKR(build_weight_images(st, im));
         }
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
-    OKR(launch_rows_direct(st, ws + f.wl, Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    OKR(launch_rows_direct(st, ws + f.wl, proj_img(ws, f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
         hipLaunchKernelGGL(cell_attend_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, g0, L, (const float*)nullptr, (const float*)nullptr,
@@ -546,7 +587,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("unit_norm_rows");
     }
     if (L > 1)
-        OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
+        OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
     // ---- inside pass (diora.py:295-331) ----
@@ -573,7 +614,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             LAUNCHOK("cell_aggregate_fwd");
         }
         if (level < L - 1)
-            OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                             StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
 
@@ -583,7 +624,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            ws + f.nrmo, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows_direct(st, ws + f.w1ro, Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -600,7 +641,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                ws + f.nrmo);
             LAUNCHOK("cell_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1ro, Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
         }
     } else {
@@ -663,10 +704,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
             LAUNCHOK("cell_gather_bwd_out");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1roT, Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1roT, proj_img(ws, f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                                 StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
             if (level == L - 1) {
-                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(256), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
                 LAUNCHOK("root_bwd");
                 break;
             }
@@ -701,7 +742,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows_direct(st, ws + f.wcatT, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcatT, proj_img(ws, f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
             hipLaunchKernelGGL(cell_attend_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
@@ -722,7 +763,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
-        OKR(launch_rows_direct(st, ws + f.wlT, Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+        OKR(launch_rows_direct(st, ws + f.wlT, proj_img(ws, f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     {
         // shared weights: inside and outside pair rows are one contiguous range -> one launch
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);
@@ -832,14 +873,21 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         }
         add_copy(u, ws + f.wcatT + 10 * Dp, ldpi, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
         OKR(run_copies(st, u));
+        if (split_bf16() && split_bf16_proj()) {
+            ImageList im;
+            im.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); im.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
+            im.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); im.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+            im.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); im.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
+            OKR(build_weight_images(st, im));
+        }
     }
     // leaves
-    OKR(launch_rows_direct(st, ws + f.wl, Dp, 3 * Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, 3 * Dp, ws + f.bl, 0, 3 * Dp}));
+    OKR(launch_rows_direct(st, ws + f.wl, proj_img(ws, f.wl3), Dp, 3 * Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, 3 * Dp, ws + f.bl, 0, 3 * Dp}));
     hipLaunchKernelGGL(lstm_leaf_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, ws + f.t, p.normalize, IH, IC, ws + f.nrmi,
                        ws + f.nrmic, IS);
     LAUNCHOK("lstm_leaf_fwd");
     if (L > 1)
-        OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
+        OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -853,7 +901,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
                            ws + f.nrmi, ws + f.nrmic);
         LAUNCHOK("lstm_aggregate_fwd");
         if (level < L - 1)
-            OKR(launch_rows_direct(st, ws + f.wcat, Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                                    StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
     if (run_outside) {
@@ -861,7 +909,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootc, 0, B, 1, C, C - 1, Dp, p.normalize, OC, ws + f.nrmoc, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows_direct(st, ws + f.w1ro, Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -875,7 +923,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
                                ws + f.nrmo, ws + f.nrmoc);
             LAUNCHOK("lstm_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1ro, Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                        StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));
         }
     } else {
@@ -932,11 +980,11 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
                                dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VH, VC, dStot);
             LAUNCHOK("lstm_gather_bwd_out");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1roT, ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1roT, proj_img(ws, f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
                                        StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
             if (level == L - 1) {
-                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(256), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
-                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(256), 0, st, B, C, Dp, VC, OC, ws + f.nrmoc, p.normalize, wb + bw.grootc);
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VC, OC, ws + f.nrmoc, p.normalize, wb + bw.grootc);
                 LAUNCHOK("root_bwd");
                 break;
             }
@@ -961,7 +1009,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
                            dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
         LAUNCHOK("lstm_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows_direct(st, ws + f.wcatT, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcatT, proj_img(ws, f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                                    StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == 0) break;
         hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic, p.normalize, Y, Xc, Sp,
@@ -975,7 +1023,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
                        p.normalize, ws + f.t, dU);
     LAUNCHOK("lstm_leaf_bwd");
     if (d_x_span)
-        OKR(launch_rows_direct(st, ws + f.wlT, 3 * Dp, Dp, B * L, PlainRowsA{dU, 3 * Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+        OKR(launch_rows_direct(st, ws + f.wlT, proj_img(ws, f.wlT3), 3 * Dp, Dp, B * L, PlainRowsA{dU, 3 * Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
     OKR(launch_tn(st, B * L, 3 * Dp, Dp, Dp, PlainRowsA{dU, 3 * Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
     {
@@ -1215,4 +1263,10 @@ extern "C" int cliora_cky_decode(cliora_plan* plan, void* fwd_ws, int32_t* split
 }
 
 extern "C" const char* cliora_last_error(void) { return g_err.c_str(); }
+extern "C" int cliora_set_mfma_mode(int mode) {
+    const int prev = split_bf16() ? CLIORA_MFMA_SPLIT_BF16 : CLIORA_MFMA_F32;
+    g_split_bf16 = mode == CLIORA_MFMA_F32 ? 0 : 1;
+    return prev;
+}
+
 extern "C" const char* cliora_version(void) { return "cliora_amd 0.1 (gfx950)"; }

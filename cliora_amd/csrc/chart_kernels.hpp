@@ -447,31 +447,52 @@ __global__ __launch_bounds__(256) void leaf_bwd_pre(int B, int L, int C, int Dp,
 }
 
 // outside root: OH[root] = unit(root_vector) broadcast over the batch (diora.py:337-356);
-// d root_vector = sum_b normbwd(vH[b, root]).  One workgroup, fixed summation order.
-__global__ __launch_bounds__(256) void root_bwd(int B, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
-                                                const float* __restrict__ nrm, int normalize, float* __restrict__ groot) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    float acc0 = 0.f, acc1 = 0.f;          // columns tid and tid + 256
-    for (int b = 0; b < B; ++b) {
+// d root_vector = sum_b normbwd(vH[b, root]).  One workgroup of 16 waves: wave w takes sentences w, w+16, ... (a lane
+// owns columns lane, lane+64, ...; the row dot product is a wave reduction), the 16 partial vectors meet in LDS and are
+// added in wave order -- a fixed summation order, so the result is bitwise reproducible.
+constexpr int ROOT_WAVES = 16;
+__global__ __launch_bounds__(ROOT_WAVES * 64) void root_bwd(int B, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
+                                                            const float* __restrict__ nrm, int normalize, float* __restrict__ groot) {
+    __shared__ float part[ROOT_WAVES][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int b = wave; b < B; b += ROOT_WAVES) {
         const size_t crow = (size_t)b * C + C - 1;
-        const float v0 = tid < Dp ? VH[crow * Dp + tid] : 0.f, v1 = tid + 256 < Dp ? VH[crow * Dp + tid + 256] : 0.f;
-        const float h0 = tid < Dp ? H[crow * Dp + tid] : 0.f, h1 = tid + 256 < Dp ? H[crow * Dp + tid + 256] : 0.f;
-        if (!normalize) { acc0 += v0; acc1 += v1; continue; }
+        float v[8], h[8];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = lane + 64 * k;
+            v[k] = col < Dp ? VH[crow * Dp + col] : 0.f;
+            h[k] = col < Dp ? H[crow * Dp + col] : 0.f;
+            dot = fmaf(v[k], h[k], dot);
+        }
+        if (!normalize) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            continue;
+        }
         const float nr = nrm[crow];
         if (nr > UNIT_EPS) {
-            red[tid] = v0 * h0 + v1 * h1;
-            __syncthreads();
-            for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-            const float dot = red[0];
-            __syncthreads();
-            acc0 += (v0 - h0 * dot) / nr; acc1 += (v1 - h1 * dot) / nr;
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += (v[k] - h[k] * dot) / nr;
         } else {
-            acc0 += v0 / UNIT_EPS; acc1 += v1 / UNIT_EPS;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k] / UNIT_EPS;
         }
     }
-    if (tid < Dp) groot[tid] = acc0;
-    if (tid + 256 < Dp) groot[tid + 256] = acc1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[wave][lane + 64 * k] = acc[k];
+    __syncthreads();
+    for (int col = threadIdx.x; col < Dp; col += ROOT_WAVES * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROOT_WAVES; ++w) t += part[w][col];
+        groot[col] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
 // j = 0..7 in the lane's four operand registers; D as for the fp32 form.  Which k of the 32-deep step a slot holds is
 // free as long as both operands agree (the sum over k is unchanged): see split_weight_image.
 // ---------------------------------------------------------------------------------
+constexpr int WS3_PAD = 8;        // pad dwords per weight-image row: S = roundup32(K) + 8
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
@@ -255,11 +256,15 @@ __device__ __forceinline__ void split_bf16x8(const float4 a, const float4 b, u32
 // ds_read_b128's four 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... : eight rows of lane group g and the
 // other eight rows of g+1, MI355X_MICROARCH.md LDS table) the 16-byte bank quads (2*row + g) mod 16 are all different.
 // grid = (ceil(S/256), nrows, nmat); the matrices are [nrows][ldw] fp32 and are laid out one after the other.
-constexpr int WS3_PAD = 8;        // pad dwords per image row: S = Kp + 8
-struct SplitImageTab { const float* src[4]; uint32_t* dst[4]; };
-__global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab, int ldw, int K, int Kp, int S) {
-    const float* W = tab.src[blockIdx.z] + (size_t)blockIdx.y * ldw;
-    uint32_t* img = tab.dst[blockIdx.z] + (size_t)blockIdx.y * S;
+constexpr int MAX_IMAGES = 12;
+struct SplitImageTab { const float* src[MAX_IMAGES]; uint32_t* dst[MAX_IMAGES]; int nrows[MAX_IMAGES], ldw[MAX_IMAGES], K[MAX_IMAGES]; };
+// grid = (ceil(max S / 256), max nrows, nmat); image m: row stride S = roundup32(K[m]) + WS3_PAD dwords
+__global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
+    const int m = blockIdx.z;
+    const int K = tab.K[m], Kp = (K + 31) / 32 * 32, S = Kp + WS3_PAD;
+    if ((int)blockIdx.y >= tab.nrows[m]) return;
+    const float* W = tab.src[m] + (size_t)blockIdx.y * tab.ldw[m];
+    uint32_t* img = tab.dst[m] + (size_t)blockIdx.y * S;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= S) return;
     const int half = Kp >> 1;
@@ -510,6 +515,107 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
         const int r = t / CT, c = t - r * CT;
         const int row = (tile0 + r) * 16 + i;
         if (row < nrows) epi.store4(epi.row(row), col0 + c * 16 + 4 * q, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// rows_gemm_ksplit3: rows_gemm_ksplit in split-bf16 arithmetic.  The weight operand comes from the same image as
+// rows_gemm_ws3 (split_weight_image), read straight from global/L2: a lane's fragment of a k-step is 16 B of hi and
+// 16 B of lo.  The four waves split the 32-deep k-steps; two steps of operands are in flight per wave, every ring slot
+// reloads unconditionally (clamped to the wave's last step) so the waits stay counted.
+// ---------------------------------------------------------------------------------
+template <int RT, int CT, class AProd, class Epi>
+__global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restrict__ Wimg, int S, int K, int nrg, int nrgp, int ncolblocks,
+                                                         int nrows, AProd ap, Epi epi) {
+    __shared__ float4 part[4][RT * CT][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;   // row group fastest: see the launcher (XCD L2 reuse)
+    if (rg >= nrg) return;
+    const int col0 = cb * (CT * 16);
+    const int tile0 = rg * RT;
+    const int Kp = S - WS3_PAD, half = Kp >> 1;
+    const int nsteps = Kp >> 5;
+    const int sbase = nsteps / 4, srem = nsteps % 4;
+    const int s0 = wave * sbase + min(wave, srem);
+    const int ns = sbase + (wave < srem ? 1 : 0);
+    using Raw = typename AProd::Raw;
+    using Ctx = decltype(ap.row(0));
+    Ctx ctx[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((tile0 + r) * 16 + i, nrows - 1));
+    const uint32_t* wrow = Wimg + (size_t)(col0 + i) * S + 4 * g;
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int PD = 2;
+    Raw ra[PD][RT][2];
+    u32x4 wh[PD][CT], wl[PD][CT];
+    auto load = [&](int slot, int s) {             // s: absolute k-step
+        const int k = 32 * s + 4 * g;
+        const int k2 = k + (32 * s + 16 < K ? 16 : 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { ra[slot][r][0] = ap.fetch(ctx[r], k); ra[slot][r][1] = ap.fetch(ctx[r], k2); }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            wh[slot][c] = *reinterpret_cast<const u32x4*>(wrow + (size_t)c * 16 * S + 16 * s);
+            wl[slot][c] = *reinterpret_cast<const u32x4*>(wrow + (size_t)c * 16 * S + 16 * s + half);
+        }
+    };
+    if (ns > 0) {
+        const int slast = s0 + ns - 1;
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) load(sl, min(s0 + sl, slast));
+        for (int base = 0; base < ns; base += PD) {
+#pragma unroll
+            for (int sl = 0; sl < PD; ++sl) {
+                const int s = s0 + base + sl;
+                if (base + sl < ns) {
+                    const bool second = 32 * s + 16 < K;
+                    u32x4 xh[RT], xl[RT];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        const float4 a0 = ap.finish(ctx[r], ra[sl][r][0]), a1 = ap.finish(ctx[r], ra[sl][r][1]);
+                        if (AProd::kSide && s % ncolblocks == cb) {     // side output, shared out over the column blocks
+                            ap.side(ctx[r], 32 * s + 4 * g, a0);
+                            if (second) ap.side(ctx[r], 32 * s + 16 + 4 * g, a1);
+                        }
+                        split_bf16x8(a0, a1, xh[r], xl[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[r][c] = mfma32bf(wl[sl][c], xh[r], acc[r][c]);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[r][c] = mfma32bf(wh[sl][c], xl[r], acc[r][c]);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[r][c] = mfma32bf(wh[sl][c], xh[r], acc[r][c]);
+                }
+                load(sl, min(s + PD, slast));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            part[wave][r * CT + c][lane] = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
+    __syncthreads();
+    // wave w finishes output tiles w, w+4, ...: fixed summation order over the four k-slices
+    for (int t = wave; t < RT * CT; t += 4) {
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                     ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        const int r = t / CT, c = t - r * CT;
+        const int row = (tile0 + r) * 16 + i;
+        if (row < nrows) epi.store4(epi.row(row), col0 + c * 16 + 4 * g, v);
     }
 }
 

@@ -145,6 +145,10 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.w2i3 = take(Dp * f.S3); f.w2iT3 = take(Dp * f.S3);
         if (p.share) { f.w2o3 = f.w2i3; f.w2oT3 = f.w2iT3; }
         else { f.w2o3 = take(Dp * f.S3); f.w2oT3 = take(Dp * f.S3); }
+        auto img = [&](size_t rows, size_t K) { return take(rows * ((K + 31) / 32 * 32 + 8)); };
+        f.wl3 = img(nlf * Dp, Dp); f.wlT3 = img(Dp, nlf * Dp);
+        f.wcat3 = img(nb * Dp, Dp); f.wcatT3 = img(Dp, nb * Dp);
+        f.w1ro3 = img(npo * Dp, Dp); f.w1roT3 = img(Dp, npo * Dp);
         f.rootp = take(Dp);
         f.xp = take(padded ? BL * Dp : 0);
         f.ihp = take(padded ? BC * Dp : 0);

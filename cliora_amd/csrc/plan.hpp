@@ -35,7 +35,8 @@ struct FwdLayout {
     size_t w2i, b2i, w2iT;              // second compose layer, inside weights
     size_t w2o, b2o, w2oT;              // outside weights (alias of inside when shared)
     size_t w2i3, w2iT3, w2o3, w2oT3;    // split-bf16 LDS images of the four (Dp rows x S3 dwords each; see split_weight_image)
-    int Kp3, S3;                        // image geometry: k rounded up to 32, row stride in dwords
+    int Kp3, S3;                        // image geometry for K = Dp: k rounded up to 32, row stride in dwords
+    size_t wl3, wlT3, wcat3, wcatT3, w1ro3, w1roT3;   // images of the leaf / projection weights and their transposes
     size_t rootp;                       // root vector, padded
     size_t xp, ihp, ohp;                // padded copies (only when D != Dp; else unused)
     size_t objp;                        // padded obj (CLIORA, D != Dp)

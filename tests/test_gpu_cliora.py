@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, params_from_golden
+from conftest import grad_check, grad_tol, load_golden, params_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def _scale(b):
     return max(1.0, float(np.abs(np.asarray(b)).max()))
 
 
-def test_cliora_eval_outputs_and_trees():
+def test_cliora_eval_outputs_and_trees(mfma_mode):
     g = load_golden('cliora_small.npz')
     m = _module(g).eval()
     t = _inputs(g)
@@ -58,7 +58,7 @@ def _chart_mask(g):
     return torch.cat([torch.from_numpy(g['mask_%d' % i]) for i in range(n)], 1).cuda()   # (B, C, R): leaves, level 1, ...
 
 
-def test_cliora_train_with_recorded_dropout_and_grads():
+def test_cliora_train_with_recorded_dropout_and_grads(mfma_mode):
     from oracle import diora_ref as R
     g = load_golden('cliora_small.npz')
     m = _module(g).train()
@@ -82,11 +82,11 @@ def test_cliora_train_with_recorded_dropout_and_grads():
         name = k[6:].replace('__', '.')
         tt = t[name].grad if name in t else named[name].grad
         assert tt is not None, k
-        assert _err(tt, v) <= GRAD_TOL * _scale(v), '%s err %.3e scale %.3e' % (k, _err(tt, v), _scale(v))
+        grad_check(tt, v, mfma_mode, GRAD_TOL, k)
 
 
 @pytest.mark.parametrize('D,B,L,R,share', [(64, 3, 5, 36, True), (48, 2, 6, 10, False), (400, 2, 7, 36, True)])
-def test_cliora_against_oracle(D, B, L, R, share):
+def test_cliora_against_oracle(D, B, L, R, share, mfma_mode):
     """Other shapes (Dp == D and Dp != D, R not a multiple of 4... of 16, unshared weights) vs the CPU oracle."""
     from cliora_amd.cliora import DioraMLP
     from oracle import diora_ref as Rf
@@ -134,6 +134,6 @@ def test_cliora_against_oracle(D, B, L, R, share):
         assert _err(getattr(m, k), ref[k].detach().numpy()) <= OUT_TOL * _scale(ref[k].detach().numpy()), k
     named = dict(m.named_parameters())
     for k, p in P.items():
-        assert _err(named[k].grad, p.grad.numpy()) <= GRAD_TOL * _scale(p.grad.numpy()), k
+        grad_check(named[k].grad, p.grad, mfma_mode, GRAD_TOL, k)
     for k in tg:
-        assert _err(tg[k].grad, tc[k].grad.numpy()) <= GRAD_TOL * _scale(tc[k].grad.numpy()), k
+        grad_check(tg[k].grad, tc[k].grad, mfma_mode, GRAD_TOL, k)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import grad_check, grad_tol, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,7 @@ def _batch(g):
 
 
 @pytest.mark.parametrize('name,vl', [('net_diora.npz', False), ('net_cliora.npz', True)])
-def test_net_losses_grads_and_three_adam_steps(name, vl):
+def test_net_losses_grads_and_three_adam_steps(name, vl, mfma_mode):
     from cliora_amd import harness as H
     g = load_golden(name)
     net = _build(g, vl).eval()             # fixtures were captured with dropout off
@@ -40,8 +40,7 @@ def test_net_losses_grads_and_three_adam_steps(name, vl):
     for k, p in net.named_parameters():
         gk = 'grad__' + k.replace('.', '__')
         if gk in g and p.grad is not None:
-            err = float((p.grad.cpu() - torch.from_numpy(g[gk])).abs().max())
-            assert err <= 2e-4 * max(1.0, float(np.abs(g[gk]).max())), (k, err)
+            grad_check(p.grad, g[gk], mfma_mode, 2e-4, k)
     # Trainer._step x3 (dropout kept off as in the fixture)
     net.zero_grad()
     tr = H.Trainer(net, lr=g['meta']['lr'])

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from oracle import diora_ref as R, synth          # noqa: E402  (checker only)
 from test_gpu_parity import _module_from_params, _run_gpu, CHARTS   # noqa: E402
 
-D, B, L, seed = 400, int(os.environ.get('B', '2')), 20, int(os.environ.get('SEED', '1234'))
+D, B, L, seed = int(os.environ.get('D', '400')), int(os.environ.get('B', '2')), int(os.environ.get('L', '20')), int(os.environ.get('SEED', '1234'))
 P, x, cot = synth.diora_case(D, B, L, seed)
 m = _module_from_params(P, D, True, 'unit')
 outs, xg = _run_gpu(m, x, cot)
