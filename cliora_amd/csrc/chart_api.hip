@@ -158,7 +158,6 @@ static int image_stride(int K);
 // outputs feed the split scores, where the 2^-18 operand rounding of the split shows up as ~1e-4 absolute on scores of
 // magnitude ~15 (measured, tools/accuracy.py), and they are latency-bound, so the split buys little (~3 % of a step).
 // CLIORA_PROJ_MFMA=bf16x3 turns it on for experiments.
-static const float* proj_img(const float* ws, size_t off);
 static int g_split_proj = -1;
 static bool split_bf16_proj() {
     if (g_split_proj < 0) {
@@ -167,7 +166,8 @@ static bool split_bf16_proj() {
     }
     return g_split_proj == 1;
 }
-static const float* proj_img(const float* ws, size_t off) { return split_bf16_proj() ? ws + off : nullptr; }
+// image argument pair (pointer, kind) of a projection weight: its split-bf16 image or its fp32 fragment image
+#define PROJ_IMG(off) (ws + (off)), (split_bf16_proj() ? 1 /* IMG_SPLIT_BF16 */ : 2 /* IMG_FRAG_F32 */)
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
 static int g_split_bf16 = -1;
@@ -221,15 +221,47 @@ static int launch_rows_ct(hipStream_t st, const float* W, int Kseg, int nseg, in
 }
 
 // small-row variant (per-level cell GEMMs): 32 x (CT*16) blocks, reduction split over the 4 waves, no weight staging
+// One split-K launch: blocks of (RT*16 rows) x (CT*16 columns).  A block's MFMA work and operand bytes are fixed by
+// its tile, so a launch with few blocks leaves most CUs idle while the busy ones work through a long reduction: the
+// tile shrinks (2x5 -> 1x5 -> 1x1 sixteen-wide tiles) until the launch has enough blocks to cover the chip.
+template <int RT, int CT, bool FRAG, class AP, class EP>
+static int launch_ksplit_tile(hipStream_t st, const float* W, int K, int nt, int nrows, AP ap, EP ep) {
+    const int nrg = ((nrows + 15) / 16 + RT - 1) / RT;
+    // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+    hipLaunchKernelGGL((rows_gemm_ksplit<RT, CT, FRAG, AP, EP>), dim3(nrgp * (nt / CT)), dim3(256), 0, st, W, K, nrg, nrgp, nt / CT, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ksplit");
+    return CLIORA_OK;
+}
+static int g_ksplit_min_blocks = -1;
+template <int CT, bool FRAG, class AP, class EP>
+static int launch_ksplit_ct(hipStream_t st, const float* W, int K, int nt, int nrows, AP ap, EP ep) {
+    if (g_ksplit_min_blocks < 0) { const char* e = getenv("CLIORA_KSPLIT_MIN_BLOCKS"); g_ksplit_min_blocks = e ? atoi(e) : 1000; }   // MI355X sweep 0..2000: 5.61 ms/step at 0, 5.44 at 160, 5.37 at 1000
+    const int nrt = (nrows + 15) / 16;
+    if (((nrt + 1) / 2) * (nt / CT) >= g_ksplit_min_blocks) return launch_ksplit_tile<2, CT, FRAG>(st, W, K, nt, nrows, ap, ep);
+    if (CT == 1 || nrt * (nt / CT) >= g_ksplit_min_blocks) return launch_ksplit_tile<1, CT, FRAG>(st, W, K, nt, nrows, ap, ep);
+    return launch_ksplit_tile<1, 1, FRAG>(st, W, K, nt, nrows, ap, ep);
+}
+template <bool FRAG, class AP, class EP>
+static int launch_ksplit_f32(hipStream_t st, const float* W, int K, int nt, int nrows, AP ap, EP ep) {
+    if (nt % 5 == 0) return launch_ksplit_ct<5, FRAG>(st, W, K, nt, nrows, ap, ep);
+    if (nt % 4 == 0) return launch_ksplit_ct<4, FRAG>(st, W, K, nt, nrows, ap, ep);
+    if (nt % 2 == 0) return launch_ksplit_ct<2, FRAG>(st, W, K, nt, nrows, ap, ep);
+    return launch_ksplit_ct<1, FRAG>(st, W, K, nt, nrows, ap, ep);
+}
+
+// image kinds a split-K launch can take beside the plain weight
+enum { IMG_NONE = 0, IMG_SPLIT_BF16 = 1, IMG_FRAG_F32 = 2 };
+
 template <class AP, class EP>
-static int launch_rows_direct(hipStream_t st, const float* W, const float* Wimg, int K, int ncols, int nrows, AP ap, EP ep) {
+static int launch_rows_direct(hipStream_t st, const float* W, const float* img, int kind, int K, int ncols, int nrows, AP ap, EP ep) {
     if (nrows <= 0) return CLIORA_OK;
     const int nt = ncols / 16;
     const int nrg = ((nrows + 15) / 16 + 1) / 2;
     // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
     const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
-    if (Wimg && split_bf16()) {      // split-bf16 arithmetic on the weight's image
-        const uint32_t* I = reinterpret_cast<const uint32_t*>(Wimg);
+    if (kind == IMG_SPLIT_BF16) {      // split-bf16 arithmetic on the weight's image
+        const uint32_t* I = reinterpret_cast<const uint32_t*>(img);
         const int S = image_stride(K);
         if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 5, nrows, ap, ep);
         else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 4, nrows, ap, ep);
@@ -238,12 +270,8 @@ static int launch_rows_direct(hipStream_t st, const float* W, const float* Wimg,
         LAUNCHOK("rows_gemm_ksplit3");
         return CLIORA_OK;
     }
-    if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 5, nrows, ap, ep);
-    else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 4, nrows, ap, ep);
-    else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit<2, 2, AP, EP>), dim3(nrgp * (nt / 2)), dim3(256), 0, st, W, K, nrg, nrgp, nt / 2, nrows, ap, ep);
-    else hipLaunchKernelGGL((rows_gemm_ksplit<2, 1, AP, EP>), dim3(nrgp * nt), dim3(256), 0, st, W, K, nrg, nrgp, nt, nrows, ap, ep);
-    LAUNCHOK("rows_gemm_ksplit");
-    return CLIORA_OK;
+    if (kind == IMG_FRAG_F32) return launch_ksplit_f32<true>(st, img, K, nt, nrows, ap, ep);
+    return launch_ksplit_f32<false>(st, W, K, nt, nrows, ap, ep);
 }
 
 // out[r][j] = sum_k A(r,k) W[j][k] for j < ncols (multiple of 16); k runs over nseg segments of Kseg (multiple of 16)
@@ -431,7 +459,7 @@ static int launch_compose(hipStream_t st, const float* W, const float* Wimg, int
         const char* e = getenv("CLIORA_COMPOSE_KSPLIT_ROWS");
         g_compose_ksplit_rows = e ? atoi(e) : 1500;   // measured crossover on MI355X (r01 sweeps: 5000 for the fp32 kernels, 1500 with the split-bf16 ones)
     }
-    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Wimg, Dp, Dp, nrows, ap, ep);
+    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Wimg, split_bf16() ? IMG_SPLIT_BF16 : IMG_NONE, Dp, Dp, nrows, ap, ep);
     if (split_bf16()) return launch_rows3(st, reinterpret_cast<const uint32_t*>(Wimg), S3, Dp, Dp, nrows, ap, ep);
     return launch_rows(st, W, Dp, 1, Dp, nrows, ap, ep);
 }
@@ -454,6 +482,12 @@ static int build_weight_images(hipStream_t st, const ImageList& l) {
     return CLIORA_OK;
 }
 static int image_stride(int K) { return (K + 31) / 32 * 32 + WS3_PAD; }
+static int build_frag_images(hipStream_t st, const ImageList& l) {
+    if (l.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(frag_weight_image, dim3(256, 1, l.n), dim3(256), 0, st, l.tab);
+    LAUNCHOK("frag_weight_image");
+    return CLIORA_OK;
+}
 
 static int run_copies(hipStream_t st, const CopyTable& tab) {
     if (tab.n == 0) return CLIORA_OK;
@@ -564,17 +598,17 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             ImageList im;
             im.add(ws + f.w2i, ws + f.w2i3, Dp, Dp, Dp); im.add(ws + f.w2iT, ws + f.w2iT3, Dp, Dp, Dp);
             if (!p.share) { im.add(ws + f.w2o, ws + f.w2o3, Dp, Dp, Dp); im.add(ws + f.w2oT, ws + f.w2oT3, Dp, Dp, Dp); }
-            if (split_bf16_proj()) {
-                im.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); im.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
-                im.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); im.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
-                im.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); im.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
-            }
+            ImageList pj;
+            pj.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
+            pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+            pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
             OKR(build_weight_images(st, im));
+            OKR(split_bf16_proj() ? build_weight_images(st, pj) : build_frag_images(st, pj));
         }
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
-    OKR(launch_rows_direct(st, ws + f.wl, proj_img(ws, f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
         hipLaunchKernelGGL(cell_attend_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, g0, L, (const float*)nullptr, (const float*)nullptr,
@@ -587,7 +621,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("unit_norm_rows");
     }
     if (L > 1)
-        OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
+        OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
     // ---- inside pass (diora.py:295-331) ----
@@ -614,7 +648,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             LAUNCHOK("cell_aggregate_fwd");
         }
         if (level < L - 1)
-            OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                             StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
 
@@ -624,7 +658,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            ws + f.nrmo, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -641,7 +675,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                ws + f.nrmo);
             LAUNCHOK("cell_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
         }
     } else {
@@ -704,7 +738,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
             LAUNCHOK("cell_gather_bwd_out");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1roT, proj_img(ws, f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                                 StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
             if (level == L - 1) {
                 hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
@@ -742,7 +776,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows_direct(st, ws + f.wcatT, proj_img(ws, f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
             hipLaunchKernelGGL(cell_attend_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
@@ -763,7 +797,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
-        OKR(launch_rows_direct(st, ws + f.wlT, proj_img(ws, f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+        OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     {
         // shared weights: inside and outside pair rows are one contiguous range -> one launch
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);
@@ -873,21 +907,21 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         }
         add_copy(u, ws + f.wcatT + 10 * Dp, ldpi, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
         OKR(run_copies(st, u));
-        if (split_bf16() && split_bf16_proj()) {
-            ImageList im;
-            im.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); im.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
-            im.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); im.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
-            im.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); im.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
-            OKR(build_weight_images(st, im));
+        {
+            ImageList pj;
+            pj.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
+            pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+            pj.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
+            OKR(split_bf16_proj() ? build_weight_images(st, pj) : build_frag_images(st, pj));
         }
     }
     // leaves
-    OKR(launch_rows_direct(st, ws + f.wl, proj_img(ws, f.wl3), Dp, 3 * Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, 3 * Dp, ws + f.bl, 0, 3 * Dp}));
+    OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, 3 * Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, 3 * Dp, ws + f.bl, 0, 3 * Dp}));
     hipLaunchKernelGGL(lstm_leaf_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, ws + f.t, p.normalize, IH, IC, ws + f.nrmi,
                        ws + f.nrmic, IS);
     LAUNCHOK("lstm_leaf_fwd");
     if (L > 1)
-        OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
+        OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -901,7 +935,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
                            ws + f.nrmi, ws + f.nrmic);
         LAUNCHOK("lstm_aggregate_fwd");
         if (level < L - 1)
-            OKR(launch_rows_direct(st, ws + f.wcat, proj_img(ws, f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                                    StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
     if (run_outside) {
@@ -909,7 +943,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootc, 0, B, 1, C, C - 1, Dp, p.normalize, OC, ws + f.nrmoc, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
@@ -923,7 +957,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
                                ws + f.nrmo, ws + f.nrmoc);
             LAUNCHOK("lstm_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1ro, proj_img(ws, f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                        StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));
         }
     } else {
@@ -980,7 +1014,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
                                dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VH, VC, dStot);
             LAUNCHOK("lstm_gather_bwd_out");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1roT, proj_img(ws, f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
+                OKR(launch_rows_direct(st, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
                                        StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
             if (level == L - 1) {
                 hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
@@ -1009,7 +1043,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
                            dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
         LAUNCHOK("lstm_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows_direct(st, ws + f.wcatT, proj_img(ws, f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                                    StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == 0) break;
         hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic, p.normalize, Y, Xc, Sp,
@@ -1023,7 +1057,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
                        p.normalize, ws + f.t, dU);
     LAUNCHOK("lstm_leaf_bwd");
     if (d_x_span)
-        OKR(launch_rows_direct(st, ws + f.wlT, proj_img(ws, f.wlT3), 3 * Dp, Dp, B * L, PlainRowsA{dU, 3 * Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+        OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), 3 * Dp, Dp, B * L, PlainRowsA{dU, 3 * Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
     OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
     OKR(launch_tn(st, B * L, 3 * Dp, Dp, Dp, PlainRowsA{dU, 3 * Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
     {

@@ -280,6 +280,22 @@ __global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
     img[p] = p < half ? h : pack_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
 }
 
+// fp32 fragment image for rows_gemm_ksplit<.., FRAG = true>: float4 index ((ct * K/16 + ch) * 64 + lane) holds
+// W[ct*16 + (lane & 15)][ch*16 + 4*(lane >> 4) .. +3].  Same table as split_weight_image; grid = (ceil(max nrows*K/4 / 256), 1, nmat).
+__global__ __launch_bounds__(256) void frag_weight_image(SplitImageTab tab) {
+    const int m = blockIdx.z;
+    const int K = tab.K[m], nch = K >> 4;
+    const size_t n4 = (size_t)tab.nrows[m] * K / 4;
+    float4* img = reinterpret_cast<float4*>(tab.dst[m]);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+        const int lane = (int)(e & 63);
+        const size_t blk = e >> 6;
+        const int ch = (int)(blk % nch), ct = (int)(blk / nch);
+        const float* src = tab.src[m] + (size_t)(ct * 16 + (lane & 15)) * tab.ldw[m] + ch * 16 + 4 * (lane >> 4);
+        img[e] = *reinterpret_cast<const float4*>(src);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // rows_gemm_ws3: rows_gemm_ws (single weight segment) in split-bf16 arithmetic.
 //   Wimg   : split_weight_image() of the [ncols][K] weight; block blockIdx.y's CT*16 image rows are one
@@ -426,9 +442,12 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
 //   * the four waves split the reduction (k) range between them and each streams its A and W
 //     fragments straight from global/L2 with a one-chunk register prefetch;
 //   * partial accumulators meet in LDS and the epilogue is shared out over the waves.
-// W: [ncols][K] row-major (K = whole reduction length, a multiple of 16).
+// W: [ncols][K] row-major (K = whole reduction length, a multiple of 16); with FRAG, W is frag_weight_image() of
+// that matrix: the 64 lanes' 16-byte weight fragments of one (column tile, 16-deep k-chunk) are 1 KiB contiguous, so a
+// weight load is one fully used run of cache lines instead of sixteen 64-byte pieces 4*K bytes apart (the per-level
+// launches are bound by how fast ONE CU can pull its block's operands through its texture-address path).
 // ---------------------------------------------------------------------------------
-template <int RT, int CT, class AProd, class Epi>
+template <int RT, int CT, bool FRAG, class AProd, class Epi>
 __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int nrg, int nrgp, int ncolblocks, int nrows,
                                                         AProd ap, Epi epi) {
     __shared__ float4 part[4][RT * CT][64];
@@ -465,7 +484,9 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < RT; ++r) ra[slot][r] = ap.fetch(ctx[r], k + 4 * q);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) rw[slot][c] = *reinterpret_cast<const float4*>(wrow + (size_t)c * 16 * K + k);
+        for (int c = 0; c < CT; ++c)
+            rw[slot][c] = FRAG ? reinterpret_cast<const float4*>(W)[((size_t)(cb * CT + c) * nchunks + ch0 + ch) * 64 + lane]
+                               : *reinterpret_cast<const float4*>(wrow + (size_t)c * 16 * K + k);
     };
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl)
