@@ -628,9 +628,11 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
-                           IH, IS, IS, ws + f.sp, ws + f.pp, IS);
-        LAUNCHOK("pair_scores_fwd");
+        if (vl) {
+            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
+                               IH, IS, IS, ws + f.sp, ws + f.pp, IS);
+            LAUNCHOK("pair_scores_fwd");
+        }
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
             OKR(launch_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, nrows,
@@ -643,9 +645,9 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
         } else {
-            hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, IH,
-                               ws + f.nrmi);
-            LAUNCHOK("cell_aggregate_fwd");
+            hipLaunchKernelGGL(cell_scores_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
+                               IH, IS, IS, ws + f.sp, ws + f.pp, IS, ws + f.y, p.normalize, IH, ws + f.nrmi);
+            LAUNCHOK("cell_scores_aggregate_fwd");
         }
         if (level < L - 1)
             OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
@@ -662,18 +664,16 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
-            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow,
-                               ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS, ws + f.sp, ws + f.pp, OS);
-            LAUNCHOK("pair_scores_fwd(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
                 OKR(launch_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, nrows,
                                 ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.x, Dp},
                                 StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
             }
-            hipLaunchKernelGGL(cell_aggregate_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, ws + f.y, ws + f.pp, p.normalize, OH,
+            hipLaunchKernelGGL(cell_scores_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow,
+                               ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS, ws + f.sp, ws + f.pp, OS, ws + f.y, p.normalize, OH,
                                ws + f.nrmo);
-            LAUNCHOK("cell_aggregate_fwd(out)");
+            LAUNCHOK("cell_scores_aggregate_fwd(out)");
             if (level >= 1)
                 OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));

@@ -178,6 +178,99 @@ __global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const flo
 }
 
 // ---------------------------------------------------------------------------------
+// pair_scores_fwd + cell_aggregate_fwd in one launch (text-only path): one workgroup per target cell.
+//   phase 1  wave w scores the splits n = w, w+4, ...                       (bilinear score, diora.py:25-52)
+//   phase 2  every wave takes the softmax over the N scores                 (diora.py:137-143)
+//   phase 3  wave w sums p_n y_n over its splits, the four partial vectors meet in LDS and are added in wave
+//            order (fixed summation order), then the unit norm              (diora.py:145-149)
+// The wave's first y rows are fetched before phase 1: they do not depend on the scores.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_scores_aggregate_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+                                                                 const float* __restrict__ QA, int ldA, const float* __restrict__ HB,
+                                                                 const float* SA, const float* SB,
+                                                                 float* __restrict__ Sp, float* __restrict__ Pp, float* Sout,
+                                                                 const float* __restrict__ Y, int normalize, float* __restrict__ H,
+                                                                 float* __restrict__ nrm) {
+    __shared__ float sh_s[64];
+    __shared__ float4 sh_v[4][128];
+    __shared__ float sh_r[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int row0 = g.rowbase + t * g.N;
+    const int nv = g.Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    float4 y0[4], y1[4];
+    auto load_y = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = min(n0 + 4 * j, g.N - 1);
+            const float* y = Y + (size_t)(row0 + n) * g.Dp;
+            y0[j] = a0 ? ld4(y + 4 * lane) : f4zero();
+            y1[j] = a1 ? ld4(y + 4 * (lane + 64)) : f4zero();
+        }
+    };
+    load_y(wave);
+    for (int n0 = wave; n0 < g.N; n0 += 16) {
+        int ar[4], br[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = min(n0 + 4 * j, g.N - 1);
+            ar[j] = arow[row0 + n];
+            br[j] = brow[row0 + n];
+        }
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* qa = QA + (size_t)ar[j] * ldA;
+            const float* hb = HB + (size_t)br[j] * g.Dp;
+            float v = 0.f;
+            if (a0) v = f4dot(ld4(qa + 4 * lane), ld4(hb + 4 * lane));
+            if (a1) v += f4dot(ld4(qa + 4 * (lane + 64)), ld4(hb + 4 * (lane + 64)));
+            d[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = wave_sum(d[j]) + SA[ar[j]] + SB[br[j]];
+            if (lane == 0 && n0 + 4 * j < g.N) sh_s[n0 + 4 * j] = s;
+        }
+    }
+    __syncthreads();
+    const float my_s = lane < g.N ? sh_s[lane] : -INFINITY;
+    const float m = wave_max(my_s);
+    const float e = lane < g.N ? expf(my_s - m) : 0.f;
+    const float pn = e / wave_sum(e);
+    if (wave == 0) {
+        if (lane < g.N) { Sp[row0 + lane] = my_s; Pp[row0 + lane] = pn; }
+        const float st = wave_sum(lane < g.N ? pn * my_s : 0.f);
+        if (lane == 0) Sout[(size_t)b * g.C + g.off + p] = st;
+    }
+    float4 v0 = f4zero(), v1 = f4zero();
+    for (int n0 = wave; n0 < g.N; n0 += 16) {
+        if (n0 != wave) load_y(n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 4 * j;
+            const float w = __shfl(pn, min(n, 63));
+            if (n < g.N) { v0 = f4fma(w, y0[j], v0); v1 = f4fma(w, y1[j], v1); }
+        }
+    }
+    if (a0) sh_v[wave][lane] = v0;
+    if (a1) sh_v[wave][lane + 64] = v1;
+    __syncthreads();
+    float4 sum = f4zero();
+    if (tid < nv) sum = f4add(f4add(f4add(sh_v[0][tid], sh_v[1][tid]), sh_v[2][tid]), sh_v[3][tid]);
+    const float ss = wave_sum(f4dot(sum, sum));
+    if (lane == 0) sh_r[wave] = ss;
+    __syncthreads();
+    const float nr = sqrtf((sh_r[0] + sh_r[1]) + (sh_r[2] + sh_r[3]));
+    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    if (tid < nv) st4(H + crow * g.Dp + 4 * tid, make_float4(sum.x / den, sum.y / den, sum.z / den, sum.w / den));
+    if (tid == 0) nrm[crow] = nr;
+}
+
+// ---------------------------------------------------------------------------------
 // Backward, step 1 for the cells of one level: gather every use of the cell.
 //   inside cell c (as left child a / right child b in the inside pass, as sibling in the outside pass):
 //     dPL  = sum_{a-uses} DA[row]            dPR = sum_{b-uses} DA[row]
