@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA; the split-bf16 compose GEMMs issue three of them per fp32 product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -79,6 +80,8 @@ def main():
     ap.add_argument('--length', type=int, default=20)
     ap.add_argument('--dim', type=int, default=400)
     ap.add_argument('--batch', type=int, default=64, help='sentences per GPU')
+    ap.add_argument('--mfma', choices=['bf16x3', 'f32'], default=None,
+                    help='arithmetic of the compose GEMMs (default: the library default, split-bf16; see include/cliora_chart.h)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the gradient all-reduce even at world size 1 (self-test of the N>1 path)')
@@ -87,6 +90,10 @@ def main():
     import torch
     import torch.distributed as dist
     from cliora_amd import _lib
+    if args.mfma:
+        _lib.set_mfma_mode(args.mfma)
+    mfma_mode = _lib.set_mfma_mode('bf16x3')      # read the mode in force (set returns the previous one) ...
+    _lib.set_mfma_mode(mfma_mode)                 # ... and put it back
     from cliora_amd.diora import DioraMLP
     from cliora_amd.parallel import FlatGradAllReduce
 
@@ -133,10 +140,6 @@ def main():
         step()
     kclasses = ('compose_fwd', 'compose_bwd', 'wgrad')
     events = (rank == 0) and not args.no_kernel_events
-    if events:
-        for k in kclasses:
-            _lib.prof_read(k)
-            _lib.prof_enable(k, True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -147,6 +150,22 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # Second pass of the same K steps with a HIP event pair around every launch of the three GEMM classes (on the
+    # launch stream), for the roofline object.  It is separate from the timed region above because the ~230 event
+    # records per step serialise neighbouring launches and cost ~8 % of a step (4.8 -> 5.3 ms on MI355X); every rank
+    # runs the steps so the all-reduces stay matched, only rank 0 records events.
+    dt_ev = None
+    if not args.no_kernel_events:
+        if events:
+            for k in kclasses:
+                _lib.prof_read(k)
+                _lib.prof_enable(k, True)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_ev = time.perf_counter() - t1
 
     out = None
     if rank == 0:
@@ -170,9 +189,14 @@ def main():
             tp = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get(dom)
-            roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+            # achieved = fp32-equivalent algorithmic FLOP/s; a split-bf16 product costs three bf16 MFMAs, so its MFMA
+            # roof is the dense bf16 peak / 3; the exact mode is priced against the fp32-input MFMA peak
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if mfma_mode == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
+            roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
+                        frac=round(ach / peak, 4), frac_of_f32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         avg_launch_ms=round(avg_ms, 5), launches_per_step=kern[dom]['launches'] / args.steps,
+                        measured='second pass of the same %d steps with per-launch HIP events' % args.steps,
+                        ms_per_step_with_events=round(dt_ev / args.steps * 1e3, 4),
                         classes={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 4),
                                          tflops=round(flops_class * args.steps / (v['total_ms'] * 1e-3) / 1e12, 2))
                                  for k, v in kern.items()})
@@ -180,11 +204,13 @@ def main():
             'metric': 'sentences/sec (inside+outside fwd+bwd), len-%d d=%d bsz=%d' % (L, D, B),
             'value': round(world * B * args.steps / dt, 2), 'unit': 'sentences/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (compose GEMMs: 3x bf16 MFMA per product, fp32 accumulate)' if mfma_mode == 'bf16x3' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': 'DioraMLP d=%d, batch %d per GPU, synthetic len %d, emb=none, text-only inside-outside '
                                    '(BASELINE configs[1]); chart forward + hand-written backward; random N(0,1) weights'
                                    % (D, B, L),
-                       'global_batch': world * B, 'length': L, 'dim': D,
+                       'global_batch': world * B, 'length': L, 'dim': D, 'mfma': mfma_mode,
                        'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU'},
             'roofline': roof,
         }
