@@ -908,6 +908,11 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
 #pragma unroll
         for (int b = 0; b < NJT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cs0 = 0.f, cs1 = 0.f;
+    // Column sums of A (the bias gradient): when some column block has a spare j-tile slot (its njt < NJT; at d = 400 the
+    // blocks hold 9, 8, 8 of the 25 tiles) that slot's B fragment is set to ones and the MFMAs the slot costs anyway
+    // deliver sum_r A[r][i] in its accumulator; otherwise block 0 adds the stage's rows up from LDS.
+    const int kb_ones = jrem > 0 && jbase < NJT ? jrem : (jbase < NJT ? 0 : -1);    // first block with njt == jbase < NJT
+    const bool ones_here = COLSUM && kb == kb_ones;
 
     const int npieces = (UA + UX) >> 6;
     int p_rr[TN3_NP], p_off[TN3_NP];
@@ -977,6 +982,10 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
         u32x4 bh[NJT], bl[NJT];
 #pragma unroll
         for (int u = 0; u < NJT; ++u) { bh[u] = bconv[(2 * u) * 64 + lane]; bl[u] = bconv[(2 * u + 1) * 64 + lane]; }
+        if (ones_here) {                 // bf16 1.0 = 0x3F80 in all eight k of the spare fragment
+            bh[NJT - 1] = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+            bl[NJT - 1] = u32x4{0u, 0u, 0u, 0u};
+        }
         // three-deep pipeline over the wave's row tiles: LDS reads of tile t+2, split of tile t+1 and the 3*NJT MFMAs of
         // tile t are issued interleaved (sched_group_barrier), so neither the LDS latency nor the split is exposed
         float raw[2][8];
@@ -1013,7 +1022,7 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             }
         }
-        if (COLSUM && kb == 0) {                 // column sums of A (bias gradient), branch-free
+        if (COLSUM && kb_ones < 0 && kb == 0) {  // column sums of A (bias gradient), branch-free
             const int c0 = min(tid, Mi - 1), c1 = min(tid + 256, Mi - 1);
 #pragma unroll 8
             for (int rr = 0; rr < TN3_RS; ++rr) {
@@ -1035,9 +1044,16 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
                         for (int reg = 0; reg < 4; ++reg)
                             out[(size_t)((it0 + t) * 16 + g * 4 + reg) * Nj + (jt0 + u) * 16 + i] = acc[t][u][reg];
     }
-    if (COLSUM && kb == 0) {
+    if (COLSUM && kb_ones < 0 && kb == 0) {
         if (tid < Mi) colsum[(size_t)slice * Mi + tid] = cs0;
         if (tid + 256 < Mi) colsum[(size_t)slice * Mi + tid + 256] = cs1;
+    }
+    if (ones_here && has_tiles && i == 0) {      // every column of the ones tile holds the same sums: lane column 0 writes
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+            if (t < nit)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) colsum[(size_t)slice * Mi + (it0 + t) * 16 + g * 4 + reg] = acc[t][NJT - 1][reg];
     }
 }
 

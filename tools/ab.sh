@@ -1,3 +1,3 @@
 #!/bin/bash
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_cliora.py -x -q 2>&1 | tail -2
+python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['classes']['wgrad'])"
