@@ -56,9 +56,13 @@ if __name__ == '__main__':
     mode = _lib.set_mfma_mode('bf16x3')
     _lib.set_mfma_mode(mode)
     print(json.dumps(dict(mfma=mode)))
-    run('c1 DioraMLP', lambda: DioraMLP(50), 8, 10, 50)
-    run('c2 DioraMLP', lambda: DioraMLP(400), 64, 20, 400)
-    run('c3 CLIORA', lambda: CDioraMLP(400), 64, 20, 400, R=36)
-    run('DioraMLP len 40', lambda: DioraMLP(400), 64, 40, 400, steps=8, warmup=2)
-    run('c5 DioraTreeLSTM len 20', lambda: DioraTreeLSTM(400), 64, 20, 400)
-    run('c5 DioraTreeLSTM len 40', lambda: DioraTreeLSTM(400), 64, 40, 400, steps=8, warmup=2)
+    only = sys.argv[1] if len(sys.argv) > 1 else ''
+    cases = [('c1 DioraMLP', lambda: DioraMLP(50), 8, 10, 50, 0, 20, 5),
+             ('c2 DioraMLP', lambda: DioraMLP(400), 64, 20, 400, 0, 20, 5),
+             ('c3 CLIORA', lambda: CDioraMLP(400), 64, 20, 400, 36, 20, 5),
+             ('DioraMLP len 40', lambda: DioraMLP(400), 64, 40, 400, 0, 8, 2),
+             ('c5 DioraTreeLSTM len 20', lambda: DioraTreeLSTM(400), 64, 20, 400, 0, 20, 5),
+             ('c5 DioraTreeLSTM len 40', lambda: DioraTreeLSTM(400), 64, 40, 400, 0, 8, 2)]
+    for name, make, B, L, D, R, steps, warmup in cases:
+        if only in name:
+            run(name, make, B, L, D, R=R, steps=steps, warmup=warmup)
