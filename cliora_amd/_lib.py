@@ -36,6 +36,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ChartLibError('HIP extension %s is missing: run `python -m cliora_amd.build` '
                             '(there is no CPU fallback for the chart path)' % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one already loaded when our library is dlopen'ed, otherwise the
+    # process ends up with two runtimes and ours sees no device ("no ROCm-capable device is detected" at the first hipMalloc)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     L.cliora_plan_create.argtypes = [i32] * 6 + [C.POINTER(vp)]
