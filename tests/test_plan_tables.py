@@ -86,3 +86,39 @@ def test_workspace_sizes_scale():
     a, b = _lib.Plan(8, 10, 50), _lib.Plan(64, 20, 400)
     assert 0 < a.fwd_bytes < b.fwd_bytes and 0 < a.bwd_bytes < b.bwd_bytes
     assert b.fwd_bytes < 2 << 30 and b.bwd_bytes < 2 << 30
+
+
+def test_entry_points_reject_null_and_mismatched_arguments():
+    """Error behaviour of the C ABI without a GPU: argument checks come before any HIP call, return a negative
+    CLIORA_E* code (never throw / crash) and leave a message in cliora_last_error()."""
+    import ctypes as C
+    L = _lib.lib()
+    p = _lib.Plan(2, 5, 16)
+    one = C.c_void_p(16)                     # a non-null dummy pointer: never dereferenced before the checks fail
+    prm = _lib.Params()
+    # forward: missing plan / params / inputs / outputs / workspace
+    L.cliora_chart_forward.restype = C.c_int
+    rc = L.cliora_chart_forward(None, C.byref(prm), one, None, None, one, one, one, one, None, one, C.c_size_t(1 << 20), 1, None)
+    assert rc < 0 and L.cliora_last_error()
+    rc = L.cliora_chart_forward(p.handle, C.byref(prm), None, None, None, one, one, one, one, None, one, C.c_size_t(1 << 20), 1, None)
+    assert rc < 0
+    # a text-only plan (R = 0) must not be given region features
+    rc = L.cliora_chart_forward(p.handle, C.byref(prm), one, one, None, one, one, one, one, None, one, C.c_size_t(p.fwd_bytes), 1, None)
+    assert rc < 0 and b'obj_span' in L.cliora_last_error()
+    # a workspace smaller than cliora_plan_fwd_workspace_bytes()
+    rc = L.cliora_chart_forward(p.handle, C.byref(prm), one, None, None, one, one, one, one, None, one, C.c_size_t(16), 1, None)
+    assert rc < 0 and b'workspace' in L.cliora_last_error().lower()
+    # a TreeLSTM plan on the MLP entry point and the other way round
+    q = _lib.Plan(2, 5, 16, arch=1)
+    rc = L.cliora_chart_forward(q.handle, C.byref(prm), one, None, None, one, one, one, one, None, one, C.c_size_t(q.fwd_bytes), 1, None)
+    assert rc < 0 and b'TreeLSTM' in L.cliora_last_error()
+    # unknown table name
+    n = C.c_size_t()
+    ptr = C.POINTER(C.c_int32)()
+    assert L.cliora_plan_table(p.handle, b'no_such_table', C.byref(ptr), C.byref(n)) < 0
+
+
+def test_mfma_mode_switch_round_trips():
+    prev = _lib.set_mfma_mode('f32')
+    assert _lib.set_mfma_mode('bf16x3') == 'f32'
+    assert _lib.set_mfma_mode(prev) == 'bf16x3'
