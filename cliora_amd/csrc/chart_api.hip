@@ -1010,7 +1010,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         for (int level = 0; level <= L - 1; ++level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
-            hipLaunchKernelGGL(lstm_gather_bwd_out, dim3(ncell), dim3(256), 0, st, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os,
+            hipLaunchKernelGGL(lstm_gather_bwd_out, dim3(ncell, (7 * Dp / 4 + 255) / 256), dim3(256), 0, st, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os,
                                dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VH, VC, dStot);
             LAUNCHOK("lstm_gather_bwd_out");
             if (level >= 1)
@@ -1039,7 +1039,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     for (int level = L - 1; level >= 0; --level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(lstm_gather_bwd_in, dim3(ncell), dim3(256), 0, st, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA],
+        hipLaunchKernelGGL(lstm_gather_bwd_in, dim3(ncell, (13 * Dp / 4 + 255) / 256), dim3(256), 0, st, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA],
                            dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
         LAUNCHOK("lstm_gather_bwd_in");
         if (level <= L - 2)

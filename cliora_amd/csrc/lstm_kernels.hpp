@@ -137,16 +137,16 @@ __global__ __launch_bounds__(256) void lstm_aggregate_fwd(LevelArgs g, const flo
 __device__ __forceinline__ float4 sum_rows(const UseTab& ut, int c, int b, const float* __restrict__ SRC, int ld, int col) {
     float4 acc = f4zero();
     const int beg = ut.off[c], end = ut.off[c + 1];
-    for (int u0 = beg; u0 < end; u0 += 4) {
-        float4 v[4];
+    for (int u0 = beg; u0 < end; u0 += 8) {            // eight rows in flight; accumulation stays in use order
+        float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const int uu = min(u0 + j, end - 1);
             const size_t r = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
             v[j] = ld4(SRC + r * ld + col);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (u0 + j < end) acc = f4add(acc, v[j]);
+        for (int j = 0; j < 8; ++j) if (u0 + j < end) acc = f4add(acc, v[j]);
     }
     return acc;
 }
@@ -154,18 +154,18 @@ __device__ __forceinline__ float4 sum_scaled(const UseTab& ut, int c, int b, int
                                              int ld, int col) {
     float4 acc = f4zero();
     const int beg = ut.off[c], end = ut.off[c + 1];
-    for (int u0 = beg; u0 < end; u0 += 4) {
-        float4 v[4];
-        float ds[4];
+    for (int u0 = beg; u0 < end; u0 += 8) {
+        float4 v[8];
+        float ds[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const int uu = min(u0 + j, end - 1);
             const size_t r = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
             ds[j] = (u0 + j < end) ? DS[r] : 0.f;
             v[j] = ld4(SRC + (size_t)(bC + ut.partner[uu]) * ld + col);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = f4fma(ds[j], v[j], acc);
+        for (int j = 0; j < 8; ++j) acc = f4fma(ds[j], v[j], acc);
     }
     return acc;
 }
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void lstm_gather_bwd_in(LevelArgs g, int D, co
     const int Dp = g.Dp, bC = b * g.C;
     const int n5 = (5 * Dp) >> 2, n1 = Dp >> 2;
     float* o = dPI + crow * ldpi;
-    for (int v = tid; v < 2 * n5 + 3 * n1; v += 256) {
+    // grid.y deals the 13*Dp/4 output float4 columns out in chunks of 256: a thread walks the use lists once
+    for (int v = blockIdx.y * 256 + tid; v < 2 * n5 + 3 * n1; v += 256 * gridDim.y) {
         if (v < n5) {                                  // dPL
             float4 a = sum_rows(ina, c, b, DA, 5 * Dp, 4 * v);
             if (with_outside) a = f4add(a, sum_rows(outa, c, b, DA, 5 * Dp, 4 * v));
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void lstm_gather_bwd_in(LevelArgs g, int D, co
             st4(VC + crow * Dp + col, a);
         }
     }
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.y == 0) {
         float vs = dS_ext ? dS_ext[crow] : 0.f;
         vs += sum_ds(inb, c, b, DS) + sum_ds(ina, c, b, DS);
         if (with_outside) vs += sum_ds(outa, c, b, DS);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void lstm_gather_bwd_out(LevelArgs g, int D, c
     const size_t crow = (size_t)b * g.C + c;
     const int Dp = g.Dp, bC = b * g.C;
     const int n5 = (5 * Dp) >> 2, n1 = Dp >> 2;
-    for (int v = tid; v < n5 + 2 * n1; v += 256) {
+    for (int v = blockIdx.y * 256 + tid; v < n5 + 2 * n1; v += 256 * gridDim.y) {
         if (v < n5) {
             st4(dPO + crow * 5 * Dp + 4 * v, sum_rows(outb, c, b, DA, 5 * Dp, 4 * v));
         } else if (v < n5 + n1) {
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void lstm_gather_bwd_out(LevelArgs g, int D, c
             st4(VC + crow * Dp + col, f4add(a, sum_rows(outb, c, b, DCB, Dp, col)));
         }
     }
-    if (tid == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + sum_ds(outb, c, b, DS);
+    if (tid == 0 && blockIdx.y == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + sum_ds(outb, c, b, DS);
 }
 
 // ---- backward, unit-norm of both vectors + softmax/score backward (one workgroup per cell)
