@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import grad_check, grad_tol, load_golden, params_from_golden
+from conftest import grad_check, load_golden, params_from_golden
 
 pytestmark = pytest.mark.gpu
 

@@ -3,13 +3,14 @@ captured from the reference and against the CPU oracle on the same seeded inputs
 
 Tolerance: outputs within 1e-4 absolute in fp32 (BASELINE.json north_star) in BOTH arithmetic modes of the
 compose GEMMs; gradients within 2e-4 of the tensor's largest reference magnitude with exact fp32 products
-(mode 'f32') and within 2e-3 in the default split-bf16 mode (conftest.grad_tol).  The parity tests run under both.
+(mode 'f32'), and the statistical check of conftest.grad_check in the default split-bf16 mode (median 1e-3, 99 % of
+the elements 2e-2, every element 1e-1 of scale).  The parity tests run under both.
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import grad_check, grad_tol, load_golden, params_from_golden
+from conftest import grad_check, load_golden, params_from_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -43,7 +44,7 @@ def _scale(b):
     return max(1.0, float(np.abs(b).max())) if b.size else 1.0
 
 
-def _grad_ok(t, ref, what='', tol=GRAD_TOL):
+def _grad_ok(t, ref, what='', mode='f32'):
     """Kink-tolerant gradient check for the d=400 / L=20 shapes.
 
     With ~6 M ReLU pre-activations per step, about one of them sits within fp32 rounding of
@@ -53,12 +54,14 @@ def _grad_ok(t, ref, what='', tol=GRAD_TOL):
     scale, median element error ~1e-6).  So: 99% of the elements within GRAD_TOL, every
     element within 100x that.
     """
+    if mode != 'f32':
+        return grad_check(t, ref, mode, GRAD_TOL, what)     # split-bf16: the statistical check of conftest.grad_check
     a = t.detach().double().cpu().flatten()
     b = ref.detach().double().cpu().flatten()
     d = (a - b).abs()
     scale = max(1.0, float(b.abs().max()))
     q = float(torch.quantile(d[:: max(1, d.numel() // 200000)], 0.99))
-    assert q <= tol * scale, '%s: q99 err %.3e scale %.3e' % (what, q, scale)
+    assert q <= GRAD_TOL * scale, '%s: q99 err %.3e scale %.3e' % (what, q, scale)
     assert float(d.max()) <= 100 * GRAD_TOL * scale, '%s: max err %.3e scale %.3e' % (what, float(d.max()), scale)
 
 
@@ -142,8 +145,8 @@ def test_c2_shape_against_oracle_and_golden(mfma_mode):
     assert _err(outs['inside_s'], g['inside_s']) <= OUT_TOL * _scale(g['inside_s'])
     named = dict(m.named_parameters())
     for k, p in P.items():
-        _grad_ok(named[k].grad, p.grad, k, grad_tol(mfma_mode, GRAD_TOL))
-    _grad_ok(xg.grad, xc.grad, 'x_span', grad_tol(mfma_mode, GRAD_TOL))
+        _grad_ok(named[k].grad, p.grad, k, mfma_mode)
+    _grad_ok(xg.grad, xc.grad, 'x_span', mfma_mode)
     m.eval()
     with torch.no_grad():
         m(x.cuda(), x.cuda())
@@ -241,3 +244,27 @@ def test_length_40_chart():
     with torch.no_grad():
         m(x.cuda(), x.cuda())
     assert str(m.cky()[0]) == str(R.cky_trees(ref['pair_s_in'], 1, L)[0])
+
+
+@pytest.mark.parametrize('D', [48, 64, 96, 400])
+def test_weight_stationary_kernels_other_widths(D, mfma_mode):
+    """Levels above 1 500 pair rows run the weight-stationary compose kernels; d = 400 has its own unrolled instance,
+    every other width the run-time-K one with 1, 2 or 4 column tiles per block (Dp = 48 / 96 / 64).  B = 32, L = 14
+    (5 824 rows at the widest level) against the CPU oracle, forward and backward, both arithmetic modes."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    B, L = (32, 14) if D < 400 else (8, 20)
+    P, x, cot = synth.diora_case(D, B, L, 17)
+    m = _module_from_params(P, D, True, 'unit')
+    outs, xg = _run_gpu(m, x, cot)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, training=True)
+    sum((ref[k] * cot[k]).sum() for k in CHARTS).backward()
+    for k in CHARTS:
+        assert _err(outs[k], ref[k]) <= OUT_TOL * _scale(ref[k]), k
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        _grad_ok(named[k].grad, p.grad, k, mfma_mode)
+    _grad_ok(xg.grad, xc.grad, 'x_span', mfma_mode)
