@@ -183,8 +183,9 @@ int cliora_prof_read(int kernel_class, double* total_ms, long long* launches, vo
 const char* cliora_last_error(void);
 /* Arithmetic of the compose-layer GEMMs (y = W2 x, dx = W2^T dz) and of the pair weight gradient dW2 = dz^T x:
  *   CLIORA_MFMA_SPLIT_BF16 (default): every fp32 operand is carried as two bf16 (hi + lo) and a product is three
- *     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (operand rounding 2^-18; outputs stay within 1e-4 of the reference,
- *     gradients within ~1e-3 of their scale in the worst element, ~1e-5 in the median);
+ *     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (operand rounding 2^-18; outputs stay within 1e-4 of the reference --
+ *     2e-5 measured; gradient elements ~1e-5 of their tensor's scale in the median, single elements up to a few 1e-2 where
+ *     a ReLU pre-activation within ~1e-5 of zero changes sign: DESIGN.md section 5);
  *   CLIORA_MFMA_F32: the fp32-input MFMA (products exact in fp32) -- the reference's arithmetic (cliora/net/diora.py:65-68
  *     nn.Linear in fp32), ~1.25x slower per step.
  * Everything else on the path (cell projections, scores, softmax, norms) is fp32 in both modes.
