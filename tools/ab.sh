@@ -1,3 +1,3 @@
 #!/bin/bash
-for m in f32 bf16x3; do D=48 B=32 L=14 SEED=17 CLIORA_MFMA=$m python tools/accuracy.py 2>/dev/null | tail -1; done
-for m in bf16x3; do D=64 B=32 L=14 SEED=17 CLIORA_MFMA=$m python tools/accuracy.py 2>/dev/null | tail -1; done
+python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -2
+for k in 1 2; do python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['classes'])"; done
