@@ -10,6 +10,9 @@ What is captured (inputs + expected outputs only -- no reference source):
   cliora_*.npz       cliora.DioraMLP (eval + train with recorded dropout masks), score tensors [net/cliora.py]
   net_*.npz          Net.forward losses + parameter grads, Trainer._step Adam updates [net/trainer.py]
   trees in diora_*/cliora_* files from analysis/cky.py + analysis/utils.py hooks
+  sampler_batches.npz   FixedLengthBatchSampler batches, BatchIterator.partition  [data/dataloader.py, batch_iterator.py]
+  interchange.npz + ref_model_*.pt   checkpoints written/loaded by Trainer.save_model/load_model, span lists, F1,
+                        parse.jsonl trees  [net/trainer.py, analysis/utils.py, scripts/parse.py helpers]
 """
 import os
 import sys
@@ -319,20 +322,6 @@ def treelstm_case(name, D, B, L, seed):
     save(name, **arrs)
 
 
-if __name__ == '__main__':
-    index_tables()
-    diora_case('diora_c1.npz', D=50, B=8, L=10, seed=1234)                       # BASELINE config 1
-    diora_case('diora_noshare.npz', D=24, B=3, L=7, seed=7, share=False)
-    diora_case('diora_nonorm.npz', D=16, B=2, L=5, seed=9, normalize='none')
-    diora_case('diora_len2.npz', D=20, B=2, L=2, seed=11)
-    diora_case('diora_c2_small.npz', D=400, B=2, L=20, seed=1234, full=False)    # config 2 shape, B=2
-    cliora_case('cliora_small.npz', D=50, B=4, L=8, seed=21)                     # config 3 shape, small
-    net_case('net_diora.npz', D=40, B=4, L=6, V=97, K=10, seed=31, vl=False)
-    net_case('net_cliora.npz', D=40, B=4, L=6, V=97, K=10, seed=33, vl=True)
-    treelstm_case('treelstm_recon.npz', D=24, B=3, L=7, seed=41)
-    sampler_case('sampler_batches.npz')
-
-
 def sampler_case(name):
     """Bucketed batching (cliora/data/dataloader.py:11-113) and rank partition (batch_iterator.py:53-66)
     on a synthetic corpus.  h5py is absent here; the module only needs it at import time."""
@@ -374,3 +363,107 @@ def sampler_case(name):
             arrs['part_l_%d_%d' % (world, rank)] = np.array(bi.partition(lst, rank, range(world)), dtype=np.int32)
     arrs['meta'] = np.array(json.dumps(dict(META, cases=[{k: (v if not isinstance(v, dict) else {str(a): b for a, b in v.items()}) for k, v in c.items()} for c in cases])))
     save(name, **arrs)
+
+
+def _parse_helpers():
+    """The tree helpers of cliora/scripts/parse.py:20-98, executed from its text: the module itself needs torchvision
+    and the training CLI at import time."""
+    import ast
+    src = open('/root/reference/cliora/scripts/parse.py').read()
+    mod = ast.parse(src)
+    keep = [n for n in mod.body if (isinstance(n, ast.FunctionDef) and n.name in ('remove_using_flat_mask', 'flatten_tree', 'postprocess', 'replace_leaves'))
+            or (isinstance(n, ast.Assign) and getattr(n.targets[0], 'id', '') == 'punctuation_words')]
+    ns = {}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), 'parse.py', 'exec'), ns)
+    return ns
+
+
+def interchange_case(name):
+    """Checkpoint files written / read by the reference's Trainer, span lists, F1 numbers and parse.jsonl trees."""
+    import copy
+    import collections
+    from cliora.analysis.utils import get_stats
+    torch.manual_seed(5)
+    D, V, K = 24, 41, 6
+
+    def make_net(seed, vl):
+        emb = torch.nn.Embedding(V, 16)
+        embed = ref_trainer.Embed(emb, input_size=16, size=D)
+        enc = ImageEncoder(input_size=20, size=D)
+        Diora = ref_cliora.DioraMLP if vl else ref_diora.DioraMLP
+        d = Diora(D, outside=True, normalize='unit', compress=False, share=True)
+        losses = [ref_trainer.ReconstructionSoftmaxLoss(emb, margin=1, k_neg=K, input_size=16, size=D)]
+        net = ref_trainer.Net(embed, enc, d, obj_feats=vl, visualize=False, loss_funcs=losses)
+        seeded_params(net, seed)
+        return net
+
+    arrs = {}
+    src = make_net(61, False)
+    tr = ref_trainer.Trainer(src, k_neg=K, ngpus=1, cuda=False)
+    tr.save_model(False, os.path.join(HERE, 'ref_model_noemb.pt'))
+    tr.save_model(True, os.path.join(HERE, 'ref_model_emb.pt'))
+    # what a DistributedDataParallel-wrapped net saves: every key behind 'module.', plus a key no net has
+    sd = collections.OrderedDict(('module.' + k, v) for k, v in src.state_dict().items())
+    sd['module.not_a_parameter'] = torch.zeros(3)
+    torch.save({'state_dict': sd}, os.path.join(HERE, 'ref_model_ddp.pt'))
+    arrs.update(state_np(src, 'src__'))
+    for tag, fname, origin_emb in (('noemb', 'ref_model_noemb.pt', False), ('emb', 'ref_model_emb.pt', True), ('ddp', 'ref_model_ddp.pt', True)):
+        dst = make_net(67, False)
+        if tag == 'noemb':
+            arrs.update(state_np(dst, 'dst0__'))
+        ref_trainer.Trainer.load_model(origin_emb, dst, os.path.join(HERE, fname))
+        arrs.update(state_np(dst, 'loaded_%s__' % tag))
+    # trees: random binary bracketings, spans / F1 / post-processing by the reference's own helpers
+    ph = _parse_helpers()
+    rs = np.random.RandomState(3)
+
+    def rand_tree(lo, hi):
+        if hi - lo == 1:
+            return lo
+        k = rs.randint(lo + 1, hi)
+        return (rand_tree(lo, k), rand_tree(k, hi))
+
+    words = ['a', 'b', 'the', 'dog', ',', 'runs', '.', 'fast', '?', 'x1', '-LRB-', 'y', '!', 'z']
+    cases, corpus, sent_f1 = [], [0., 0., 0.], []
+    for n in (2, 3, 5, 8, 11, 14):
+        for _rep in range(3):
+            t, gold_t = rand_tree(0, n), rand_tree(0, n)
+            toks = [words[int(i)] for i in rs.randint(0, len(words), size=n)]
+            if _rep == 1:
+                toks[-1] = '.'
+            spans = get_spans(get_actions(str(t)))
+            gold = set(get_spans(get_actions(str(gold_t)))[:-1]) if _rep != 2 else set()
+            pred = set(spans[:-1])
+            tp, fp, fn = get_stats(pred, gold)
+            corpus[0] += tp; corpus[1] += fp; corpus[2] += fn
+            overlap = pred.intersection(gold)
+            prec = float(len(overlap)) / (len(pred) + 1e-8)
+            reca = float(len(overlap)) / (len(gold) + 1e-8)
+            if len(gold) == 0:
+                reca = 1.
+                if len(pred) == 0:
+                    prec = 1.
+            sent_f1.append(2 * prec * reca / (prec + reca + 1e-8))
+            leaves = ph['replace_leaves'](copy.deepcopy(t), toks)
+            cases.append(dict(tree=t, tokens=toks, spans=spans, gold=sorted(gold), replaced=leaves,
+                              post=ph['postprocess'](copy.deepcopy(leaves), toks), flat=ph['flatten_tree'](t)))
+    tp, fp, fn = corpus
+    prec, rec = tp / (tp + fp), tp / (tp + fn)
+    arrs['meta'] = np.array(json.dumps(dict(META, D=D, V=V, K=K, cases=cases, corpus_f1=2 * prec * rec / (prec + rec),
+                                            sent_f1=float(np.mean(np.array(sent_f1))))))
+    save(name, **arrs)
+
+
+if __name__ == '__main__':
+    index_tables()
+    diora_case('diora_c1.npz', D=50, B=8, L=10, seed=1234)                       # BASELINE config 1
+    diora_case('diora_noshare.npz', D=24, B=3, L=7, seed=7, share=False)
+    diora_case('diora_nonorm.npz', D=16, B=2, L=5, seed=9, normalize='none')
+    diora_case('diora_len2.npz', D=20, B=2, L=2, seed=11)
+    diora_case('diora_c2_small.npz', D=400, B=2, L=20, seed=1234, full=False)    # config 2 shape, B=2
+    cliora_case('cliora_small.npz', D=50, B=4, L=8, seed=21)                     # config 3 shape, small
+    net_case('net_diora.npz', D=40, B=4, L=6, V=97, K=10, seed=31, vl=False)
+    net_case('net_cliora.npz', D=40, B=4, L=6, V=97, K=10, seed=33, vl=True)
+    treelstm_case('treelstm_recon.npz', D=24, B=3, L=7, seed=41)
+    sampler_case('sampler_batches.npz')
+    interchange_case('interchange.npz')
