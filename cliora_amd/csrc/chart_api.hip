@@ -611,7 +611,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
-        hipLaunchKernelGGL(cell_attend_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, g0, L, (const float*)nullptr, (const float*)nullptr,
+        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, (const float*)nullptr, (const float*)nullptr,
                            ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                            inside_c, D, IS);
         LAUNCHOK("cell_attend_fwd(leaves)");
@@ -640,7 +640,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
         if (vl) {   // cliora.py:140-157: aggregate, attention residual, second unit norm
-            hipLaunchKernelGGL(cell_attend_fwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, L, ws + f.y, ws + f.pp, (const float*)nullptr,
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L, ws + f.y, ws + f.pp, (const float*)nullptr,
                                OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                                (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
@@ -779,7 +779,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
-            hipLaunchKernelGGL(cell_attend_bwd, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
+            hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
                                drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
             LAUNCHOK("cell_attend_bwd");
         }

@@ -31,29 +31,40 @@ __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const
                                                        float* __restrict__ H, float* __restrict__ nrmV, float* __restrict__ U,
                                                        float* __restrict__ nrmU, float* __restrict__ PK, float* __restrict__ IC,
                                                        int icD, float* __restrict__ S) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
+    // one workgroup (4 waves) per cell: the splits of the aggregate and the regions of the attention are dealt over the
+    // waves (4 rows in flight each), partial vectors meet in LDS and are added in wave order (fixed summation order)
+    __shared__ float4 sh_v[4][128];
+    __shared__ float sh_sc[VL_MAXR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const int Dp = g.Dp, nv = Dp >> 2;
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
     const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    auto sum_waves = [&](float4& x0, float4& x1) {          // every wave leaves with the sum of the four partial vectors
+        __syncthreads();                                    // (the previous round's readers are done)
+        if (a0) sh_v[wave][lane] = x0;
+        if (a1) sh_v[wave][lane + 64] = x1;
+        __syncthreads();
+        if (a0) x0 = f4add(f4add(f4add(sh_v[0][lane], sh_v[1][lane]), sh_v[2][lane]), sh_v[3][lane]);
+        if (a1) x1 = f4add(f4add(f4add(sh_v[0][lane + 64], sh_v[1][lane + 64]), sh_v[2][lane + 64]), sh_v[3][lane + 64]);
+    };
     float4 v0 = f4zero(), v1 = f4zero();
     if (g.N == 0) {
         const float* s = T + ((size_t)b * L + p) * Dp;
         if (a0) v0 = ld4(s + c0);
         if (a1) v1 = ld4(s + c1);
-        if (lane == 0) S[crow] = 0.f;
+        if (tid == 0) S[crow] = 0.f;
     } else {
         const int row0 = g.rowbase + t * g.N;
-        for (int n0 = 0; n0 < g.N; n0 += 4) {
+        for (int n0 = wave; n0 < g.N; n0 += 16) {
             float pn[4];
             float4 y0[4], y1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = min(n0 + j, g.N - 1);
-                pn[j] = (n0 + j < g.N) ? Pp[row0 + n] : 0.f;
+                const int n = min(n0 + 4 * j, g.N - 1);
+                pn[j] = (n0 + 4 * j < g.N) ? Pp[row0 + n] : 0.f;
                 const float* y = Y + (size_t)(row0 + n) * Dp;
                 y0[j] = a0 ? ld4(y + c0) : f4zero();
                 y1[j] = a1 ? ld4(y + c1) : f4zero();
@@ -61,20 +72,20 @@ __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v0 = f4fma(pn[j], y0[j], v0); v1 = f4fma(pn[j], y1[j], v1); }
         }
+        sum_waves(v0, v1);
     }
-    // u = unit(v)
+    // u = unit(v)   (every wave holds the whole row)
     const float nu = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
     const float du = normalize ? fmaxf(nu, UNIT_EPS) : 1.f;
     const float4 u0 = make_float4(v0.x / du, v0.y / du, v0.z / du, v0.w / du);
     const float4 u1 = make_float4(v1.x / du, v1.y / du, v1.z / du, v1.w / du);
-    // scores over the regions of this sentence
+    // scores over the regions of this sentence: wave w takes regions w, w+4, ...
     const float* ob = OBJ + (size_t)b * R * Dp;
-    float my_sc = -INFINITY;
-    for (int k0 = 0; k0 < R; k0 += 4) {
+    for (int k0 = wave; k0 < R; k0 += 16) {
         float d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* o = ob + (size_t)min(k0 + j, R - 1) * Dp;
+            const float* o = ob + (size_t)min(k0 + 4 * j, R - 1) * Dp;
             float s = 0.f;
             if (a0) s = f4dot(u0, ld4(o + c0));
             if (a1) s += f4dot(u1, ld4(o + c1));
@@ -83,24 +94,26 @@ __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = wave_sum(d[j]);
-            if (lane == k0 + j) my_sc = s;
+            if (lane == 0 && k0 + 4 * j < R) sh_sc[k0 + 4 * j] = s;
         }
     }
+    __syncthreads();
+    const float my_sc = lane < R ? sh_sc[lane] : -INFINITY;
     const float mx = wave_max(my_sc);
     const float e = lane < R ? expf(my_sc - mx) : 0.f;
     const float pk = e / wave_sum(e);
     const float pm = (mask && lane < R) ? pk * mask[crow * R + lane] : pk;   // pre-scaled dropout mask (0 or 1/(1-p))
-    if (lane < R) PK[crow * VL_MAXR + lane] = pk;
-    // context = sum_k pm_k o_k
+    if (wave == 0 && lane < R) PK[crow * VL_MAXR + lane] = pk;
+    // context = sum_k pm_k o_k, the wave's regions first
     float4 x0 = f4zero(), x1 = f4zero();
-    for (int k0 = 0; k0 < R; k0 += 4) {
+    for (int k0 = wave; k0 < R; k0 += 16) {
         float w[4];
         float4 o0[4], o1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = min(k0 + j, R - 1);
+            const int k = min(k0 + 4 * j, R - 1);
             const float pj = __shfl(pm, k);
-            w[j] = (k0 + j < R) ? pj : 0.f;
+            w[j] = (k0 + 4 * j < R) ? pj : 0.f;
             const float* o = ob + (size_t)k * Dp;
             o0[j] = a0 ? ld4(o + c0) : f4zero();
             o1[j] = a1 ? ld4(o + c1) : f4zero();
@@ -108,6 +121,8 @@ __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x0 = f4fma(w[j], o0[j], x0); x1 = f4fma(w[j], o1[j], x1); }
     }
+    sum_waves(x0, x1);
+    if (wave != 0) return;
     // h = unit(u + ctx)
     const float4 w0 = f4add(u0, x0), w1 = f4add(u1, x1);
     const float nw = sqrtf(wave_sum(f4dot(w0, w0) + f4dot(w1, w1)));
@@ -140,9 +155,11 @@ __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __res
                                                        const float* __restrict__ nrmV, int normalize, const float* __restrict__ OBJ,
                                                        int R, const float* __restrict__ mask, const float* __restrict__ PK,
                                                        float* __restrict__ DCTX, float* __restrict__ PMo, float* __restrict__ DSC) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
+    // one workgroup (4 waves) per cell, the regions dealt over the waves as in cell_attend_fwd
+    __shared__ float4 sh_v[4][128];
+    __shared__ float sh_d[VL_MAXR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const int Dp = g.Dp, nv = Dp >> 2;
@@ -151,14 +168,13 @@ __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __res
     float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
     if (a0) { v0 = ld4(VH + crow * Dp + c0); h0 = ld4(H + crow * Dp + c0); }
     if (a1) { v1 = ld4(VH + crow * Dp + c1); h1 = ld4(H + crow * Dp + c1); }
-    unit_norm_bwd(v0, v1, h0, h1, nrmV[crow], normalize);        // v = dL/d(u + ctx)
+    unit_norm_bwd(v0, v1, h0, h1, nrmV[crow], normalize);        // v = dL/d(u + ctx), the same in every wave
     const float* ob = OBJ + (size_t)b * R * Dp;
-    float dpm = 0.f;
-    for (int k0 = 0; k0 < R; k0 += 4) {
+    for (int k0 = wave; k0 < R; k0 += 16) {
         float d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* o = ob + (size_t)min(k0 + j, R - 1) * Dp;
+            const float* o = ob + (size_t)min(k0 + 4 * j, R - 1) * Dp;
             float s = 0.f;
             if (a0) s = f4dot(v0, ld4(o + c0));
             if (a1) s += f4dot(v1, ld4(o + c1));
@@ -167,25 +183,27 @@ __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = wave_sum(d[j]);
-            if (lane == k0 + j) dpm = s;
+            if (lane == 0 && k0 + 4 * j < R) sh_d[k0 + 4 * j] = s;
         }
     }
+    __syncthreads();
     const bool ak = lane < R;
+    const float dpm = ak ? sh_d[lane] : 0.f;
     const float pk = ak ? PK[crow * VL_MAXR + lane] : 0.f;
     const float mk = (mask && ak) ? mask[crow * R + lane] : 1.f;
     const float dp = ak ? dpm * mk : 0.f;
     const float mean = wave_sum(pk * dp);
     const float dsc = pk * (dp - mean);
-    if (ak) { PMo[crow * VL_MAXR + lane] = pk * mk; DSC[crow * VL_MAXR + lane] = dsc; }
-    float4 u0 = v0, u1 = v1;
-    for (int k0 = 0; k0 < R; k0 += 4) {
+    if (wave == 0 && ak) { PMo[crow * VL_MAXR + lane] = pk * mk; DSC[crow * VL_MAXR + lane] = dsc; }
+    float4 u0 = wave == 0 ? v0 : f4zero(), u1 = wave == 0 ? v1 : f4zero();
+    for (int k0 = wave; k0 < R; k0 += 16) {
         float w[4];
         float4 o0[4], o1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = min(k0 + j, R - 1);
+            const int k = min(k0 + 4 * j, R - 1);
             const float dj = __shfl(dsc, k);
-            w[j] = (k0 + j < R) ? dj : 0.f;
+            w[j] = (k0 + 4 * j < R) ? dj : 0.f;
             const float* o = ob + (size_t)k * Dp;
             o0[j] = a0 ? ld4(o + c0) : f4zero();
             o1[j] = a1 ? ld4(o + c1) : f4zero();
@@ -193,8 +211,12 @@ __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) { u0 = f4fma(w[j], o0[j], u0); u1 = f4fma(w[j], o1[j], u1); }
     }
-    if (a0) { st4(DCTX + crow * Dp + c0, v0); st4(VH + crow * Dp + c0, u0); }
-    if (a1) { st4(DCTX + crow * Dp + c1, v1); st4(VH + crow * Dp + c1, u1); }
+    if (a0) sh_v[wave][lane] = u0;
+    if (a1) sh_v[wave][lane + 64] = u1;
+    __syncthreads();
+    if (wave != 0) return;
+    if (a0) { st4(DCTX + crow * Dp + c0, v0); st4(VH + crow * Dp + c0, f4add(f4add(f4add(sh_v[0][lane], sh_v[1][lane]), sh_v[2][lane]), sh_v[3][lane])); }
+    if (a1) { st4(DCTX + crow * Dp + c1, v1); st4(VH + crow * Dp + c1, f4add(f4add(f4add(sh_v[0][lane + 64], sh_v[1][lane + 64]), sh_v[2][lane + 64]), sh_v[3][lane + 64])); }
 }
 
 // d obj[b][k][:] = sum over the inside cells of sentence b of  pm[cell][k] * dctx[cell][:] + dsc[cell][k] * u[cell][:]
