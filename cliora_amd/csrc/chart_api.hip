@@ -611,7 +611,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
-        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, (const float*)nullptr, (const float*)nullptr,
+        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, PairScoreArgs{}, (const float*)nullptr, (const float*)nullptr,
                            ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                            inside_c, D, IS);
         LAUNCHOK("cell_attend_fwd(leaves)");
@@ -628,11 +628,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        if (vl) {
-            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
-                               IH, IS, IS, ws + f.sp, ws + f.pp, IS);
-            LAUNCHOK("pair_scores_fwd");
-        }
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
             OKR(launch_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, nrows,
@@ -640,7 +635,10 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                             StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
         }
         if (vl) {   // cliora.py:140-157: aggregate, attention residual, second unit norm
-            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L, ws + f.y, ws + f.pp, (const float*)nullptr,
+            // split scores + softmax + aggregate + attention in one launch
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L,
+                               PairScoreArgs{dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS, ws + f.sp, ws + f.pp, IS},
+                               ws + f.y, ws + f.pp, (const float*)nullptr,
                                OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                                (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");

@@ -25,7 +25,15 @@ constexpr int VL_MAXR = 64;     // regions per image (one per lane in the softma
 // source = tanh output T).  Writes H = unit(u + ctx), U = u, P = prob (before dropout), the two
 // norms, and for the leaves inside_c = unit(ctx).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const float* __restrict__ Y, const float* __restrict__ Pp,
+// split-score inputs / outputs when the scoring of pair_scores_fwd is done inside cell_attend_fwd (arow == nullptr: not fused)
+struct PairScoreArgs {
+    const int32_t *arow, *brow;
+    const float* QA; int ldA;
+    const float *HB, *SA, *SB;
+    float *Sp, *Pp, *Sout;
+};
+
+__global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, PairScoreArgs sc, const float* __restrict__ Y, const float* __restrict__ Pp,
                                                        const float* __restrict__ T, const float* __restrict__ OBJ, int R,
                                                        const float* __restrict__ mask, int normalize,
                                                        float* __restrict__ H, float* __restrict__ nrmV, float* __restrict__ U,
@@ -58,13 +66,52 @@ __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const
         if (tid == 0) S[crow] = 0.f;
     } else {
         const int row0 = g.rowbase + t * g.N;
+        const bool fused = sc.arow != nullptr;        // uniform
+        float pn_lane = 0.f;                          // softmax weight of split `lane` (fused scoring)
+        if (fused) {                                  // bilinear split scores + softmax, as pair_scores_fwd
+            for (int n0 = wave; n0 < g.N; n0 += 16) {
+                int ar[4], br[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = min(n0 + 4 * j, g.N - 1);
+                    ar[j] = sc.arow[row0 + n];
+                    br[j] = sc.brow[row0 + n];
+                }
+                float d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* qa = sc.QA + (size_t)ar[j] * sc.ldA;
+                    const float* hb = sc.HB + (size_t)br[j] * Dp;
+                    float v = 0.f;
+                    if (a0) v = f4dot(ld4(qa + c0), ld4(hb + c0));
+                    if (a1) v += f4dot(ld4(qa + c1), ld4(hb + c1));
+                    d[j] = v;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s = wave_sum(d[j]) + sc.SA[ar[j]] + sc.SB[br[j]];
+                    if (lane == 0 && n0 + 4 * j < g.N) sh_sc[n0 + 4 * j] = s;
+                }
+            }
+            __syncthreads();
+            const float my_s = lane < g.N ? sh_sc[lane] : -INFINITY;
+            const float m = wave_max(my_s);
+            const float e = lane < g.N ? expf(my_s - m) : 0.f;
+            pn_lane = e / wave_sum(e);
+            if (wave == 0) {
+                if (lane < g.N) { sc.Sp[row0 + lane] = my_s; sc.Pp[row0 + lane] = pn_lane; }
+                const float st = wave_sum(lane < g.N ? pn_lane * my_s : 0.f);
+                if (lane == 0) sc.Sout[crow] = st;
+            }
+        }
         for (int n0 = wave; n0 < g.N; n0 += 16) {
             float pn[4];
             float4 y0[4], y1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = min(n0 + 4 * j, g.N - 1);
-                pn[j] = (n0 + 4 * j < g.N) ? Pp[row0 + n] : 0.f;
+                const float pf = __shfl(pn_lane, min(n, 63));
+                pn[j] = (n0 + 4 * j < g.N) ? (fused ? pf : Pp[row0 + n]) : 0.f;
                 const float* y = Y + (size_t)(row0 + n) * Dp;
                 y0[j] = a0 ? ld4(y + c0) : f4zero();
                 y1[j] = a1 ? ld4(y + c1) : f4zero();
