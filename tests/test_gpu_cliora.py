@@ -85,7 +85,7 @@ def test_cliora_train_with_recorded_dropout_and_grads(mfma_mode):
         grad_check(tt, v, mfma_mode, GRAD_TOL, k)
 
 
-@pytest.mark.parametrize('D,B,L,R,share', [(64, 3, 5, 36, True), (48, 2, 6, 10, False), (400, 2, 7, 36, True)])
+@pytest.mark.parametrize('D,B,L,R,share', [(64, 3, 5, 36, True), (48, 2, 6, 10, False), (400, 2, 7, 36, True), (32, 2, 5, 64, True), (32, 2, 4, 1, True)])
 def test_cliora_against_oracle(D, B, L, R, share, mfma_mode):
     """Other shapes (Dp == D and Dp != D, R not a multiple of 4... of 16, unshared weights) vs the CPU oracle."""
     from cliora_amd.cliora import DioraMLP
