@@ -182,23 +182,48 @@ def main():
         roof = None
         if kern and all(v['launches'] for v in kern.values()):
             dom = max(kern, key=lambda k: kern[k]['total_ms'])
-            per_launch_flops = flops_class * args.steps / kern[dom]['launches']
+            nlaunch = kern[dom]['launches'] / args.steps
             avg_ms = kern[dom]['total_ms'] / kern[dom]['launches']
-            ach = per_launch_flops / (avg_ms * 1e-3) / 1e12
+            # t_roof = max(algorithmic bytes / HBM bandwidth, executed FLOPs / MFMA peak of the dtype
+            # used); the larger term names the bound.  Per step and class (one D x D layer per pair row, factored compose):
+            #   FLOPs  2 Dp^2 per pair row
+            #   bytes  fwd: x and y rows written + the operand cells read (each touched cell row once per level, at most 2
+            #          per pair row);  bwd: y, x read and DA, DZ written per pair row + one dG row per target cell;
+            #          weight gradient: x and dz rows read once
+            row_b = 4.0 * Dp
+            lv_in = [((L - l) * l * B, (L - l) * B) for l in range(1, L)]                 # (pair rows, target cells) per level
+            lv_out = [((L - l) * (L - 1 - l) * B, (L - l) * B) for l in range(0, L - 1)]
+            levels = lv_in + lv_out
+            bytes_class = {
+                'compose_fwd': sum(2 * r * row_b + min(2 * r, 2 * B * C) * row_b for r, _ in levels),
+                'compose_bwd': sum(4 * r * row_b + c * row_b for r, c in levels),
+                'wgrad': 2.0 * pairs * B * row_b,
+            }
+            peak_mfma = PEAK_BF16_MFMA_TFLOPS / 3.0 if mfma_mode == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS   # 3 bf16 MFMAs per product
+            t_meas = kern[dom]['total_ms'] / args.steps * 1e-3                  # seconds per step in this class
+            t_mfma = flops_class / (peak_mfma * 1e12)
+            t_hbm = bytes_class[dom] / (PEAK_HBM_GBS * 1e9)
+            ach_tf = flops_class / t_meas / 1e12
+            ach_gb = bytes_class[dom] / t_meas / 1e9
             traffic = None
             tp = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get(dom)
-            # achieved = fp32-equivalent algorithmic FLOP/s; a split-bf16 product costs three bf16 MFMAs, so its MFMA
-            # roof is the dense bf16 peak / 3; the exact mode is priced against the fp32-input MFMA peak
-            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if mfma_mode == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
-            roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
-                        frac=round(ach / peak, 4), frac_of_f32_mfma_peak=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                        avg_launch_ms=round(avg_ms, 5), launches_per_step=kern[dom]['launches'] / args.steps,
+            hbm_bound = t_hbm >= t_mfma
+            roof = dict(bound='hbm' if hbm_bound else 'mfma', kernel=dom,
+                        achieved=round(ach_gb if hbm_bound else ach_tf, 2), peak=PEAK_HBM_GBS if hbm_bound else round(peak_mfma, 1),
+                        unit='GB/s' if hbm_bound else 'TFLOP/s', frac=round(max(t_hbm, t_mfma) / t_meas, 4), traffic=traffic,
+                        hbm_term=dict(algorithmic_bytes_per_launch=round(bytes_class[dom] / nlaunch), achieved_GBs=round(ach_gb, 1),
+                                      peak_GBs=PEAK_HBM_GBS, frac=round(t_hbm / t_meas, 4)),
+                        mfma_term=dict(algorithmic_flop_per_launch=round(flops_class / nlaunch), achieved_TFLOPs=round(ach_tf, 2),
+                                       peak_TFLOPs=round(peak_mfma, 1), frac=round(t_mfma / t_meas, 4),
+                                       frac_of_f32_mfma_peak=round(ach_tf / PEAK_FP32_MFMA_TFLOPS, 4)),
+                        avg_launch_ms=round(avg_ms, 5), launches_per_step=nlaunch,
                         measured='second pass of the same %d steps with per-launch HIP events' % args.steps,
                         ms_per_step_with_events=round(dt_ev / args.steps * 1e3, 4),
                         classes={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 4),
-                                         tflops=round(flops_class * args.steps / (v['total_ms'] * 1e-3) / 1e12, 2))
+                                         tflops=round(flops_class * args.steps / (v['total_ms'] * 1e-3) / 1e12, 2),
+                                         algorithmic_GBs=round(bytes_class[k] * args.steps / (v['total_ms'] * 1e-3) / 1e9, 1))
                                  for k, v in kern.items()})
         out = {
             'metric': 'sentences/sec (inside+outside fwd+bwd), len-%d d=%d bsz=%d' % (L, D, B),
