@@ -22,6 +22,7 @@ using namespace cliora;
 struct cliora_plan {
     Plan p;
     bool uploaded = false;
+    int proj_kind = 2;          // image kind of the projection weights the last forward call built (IMG_FRAG_F32 / IMG_SPLIT_BF16)
 };
 
 static thread_local std::string g_err;
@@ -154,6 +155,7 @@ static int pick_tiles(int ntiles16) {
 }
 
 static int image_stride(int K);
+static bool split_bf16();
 // The per-cell projection GEMMs (leaf, PL/PR/QL and their backward) stay on the exact fp32-input MFMA by default: their
 // outputs feed the split scores, where the 2^-18 operand rounding of the split shows up as ~1e-4 absolute on scores of
 // magnitude ~15 (measured, tools/accuracy.py), and they are latency-bound, so the split buys little (~3 % of a step).
@@ -164,10 +166,10 @@ static bool split_bf16_proj() {
         const char* e = getenv("CLIORA_PROJ_MFMA");
         g_split_proj = (e && !strcmp(e, "bf16x3")) ? 1 : 0;
     }
-    return g_split_proj == 1;
+    return g_split_proj == 1 && split_bf16();      // never in the exact-fp32 mode
 }
 // image argument pair (pointer, kind) of a projection weight: its split-bf16 image or its fp32 fragment image
-#define PROJ_IMG(off) (ws + (off)), (split_bf16_proj() ? 1 /* IMG_SPLIT_BF16 */ : 2 /* IMG_FRAG_F32 */)
+#define PROJ_IMG(off) (ws + (off)), proj_kind        /* proj_kind: local of the entry point, see cliora_plan::proj_kind */
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
 static int g_split_bf16 = -1;
@@ -537,6 +539,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     if (!plan || !P || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
+    const int proj_kind = plan->proj_kind = split_bf16_proj() ? IMG_SPLIT_BF16 : IMG_FRAG_F32;
     const bool vl = p.R > 0;
     if (p.arch != 0) return fail(CLIORA_EINVAL, "TreeLSTM plan: use cliora_lstm_forward");
     if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
@@ -603,7 +606,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
             pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
             OKR(build_weight_images(st, im));
-            OKR(split_bf16_proj() ? build_weight_images(st, pj) : build_frag_images(st, pj));
+            OKR(proj_kind == IMG_SPLIT_BF16 ? build_weight_images(st, pj) : build_frag_images(st, pj));
         }
     }
 
@@ -700,6 +703,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     if (!plan || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws || !bwd_ws || !G)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
+    const int proj_kind = plan->proj_kind;      // the images this plan's last forward call left in the workspace
     const bool vl = p.R > 0;
     if (p.arch != 0) return fail(CLIORA_EINVAL, "TreeLSTM plan: use cliora_lstm_backward");
     if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
@@ -863,6 +867,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     if (!plan || !P || !x_span || !inside_h || !inside_c || !inside_s || !outside_h || !outside_c || !outside_s || !fwd_ws)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
+    const int proj_kind = plan->proj_kind = split_bf16_proj() ? IMG_SPLIT_BF16 : IMG_FRAG_F32;
     if (p.arch != 1) return fail(CLIORA_EINVAL, "not a TreeLSTM plan (create it with cliora_plan_create_ex(..., arch = 1))");
     if (!P->lstm_w || !P->lstm_u || !P->lstm_b || !P->in_mat || !P->root_h || !P->root_c) return fail(CLIORA_EINVAL, "missing TreeLSTM parameter");
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
@@ -910,7 +915,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
             pj.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
             pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
             pj.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
-            OKR(split_bf16_proj() ? build_weight_images(st, pj) : build_frag_images(st, pj));
+            OKR(proj_kind == IMG_SPLIT_BF16 ? build_weight_images(st, pj) : build_frag_images(st, pj));
         }
     }
     // leaves
@@ -983,6 +988,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     if (!plan || !x_span || !inside_h || !inside_c || !inside_s || !outside_h || !outside_c || !outside_s || !fwd_ws || !bwd_ws || !G)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
+    const int proj_kind = plan->proj_kind;      // the images this plan's last forward call left in the workspace
     if (p.arch != 1) return fail(CLIORA_EINVAL, "not a TreeLSTM plan");
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
     if (bwd_ws_bytes < p.bwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "backward workspace too small");
