@@ -63,6 +63,8 @@ def lib():
     L.cliora_chart_backward.restype = i32
     L.cliora_inside_pair_states.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.cliora_inside_pair_states.restype = i32
+    L.cliora_outside_pair_states.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.cliora_outside_pair_states.restype = i32
     L.cliora_plan_vl_workspace_bytes.argtypes = [vp]
     L.cliora_plan_vl_workspace_bytes.restype = sz
     L.cliora_vl_scores_forward.argtypes = [vp] + [vp] * 5 + [i32, vp, vp, vp, sz, vp]

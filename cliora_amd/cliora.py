@@ -171,14 +171,7 @@ class DioraMLP(DioraBase):
         self.chart = ch
         self._wss, self._plan, self._nchunks = holder, plan, 1
         self.init_with_batch(ih[:, :L], ic[:, :L])
-        if self._hook_overridden('outside_hook'):
-            # the reference calls outside_hook(level, h, c, s) with the per-pair outside states (diora.py:398) and never
-            # overrides it; the native pass keeps those rows in its own split order, so an override cannot be served
-            raise NotImplementedError('outside_hook is not served by the native chart path (inside_hook is)')
-        if self._hook_overridden('inside_hook'):
-            for level in range(1, L):
-                h, s = self.pair_states(level)
-                self.inside_hook(level, h, torch.zeros_like(h), s)
+        self._serve_hooks(L)
         # cliora.py:453-468
         all_att, vg = VLScoreFunction.apply(plan, self.training, ih, oh, obj_embed_span, x_word, obj_embed_word)
         self.all_atten_score = all_att

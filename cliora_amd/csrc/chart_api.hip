@@ -1251,6 +1251,19 @@ extern "C" int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_ws, 
     return CLIORA_OK;
 }
 
+extern "C" int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_ws, int level, const float** scores, const float** h,
+                                          size_t* rows, size_t* ldh) {
+    if (!plan || !fwd_ws || !scores || !h || !rows || !ldh) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (level < 0 || level > p.L - 2) return fail(CLIORA_EINVAL, "level out of range");
+    const size_t r0 = (size_t)p.row_base_out(level);
+    *scores = (const float*)fwd_ws + p.fwd.sp + r0;
+    *h = (const float*)fwd_ws + p.fwd.y + r0 * p.Dp;
+    *rows = (size_t)p.B * (p.L - level) * (p.L - level - 1);
+    *ldh = (size_t)p.Dp;
+    return CLIORA_OK;
+}
+
 // One wavefront per sentence.  val[] (chart of best scores) lives in LDS; leaves start at 1
 // (analysis/cky.py:24-25, 39).  Candidate = (val_l + val_r) + (s_n - max_n s) in fp32, in that
 // order (cky.py:83, utils.py:89-90); argmax keeps the first maximum (cky.py:86).

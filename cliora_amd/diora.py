@@ -294,14 +294,7 @@ class DioraBase(nn.Module):
         self.chart = ch
         self._wss, self._plan, self._nchunks = holder, plan, nchunks
         self.init_with_batch(ih[:, :L], ch.inside_c[:, :L])
-        if self._hook_overridden('outside_hook'):
-            # the reference calls outside_hook(level, h, c, s) with the per-pair outside states (diora.py:398) and never
-            # overrides it; the native pass keeps those rows in its own split order, so an override cannot be served
-            raise NotImplementedError('outside_hook is not served by the native chart path (inside_hook is)')
-        if self._hook_overridden('inside_hook'):
-            for level in range(1, L):
-                h, s = self.pair_states(level)
-                self.inside_hook(level, h, torch.zeros_like(h), s)
+        self._serve_hooks(L)
         return None
 
     # ---- un-aggregated per-split tensors the hooks receive (diora.py:295-334)
@@ -321,6 +314,44 @@ class DioraBase(nn.Module):
         if len(hs) == 1:
             return hs[0], ss[0]
         return torch.cat(hs, 0), torch.cat(ss, 0)
+
+    def pair_states_out(self, level):
+        """(h, s) of one outside level in the REFERENCE's order (diora.py:364-398): h (B*N*Lc, D) compose outputs,
+        s (B, N, Lc, 1) split scores, N = L-level-1 (parent, sibling) splits of the Lc = L-level target cells."""
+        plan = self._plan
+        L = plan.L
+        Lc, N = L - level, L - level - 1
+        ii = torch.arange(N).view(N, 1)
+        jj = torch.arange(Lc).view(1, Lc).expand(N, Lc)
+        nn_ = torch.where(jj < N - ii, L - 2 - ii - level, N - ii - 1)          # our split of the reference's (i, j)
+        hs, ss = [], []
+        for ws in self._wss:
+            ps, ph, rows, ldh = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+            _lib.check(_lib.lib().cliora_outside_pair_states(plan.handle, _ptr(ws), level, C.byref(ps), C.byref(ph),
+                                                             C.byref(rows), C.byref(ldh)), 'cliora_outside_pair_states')
+            wsf = ws.view(torch.float32)
+            so, ho = (ps.value - ws.data_ptr()) // 4, (ph.value - ws.data_ptr()) // 4
+            n, ld = rows.value, ldh.value
+            jd, nd = jj.to(ws.device), nn_.to(ws.device)
+            s_ours = wsf[so:so + n].view(plan.B, Lc, N)
+            h_ours = wsf[ho:ho + n * ld].view(plan.B, Lc, N, ld)
+            ss.append(s_ours[:, jd, nd].unsqueeze(-1))                           # (B, N, Lc, 1)
+            hs.append(h_ours[:, jd, nd][..., :plan.D].reshape(plan.B * N * Lc, plan.D))
+        if len(hs) == 1:
+            return hs[0], ss[0]
+        return torch.cat(hs, 0), torch.cat(ss, 0)
+
+    def _serve_hooks(self, L):
+        """inside_hook / outside_hook overrides get the per-split states the reference passes them (diora.py:331, 398),
+        after the native passes have run."""
+        if self._hook_overridden('inside_hook'):
+            for level in range(1, L):
+                h, s = self.pair_states(level)
+                self.inside_hook(level, h, torch.zeros_like(h), s)
+        if self.outside and self._hook_overridden('outside_hook'):
+            for level in range(L - 2, -1, -1):
+                h, s = self.pair_states_out(level)
+                self.outside_hook(level, h, torch.zeros_like(h), s)
 
     def cky(self):
         """Best binary tree per sentence (analysis/cky.py:31-99) decoded on the GPU.

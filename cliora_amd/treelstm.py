@@ -106,9 +106,8 @@ class DioraTreeLSTM(DioraBase):
         self._wss, self._plan, self._nchunks = holder, plan, 1
         self.init_with_batch(ih[:, :L], ic[:, :L])
         if self._hook_overridden('outside_hook'):
-            # the reference calls outside_hook(level, h, c, s) with the per-pair outside states (diora.py:398) and never
-            # overrides it; the native pass keeps those rows in its own split order, so an override cannot be served
-            raise NotImplementedError('outside_hook is not served by the native chart path (inside_hook is)')
+            # the TreeLSTM pair rows keep (h, c) of the outside splits in this library's own order only
+            raise NotImplementedError('outside_hook is not served by the native TreeLSTM path (inside_hook is)')
         if self._hook_overridden('inside_hook'):
             for level in range(1, L):
                 h, s = self.pair_states(level)

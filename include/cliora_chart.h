@@ -165,6 +165,14 @@ int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_h, const fl
 int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_workspace, int level,
                               const float** scores, const float** h, size_t* rows, size_t* ldh);
 
+/* The same for the outside pass (what the reference hands to outside_hook, diora.py:364-398), for target `level`
+ * (0 <= level <= L-2): `rows` = B*(L-level)*(L-level-1) rows in THIS library's split order
+ * [sentence][target position j][split n]; the reference's order is [sentence][split i][target position j] with
+ *   n = L-2-i-level  if j < (L-level-1) - i,   else n = (L-level-1) - i - 1
+ * (cliora/net/outside_index.py:39-62; cliora_amd/index.py::Index.get_outside_index applies it). */
+int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_workspace, int level,
+                               const float** scores, const float** h, size_t* rows, size_t* ldh);
+
 /* CKY decode (cliora/analysis/cky.py:31-99 + analysis/utils.py:78-95): best binary
  * tree per sentence from the inside per-split scores of the last forward; first
  * maximum wins.  split_out (B, C) int32 device: chosen split n per cell (leaves -1);

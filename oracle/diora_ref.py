@@ -160,7 +160,7 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
         Win, Wout = _side(P, 'inside', share), _side(P, 'outside', share)
     off = CL.level_offsets(L)
     ch = Charts(B, L, D)
-    pair_s_in, pair_s_out = {}, {}
+    pair_s_in, pair_s_out, pair_h_out = {}, {}, {}
 
     # ---- leaves: diora.py:58-63,283-292 / cliora.py:71-80,290-301
     if lstm:
@@ -239,10 +239,11 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
             ch.outside_s[:, o:o + Lc] = s_agg
             if keep_pairs:
                 pair_s_out[level] = s
+                pair_h_out[level] = ph.view(B, N, Lc, -1)       # what outside_hook receives as h (diora.py:398)
 
     out = dict(inside_h=ch.inside_h, inside_c=ch.inside_c, inside_s=ch.inside_s,
                outside_h=ch.outside_h, outside_c=ch.outside_c, outside_s=ch.outside_s,
-               pair_s_in=pair_s_in, pair_s_out=pair_s_out,
+               pair_s_in=pair_s_in, pair_s_out=pair_s_out, pair_h_out=pair_h_out,
                all_atten_score=None, vg_atten_score=None, atten_score=None)
 
     # ---- CLIORA tail: cliora.py:453-468

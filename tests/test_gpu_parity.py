@@ -298,3 +298,29 @@ def test_limits_of_the_plan(D, B, L, mfma_mode):
         with torch.no_grad():
             want = R.cky_trees(R.diora_forward(P, x, x, keep_pairs=True)['pair_s_in'], B, L)
         assert [str(t) for t in m.cky()] == [str(t) for t in want]
+
+
+def test_outside_hook_receives_the_reference_states():
+    """An overridden outside_hook gets (level, h, c, s) in the reference's layout and order (diora.py:364-398):
+    s (B, N, Lc, 1), h (B*N*Lc, D), from level L-2 down to 0 -- checked against the oracle's per-split outside states."""
+    import types
+    from oracle import diora_ref as R
+    from oracle import synth
+    D, B, L = 24, 3, 7
+    P, x, _ = synth.diora_case(D, B, L, 19)
+    m = _module_from_params(P, D, True, 'unit').eval()
+    seen = []
+    m.outside_hook = types.MethodType(lambda self, level, h, c, s: seen.append((level, h.clone(), c.clone(), s.clone())), m)
+    with torch.no_grad():
+        m(x.cuda(), x.cuda())
+        ref = R.diora_forward(P, x, x, keep_pairs=True)
+    assert [lv for lv, _, _, _ in seen] == list(range(L - 2, -1, -1))
+    for level, h, c, s in seen:
+        Lc, N = L - level, L - level - 1
+        want_s = ref['pair_s_out'][level]
+        assert tuple(s.shape) == (B, N, Lc, 1) == tuple(want_s.shape)
+        assert _err(s, want_s) <= 2e-4 * _scale(want_s), level
+        assert tuple(h.shape) == (B * N * Lc, D) and float(c.abs().max()) == 0.0
+        if 'pair_h_out' in ref:
+            want_h = ref['pair_h_out'][level].reshape(B * N * Lc, D)      # un-normalised compose outputs (magnitude ~10)
+            assert _err(h, want_h) <= OUT_TOL * _scale(want_h), level
