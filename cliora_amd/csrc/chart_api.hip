@@ -725,7 +725,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const float* X = padded ? ws + f.xp : x_span;
     float *VH = wb + bw.vh, *dG = wb + bw.dg, *dStot = wb + bw.dstot, *DA = wb + bw.da, *DS = wb + bw.ds;
     float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
-    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po, *Xp = ws + f.x;
+    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *Xp = ws + f.x;
     float* DZ = wb + bw.dz;
     const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
     // CLIORA: the unit-norm / softmax backward of the inside cells works on u = unit(aggregate), not on h

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
     // LDS / global offset, ring slot and "second run inside the row" test becomes an immediate (d = 400: K16 = 25);
     // K16 == 0: the same code with run-time K
     constexpr bool KS = K16 > 0;
+    constexpr int UNROLL_STEPS = KS ? 64 : 1;      // the k-step loop: fully unrolled when K is a compile-time constant
     const int K = KS ? K16 * 16 : K_;
     const int S = KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
         asm volatile("" : "+v"(wfrag_off));
         const uint32_t* wfrag = lds_img + wfrag_off;
         int side_turn = 0;                       // k-step modulo the number of column blocks (side output shared out)
-#pragma unroll(KS ? 64 : 1)
+#pragma unroll UNROLL_STEPS
         for (int base = 0; base < nsteps_p; base += PD) {
 #pragma unroll
             for (int sl = 0; sl < PD; ++sl) {
