@@ -4,7 +4,9 @@ The product path has NO CPU fallback: if the HIP library is missing or a call
 fails, this raises.  Build it with ``python -m cliora_amd.build`` (or
 ``__graft_entry__.build()``).
 """
+import collections
 import ctypes as C
+import functools
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -55,6 +57,8 @@ def lib():
     L.cliora_plan_fwd_workspace_bytes.restype = sz
     L.cliora_plan_bwd_workspace_bytes.argtypes = [vp]
     L.cliora_plan_bwd_workspace_bytes.restype = sz
+    L.cliora_plan_device_bytes.argtypes = [vp]
+    L.cliora_plan_device_bytes.restype = sz
     L.cliora_plan_table.argtypes = [vp, C.c_char_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(sz)]
     L.cliora_plan_table.restype = i32
     L.cliora_chart_forward.argtypes = [vp, C.POINTER(Params)] + [vp] * 8 + [vp, sz, i32, vp]
@@ -104,6 +108,7 @@ class Plan:
         self.handle = h
         self.fwd_bytes = lib().cliora_plan_fwd_workspace_bytes(h)
         self.bwd_bytes = lib().cliora_plan_bwd_workspace_bytes(h)
+        self.table_bytes = lib().cliora_plan_device_bytes(h)     # index tables: this much host memory, and as much HBM after the first forward
 
     def table(self, name):
         import numpy as np
@@ -123,17 +128,41 @@ class Plan:
             pass
 
 
-_plans = {}
+# Plan cache: least-recently-used, bounded by the bytes of index tables the cached plans hold (host + device).  Length-bucketed
+# batches give one (B, L) key per bucket; a plan at B=64, L=40 holds ~25 MB of tables, so the budget keeps a few dozen shapes.
+PLAN_CACHE_BYTES = int(os.environ.get('CLIORA_PLAN_CACHE_MB', '512')) << 20
+_plans = collections.OrderedDict()
 
 
 def get_plan(B, L, D, share, normalize, R, device_index, arch=0):
     key = (B, L, D, bool(share), normalize, R, device_index, arch)
     pl = _plans.get(key)
-    if pl is None:
-        if len(_plans) > 64:
-            _plans.clear()
-        pl = _plans[key] = Plan(B, L, D, share, normalize, R, arch)
+    if pl is not None:
+        _plans.move_to_end(key)
+        return pl
+    pl = _plans[key] = Plan(B, L, D, share, normalize, R, arch)
+    total = sum(q.table_bytes for q in _plans.values())
+    while total > PLAN_CACHE_BYTES and len(_plans) > 1:
+        _, old = _plans.popitem(last=False)          # evicted plans free their device tables when the last user drops them
+        total -= old.table_bytes
     return pl
+
+
+def on_device(pick):
+    """Decorator for the autograd Function bodies: run under the device of the tensor `pick(*args)` returns, so that the
+    plan's index tables, the kernels' per-device attributes and every allocation land on the tensors' GPU even when it is
+    not the current one."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def run(*args):
+            import torch
+            t = pick(*args)
+            if t is None or not t.is_cuda:
+                return fn(*args)
+            with torch.cuda.device(t.device):
+                return fn(*args)
+        return run
+    return deco
 
 
 def prof_enable(kclass, on=True):

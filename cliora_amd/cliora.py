@@ -25,6 +25,7 @@ class VLChartFunction(torch.autograd.Function):
     """cliora_chart_forward / _backward with image regions (R > 0)."""
 
     @staticmethod
+    @_lib.on_device(lambda ctx, plan, holder, run_outside, x_span, *a: x_span)
     def forward(ctx, plan, holder, run_outside, x_span, obj_span, drop_mask, *params):
         if not x_span.is_cuda:
             raise _lib.ChartLibError('the chart path runs on the GPU only (got a CPU tensor)')
@@ -54,6 +55,7 @@ class VLChartFunction(torch.autograd.Function):
         return inside_h, inside_s, outside_h, outside_s, inside_c
 
     @staticmethod
+    @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
     def backward(ctx, d_ih, d_is, d_oh, d_os, _d_ic):
         plan = ctx.plan
         x_span, obj_span, inside_h, inside_s, outside_h, outside_s = ctx.saved_tensors
@@ -78,6 +80,7 @@ class VLScoreFunction(torch.autograd.Function):
     """cliora_vl_scores_forward / _backward: the einsum('abx,cdx->acbd') scorers of cliora.py:453-466."""
 
     @staticmethod
+    @_lib.on_device(lambda ctx, plan, training, inside_h, *a: inside_h)
     def forward(ctx, plan, training, inside_h, outside_h, obj_span, x_word, obj_word):
         B, L, Cc, R = plan.B, plan.L, plan.C, plan.R
         tens = [t.contiguous().float() for t in (inside_h, outside_h, obj_span, x_word, obj_word)]
@@ -95,6 +98,7 @@ class VLScoreFunction(torch.autograd.Function):
         return all_att, vg
 
     @staticmethod
+    @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
     def backward(ctx, d_all, d_vg):
         plan = ctx.plan
         inside_h, outside_h, obj_span, x_word, obj_word = ctx.saved_tensors
@@ -169,7 +173,7 @@ class DioraMLP(DioraBase):
         ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s, ch.inside_c = ih, is_, oh, os_, ic
         ch.outside_c = torch.zeros_like(oh)
         self.chart = ch
-        self._wss, self._plan, self._nchunks = holder, plan, 1
+        self._wss, self._plan = holder, plan
         self.init_with_batch(ih[:, :L], ic[:, :L])
         self._serve_hooks(L)
         # cliora.py:453-468

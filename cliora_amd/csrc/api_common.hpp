@@ -1,0 +1,432 @@
+// Shared pieces of the C-ABI translation units (api_core / api_mlp / api_lstm / api_vl): the plan handle, error and
+// profiling plumbing, and the launch helpers of the MFMA kernels.  Header-only templates: each unit instantiates what it uses,
+// so the units compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cliora_chart.h"
+#include "chart_kernels.hpp"
+#include "gemm_kernels.hpp"
+#include "plan.hpp"
+
+using namespace cliora;
+
+struct cliora_plan {
+    Plan p;
+    bool uploaded = false;
+    int device = -1;            // HIP device the index tables live on (set at upload; every later call must run there)
+};
+
+extern thread_local std::string g_cliora_err;
+static inline int fail(int code, const std::string& msg) { g_cliora_err = msg; return code; }
+
+#define HIPOK(expr)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CLIORA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+#define LAUNCHOK(name)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CLIORA_EHIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define OKR(expr) do { int rc_ = (expr); if (rc_ != CLIORA_OK) return rc_; } while (0)
+
+// kernels that need more than 64 KiB of dynamic LDS: the attribute is per device, so it is set once per (function, device)
+int cliora_ensure_max_lds(const void* fn);
+// uploads the plan's index tables on first use (current device) and checks that later calls run on that device
+int cliora_plan_ready(cliora_plan* plan, hipStream_t st);
+
+// ------------------------------------------------------------------ profiling (HIP events)
+struct ProfClass {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t used = 0;
+    double total_ms = 0;
+    long long launches = 0;
+};
+extern ProfClass g_cliora_prof[CLIORA_KCLASS_COUNT];
+struct ProfScope {
+    ProfClass* pc = nullptr;
+    hipStream_t st;
+    hipEvent_t stop{};
+    ProfScope(int cls, hipStream_t s) : st(s) {
+        ProfClass& c = g_cliora_prof[cls];
+        if (!c.on) return;
+        if (c.used + 2 > c.ev.size()) {
+            for (int k = 0; k < 256; ++k) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c.ev.push_back(e); }
+        }
+        pc = &c;
+        hipEventRecord(c.ev[c.used], st);
+        stop = c.ev[c.used + 1];
+        c.used += 2;
+    }
+    ~ProfScope() { if (pc) hipEventRecord(stop, st); }
+};
+
+// Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
+// gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
+extern int g_cliora_split_bf16;
+static inline bool split_bf16() {
+    if (g_cliora_split_bf16 < 0) {
+        const char* e = getenv("CLIORA_MFMA");
+        g_cliora_split_bf16 = (e && !strcmp(e, "f32")) ? 0 : 1;
+    }
+    return g_cliora_split_bf16 == 1;
+}
+// The per-cell projection GEMMs (leaf, PL/PR/QL and their backward) run on the exact fp32-input MFMA in both modes: their
+// outputs feed the split scores, where a 2^-18 operand rounding shows up as ~1e-4 absolute on scores of magnitude ~15
+// (measured in round 1), and they are latency-bound.  Their weights are read from fp32 fragment images (frag_weight_image).
+static inline int image_stride(int K) { return (K + 31) / 32 * 32 + WS3_PAD; }
+// image argument pair (pointer, kind) of a projection weight
+#define PROJ_IMG(off) (ws + (off)), IMG_FRAG_F32
+
+// ------------------------------------------------------------------ launch helpers
+static int pick_tiles(int ntiles16) {
+    for (int t : {5, 4, 2, 1}) if (ntiles16 % t == 0) return t;
+    return 1;
+}
+
+template <int CT, int SC, int WAVES, class AP, class EP>
+static int launch_rows_inst(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    const size_t lds = (size_t)CT * 16 * (Kseg + WS_LDS_PAD) * sizeof(float);
+    OKR(cliora_ensure_max_lds((const void*)rows_gemm_ws<CT, SC, WAVES, AP, EP>));
+    const int ntiles = (nrows + 15) / 16;
+    const int gy = ncols / (16 * CT);
+    // one workgroup per CU (the weight block fills LDS): take the fewest passes over the row tiles the chip allows,
+    // then the smallest grid that still does it in that many passes
+    const int cap = std::max(1, 256 / gy);
+    const int passes = (ntiles + WAVES * cap - 1) / (WAVES * cap);
+    int gx = (ntiles + WAVES * passes - 1) / (WAVES * passes);
+    // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8
+    // the gy column blocks that re-read the same A rows share one XCD's L2 (speed only, never correctness)
+    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;
+    hipLaunchKernelGGL((rows_gemm_ws<CT, SC, WAVES, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, W, Kseg * nseg, Kseg, nseg,
+                       nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ws");
+    return CLIORA_OK;
+}
+
+template <int CT, int SC, class AP, class EP>
+static int launch_rows_waves(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    // one wave per SIMD while the launch cannot fill the chip twice over; two per SIMD beyond that
+    const long long tasks = (long long)((nrows + 15) / 16) * (ncols / (16 * CT));
+    if (tasks > 1536) return launch_rows_inst<CT, SC, 8>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    return launch_rows_inst<CT, SC, 4>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+}
+
+template <int CT, class AP, class EP>
+static int launch_rows_ct(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    const int chunks = Kseg / 16;
+    if (chunks % 5 == 0) return launch_rows_waves<CT, 5>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    if (chunks % 4 == 0) return launch_rows_waves<CT, 4>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    if (chunks % 2 == 0) return launch_rows_waves<CT, 2>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+    return launch_rows_waves<CT, 1>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+}
+
+// small-row variant (per-level cell GEMMs): 32 x (CT*16) blocks, reduction split over the 4 waves, no weight staging
+// One split-K launch: blocks of (RT*16 rows) x (CT*16 columns).  A block's MFMA work and operand bytes are fixed by
+// its tile, so a launch with few blocks leaves most CUs idle while the busy ones work through a long reduction: the
+// tile shrinks (2x5 -> 1x5 -> 1x1 sixteen-wide tiles) until the launch has enough blocks to cover the chip.
+template <int RT, int CT, bool FRAG, class AP, class EP>
+static int launch_ksplit_tile(hipStream_t st, const float* W, int K, int nt, int nrows, AP ap, EP ep) {
+    const int nrg = ((nrows + 15) / 16 + RT - 1) / RT;
+    // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+    hipLaunchKernelGGL((rows_gemm_ksplit<RT, CT, FRAG, AP, EP>), dim3(nrgp * (nt / CT)), dim3(256), 0, st, W, K, nrg, nrgp, nt / CT, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ksplit");
+    return CLIORA_OK;
+}
+static int g_ksplit_min_blocks = -1;   // per translation unit (read from the environment once each)
+template <int CT, bool FRAG, class AP, class EP>
+static int launch_ksplit_ct(hipStream_t st, const float* W, int K, int nt, int nrows, AP ap, EP ep) {
+    if (g_ksplit_min_blocks < 0) { const char* e = getenv("CLIORA_KSPLIT_MIN_BLOCKS"); g_ksplit_min_blocks = e ? atoi(e) : 1000; }   // MI355X sweep 0..2000: 5.61 ms/step at 0, 5.44 at 160, 5.37 at 1000
+    const int nrt = (nrows + 15) / 16;
+    if (((nrt + 1) / 2) * (nt / CT) >= g_ksplit_min_blocks) return launch_ksplit_tile<2, CT, FRAG>(st, W, K, nt, nrows, ap, ep);
+    if (CT == 1 || nrt * (nt / CT) >= g_ksplit_min_blocks) return launch_ksplit_tile<1, CT, FRAG>(st, W, K, nt, nrows, ap, ep);
+    return launch_ksplit_tile<1, 1, FRAG>(st, W, K, nt, nrows, ap, ep);
+}
+template <bool FRAG, class AP, class EP>
+static int launch_ksplit_f32(hipStream_t st, const float* W, int K, int nt, int nrows, AP ap, EP ep) {
+    if (nt % 5 == 0) return launch_ksplit_ct<5, FRAG>(st, W, K, nt, nrows, ap, ep);
+    if (nt % 4 == 0) return launch_ksplit_ct<4, FRAG>(st, W, K, nt, nrows, ap, ep);
+    if (nt % 2 == 0) return launch_ksplit_ct<2, FRAG>(st, W, K, nt, nrows, ap, ep);
+    return launch_ksplit_ct<1, FRAG>(st, W, K, nt, nrows, ap, ep);
+}
+
+// image kinds a split-K launch can take beside the plain weight
+enum { IMG_NONE = 0, IMG_SPLIT_BF16 = 1, IMG_FRAG_F32 = 2 };
+
+template <class AP, class EP>
+static int launch_rows_direct(hipStream_t st, const float* W, const float* img, int kind, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const int nt = ncols / 16;
+    const int nrg = ((nrows + 15) / 16 + 1) / 2;
+    // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+    if (kind == IMG_SPLIT_BF16) {      // split-bf16 arithmetic on the weight's image
+        const uint32_t* I = reinterpret_cast<const uint32_t*>(img);
+        const int S = image_stride(K);
+        if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 5, nrows, ap, ep);
+        else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 4, nrows, ap, ep);
+        else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 2, AP, EP>), dim3(nrgp * (nt / 2)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 2, nrows, ap, ep);
+        else hipLaunchKernelGGL((rows_gemm_ksplit3<2, 1, AP, EP>), dim3(nrgp * nt), dim3(256), 0, st, I, S, K, nrg, nrgp, nt, nrows, ap, ep);
+        LAUNCHOK("rows_gemm_ksplit3");
+        return CLIORA_OK;
+    }
+    if (kind == IMG_FRAG_F32) return launch_ksplit_f32<true>(st, img, K, nt, nrows, ap, ep);
+    return launch_ksplit_f32<false>(st, W, K, nt, nrows, ap, ep);
+}
+
+// out[r][j] = sum_k A(r,k) W[j][k] for j < ncols (multiple of 16); k runs over nseg segments of Kseg (multiple of 16)
+template <class AP, class EP>
+static int launch_rows(hipStream_t st, const float* W, int Kseg, int nseg, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const size_t budget = 150 * 1024;
+    const int nt = ncols / 16;
+    for (int ct : {5, 4, 2, 1}) {
+        if (nt % ct) continue;
+        if ((size_t)ct * 16 * (Kseg + WS_LDS_PAD) * sizeof(float) > budget) continue;
+        switch (ct) {
+            case 5: return launch_rows_ct<5>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+            case 4: return launch_rows_ct<4>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+            case 2: return launch_rows_ct<2>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+            default: return launch_rows_ct<1>(st, W, Kseg, nseg, ncols, nrows, ap, ep);
+        }
+    }
+    return fail(CLIORA_EINVAL, "weight block does not fit LDS");
+}
+
+template <int T, class AP, class BP>
+static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats,
+                       float* out, float* colsum_out) {
+    const int blocks = (Mi / (T * 16)) * (Nj / (T * 16));
+    size_t per_slice = (size_t)Mi * Nj + (colsum_out ? Mi : 0);
+    int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 2048 / blocks));
+    nsl = std::min(nsl, (nrows + 15) / 16);
+    nsl = std::max(4, nsl / 4 * 4);
+    if ((size_t)nsl * per_slice > slab_floats) return fail(CLIORA_ENOMEM, "slab too small for the weight-gradient GEMM");
+    int rps = (nrows + nsl - 1) / nsl;
+    rps = (rps + 3) / 4 * 4;
+    float* csl = slab + (size_t)nsl * Mi * Nj;
+    if (colsum_out)
+        hipLaunchKernelGGL((tn_gemm<T, T, true, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
+    else
+        hipLaunchKernelGGL((tn_gemm<T, T, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
+    LAUNCHOK("tn_gemm");
+    const size_t n = (size_t)Mi * Nj;
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
+    LAUNCHOK("slab_reduce");
+    if (colsum_out) {
+        hipLaunchKernelGGL(slab_reduce, dim3((Mi + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Mi, colsum_out);
+        LAUNCHOK("slab_reduce(colsum)");
+    }
+    return CLIORA_OK;
+}
+
+// out[i][j] = sum_r A(r,i) B(r,j); colsum_out[i] = sum_r A(r,i) (optional)
+template <class AP, class BP>
+static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, BP bp, float* slab, size_t slab_floats,
+                     float* out, float* colsum_out) {
+    if (nrows <= 0) {
+        HIPOK(hipMemsetAsync(out, 0, (size_t)Mi * Nj * sizeof(float), st));
+        if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Mi * sizeof(float), st));
+        return CLIORA_OK;
+    }
+    switch (pick_tiles(Dp / 16)) {
+        case 5: return launch_tn_t<5>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        case 4: return launch_tn_t<4>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        case 2: return launch_tn_t<2>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        default: return launch_tn_t<1>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+    }
+}
+
+// the big weight-gradient GEMM over span-pair rows: C = DZ^T X (Mi = Nj = Dp), LDS-DMA fed, split over row slices
+template <int NIT, int NJT>
+static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, int nkb, float* slab,
+                                size_t slab_floats, float* out, float* colsum_out) {
+    const size_t per_slice = (size_t)Dp * Dp + Dp;
+    int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 256 / nkb));
+    nsl = std::max(1, std::min(nsl, (nrows + 63) / 64));
+    int rps = (nrows + nsl - 1) / nsl;
+    rps = (rps + TN_RS - 1) / TN_RS * TN_RS;
+    nsl = (nrows + rps - 1) / rps;
+    float* csl = slab + (size_t)nsl * Dp * Dp;
+    const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float) + (size_t)NJT * 2048;   // two fp32 stages + the split column fragments
+    if (split_bf16() && lds3 <= 160 * 1024 && (Dp + NJT * 16) / 32 <= TN3_NP) {
+        OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3<NIT, NJT, true>));
+        // whole groups of 8 slices (one per XCD), all resident at once: one workgroup per CU, no second round
+        const int nsl_cap = std::max(1, 256 / (8 * nkb)) * 8;
+        if (nsl > nsl_cap) { nsl = nsl_cap; rps = (nrows + nsl - 1) / nsl; }
+        rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
+        nsl = (nrows + rps - 1) / rps;
+        csl = slab + (size_t)nsl * Dp * Dp;
+        hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(256), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
+        LAUNCHOK("tn_gemm_dma3");
+    } else {
+        const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);
+        OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma<NIT, NJT, true>));
+        hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
+        LAUNCHOK("tn_gemm_dma");
+    }
+    const size_t n = (size_t)Dp * Dp;
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
+    LAUNCHOK("slab_reduce");
+    hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out);
+    LAUNCHOK("slab_reduce(colsum)");
+    return CLIORA_OK;
+}
+
+static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, float* slab, size_t slab_floats,
+                           float* out, float* colsum_out) {
+    if (nrows <= 0) {
+        HIPOK(hipMemsetAsync(out, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
+        return CLIORA_OK;
+    }
+    // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
+    // nkb column blocks of NJT = ceil(NT/nkb) j-tiles
+    const int NT = Dp / 16;
+#define TN_CASE(nit, njt, nkb) return launch_tn_pairs_inst<nit, njt>(st, DZ, X, nrows, Dp, nkb, slab, slab_floats, out, colsum_out)
+    if (NT <= 4) TN_CASE(1, 4, 1);
+    if (NT <= 8) TN_CASE(2, 8, 1);
+    if (NT <= 12) TN_CASE(3, 12, 1);
+    if (NT <= 16) TN_CASE(4, 8, 2);
+    if (NT <= 20) TN_CASE(5, 10, 2);
+    if (NT <= 27) TN_CASE(7, 9, 3);     // 63 accumulator tiles = 252 registers: the most that stays spill-free
+    TN_CASE(8, 8, 4);
+#undef TN_CASE
+}
+
+template <int CT, int WAVES, int K16, class AP, class EP>
+static int launch_rows3_k(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    constexpr int PD = 4;     // four k-steps of row operands in flight per wave; deeper rings (6, 7) measured the same on MI355X
+    const size_t lds = (size_t)CT * 16 * S * sizeof(uint32_t);
+    OKR(cliora_ensure_max_lds((const void*)rows_gemm_ws3<CT, WAVES, PD, K16, AP, EP>));
+    const int ntiles = (nrows + 15) / 16;
+    const int gy = ncols / (16 * CT);
+    // same grid rule as the fp32 kernel: fewest passes over the row tiles, then the smallest grid that does it
+    const int cap = std::max(1, 256 / gy);
+    const int passes = (ntiles + WAVES * cap - 1) / (WAVES * cap);
+    int gx = (ntiles + WAVES * passes - 1) / (WAVES * passes);
+    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;
+    hipLaunchKernelGGL((rows_gemm_ws3<CT, WAVES, PD, K16, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, Wimg, S, K, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ws3");
+    return CLIORA_OK;
+}
+
+template <int CT, int WAVES, class AP, class EP>
+static int launch_rows3_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    // the hidden size of the reference's configurations (d = 400, K = 25 * 16) runs the fully unrolled instance
+    if (CT == 5 && K == 400) return launch_rows3_k<CT, WAVES, 25>(st, Wimg, S, K, ncols, nrows, ap, ep);
+    return launch_rows3_k<CT, WAVES, 0>(st, Wimg, S, K, ncols, nrows, ap, ep);
+}
+
+// out[r][j] = sum_k A(r,k) W[j][k] in split-bf16 arithmetic; Wimg = split_weight_image of W ([ncols][K], S dwords per row)
+template <class AP, class EP>
+static int launch_rows3(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const size_t budget = 150 * 1024;
+    const int nt = ncols / 16;
+    const long long ntiles = (nrows + 15) / 16;
+    for (int ct : {5, 4, 2, 1}) {
+        if (nt % ct) continue;
+        if ((size_t)ct * 16 * S * sizeof(uint32_t) > budget) continue;
+        const bool two = ntiles * (nt / ct) > 1536;      // two waves per SIMD once the launch fills the chip
+        switch (ct) {
+#define WS3_CASE(c) case c: return two ? launch_rows3_inst<c, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<c, 4>(st, Wimg, S, K, ncols, nrows, ap, ep)
+            WS3_CASE(5); WS3_CASE(4); WS3_CASE(2);
+            default: return two ? launch_rows3_inst<1, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<1, 4>(st, Wimg, S, K, ncols, nrows, ap, ep);
+#undef WS3_CASE
+        }
+    }
+    return fail(CLIORA_EINVAL, "weight block does not fit LDS");
+}
+
+// compose layer: weight-stationary kernel for the big levels, split-K kernel for the small ones
+static int g_compose_ksplit_rows = -1;  // per translation unit
+template <class AP, class EP>
+static int launch_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int nrows, AP ap, EP ep) {
+    if (g_compose_ksplit_rows < 0) {
+        const char* e = getenv("CLIORA_COMPOSE_KSPLIT_ROWS");
+        g_compose_ksplit_rows = e ? atoi(e) : 1500;   // measured crossover on MI355X (r01 sweeps: 5000 for the fp32 kernels, 1500 with the split-bf16 ones)
+    }
+    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Wimg, split_bf16() ? IMG_SPLIT_BF16 : IMG_NONE, Dp, Dp, nrows, ap, ep);
+    if (split_bf16()) return launch_rows3(st, reinterpret_cast<const uint32_t*>(Wimg), S3, Dp, Dp, nrows, ap, ep);
+    return launch_rows(st, W, Dp, 1, Dp, nrows, ap, ep);
+}
+
+// split-bf16 images (see split_weight_image) of weight matrices already in the workspace
+struct ImageList {
+    SplitImageTab tab{};
+    int n = 0, max_rows = 0, max_S = 0;
+    void add(const float* src, float* dst, int nrows, int ldw, int K) {
+        tab.src[n] = src; tab.dst[n] = reinterpret_cast<uint32_t*>(dst); tab.nrows[n] = nrows; tab.ldw[n] = ldw; tab.K[n] = K;
+        max_rows = std::max(max_rows, nrows);
+        max_S = std::max(max_S, (K + 31) / 32 * 32 + WS3_PAD);
+        ++n;
+    }
+};
+static int build_weight_images(hipStream_t st, const ImageList& l) {
+    if (l.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(split_weight_image, dim3((l.max_S + 255) / 256, l.max_rows, l.n), dim3(256), 0, st, l.tab);
+    LAUNCHOK("split_weight_image");
+    return CLIORA_OK;
+}
+static int build_frag_images(hipStream_t st, const ImageList& l) {
+    if (l.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(frag_weight_image, dim3(256, 1, l.n), dim3(256), 0, st, l.tab);
+    LAUNCHOK("frag_weight_image");
+    return CLIORA_OK;
+}
+
+static int run_copies(hipStream_t st, const CopyTable& tab) {
+    if (tab.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(copy2d_multi, dim3(64, tab.n), dim3(256), 0, st, tab);
+    LAUNCHOK("copy2d_multi");
+    return CLIORA_OK;
+}
+
+static void add_copy(CopyTable& t, float* dst, int ldd, int drows, int dcols, const float* s0, int ld0, int rows0, int cols0,
+                     int r0, int c0, int T0, const float* s1 = nullptr, int ld1 = 0, int rows1 = 0, int cols1 = 0, int r1 = 0,
+                     int c1 = 0, int T1 = 0) {
+    CopyDesc& d = t.d[t.n++];
+    d.dst = dst; d.ldd = ldd; d.drows = drows; d.dcols = dcols;
+    d.s[0] = CopySrc{s0, ld0, rows0, cols0, r0, c0, T0};
+    d.s[1] = CopySrc{s1, ld1, rows1, cols1, r1, c1, T1};
+}
+
+static inline unsigned cells_grid(int ncells) { return (unsigned)((ncells + 3) / 4); }
+
+struct Dev {   // device views for one call
+    const int32_t *arow, *brow, *trow;
+    UseTab use[N_ROLES];
+};
+static Dev dev_views(const Plan& p) {
+    Dev d;
+    const int32_t* t = p.d_tables;
+    d.arow = t + p.dev.arow; d.brow = t + p.dev.brow; d.trow = t + p.dev.trow;
+    for (int r = 0; r < N_ROLES; ++r)
+        d.use[r] = UseTab{t + p.dev.use_off[r], t + p.dev.use_row[r], t + p.dev.use_stride[r], t + p.dev.use_partner[r]};
+    return d;
+}
+
+static LevelArgs level_args(const Plan& p, int level, bool outside_pass) {
+    LevelArgs g;
+    g.B = p.B; g.C = p.C; g.Dp = p.Dp; g.Lc = p.L - level;
+    g.N = outside_pass ? p.Nout(level) : p.Nin(level);
+    g.off = p.level_offset[level];
+    g.rowbase = (int)(outside_pass ? p.row_base_out(level) : p.row_base_in(level));
+    return g;
+}

@@ -1,0 +1,201 @@
+// C ABI, core unit: plan management, error / profiling plumbing, arithmetic mode, hook views and the CKY decode.
+// See include/cliora_chart.h for the contract and the reference lines it replaces.
+#include <set>
+#include <utility>
+
+#include "api_common.hpp"
+
+thread_local std::string g_cliora_err;
+ProfClass g_cliora_prof[CLIORA_KCLASS_COUNT];
+int g_cliora_split_bf16 = -1;
+static std::mutex g_prof_mu;
+
+int cliora_ensure_max_lds(const void* fn) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    HIPOK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return CLIORA_OK;
+    HIPOK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({fn, dev});
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_prof_enable(int cls, int on) {
+    if (cls < 0 || cls >= CLIORA_KCLASS_COUNT) return fail(CLIORA_EINVAL, "bad kernel class");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_cliora_prof[cls].on = on != 0;
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_prof_read(int cls, double* total_ms, long long* launches, void* stream) {
+    if (cls < 0 || cls >= CLIORA_KCLASS_COUNT) return fail(CLIORA_EINVAL, "bad kernel class");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfClass& c = g_cliora_prof[cls];
+    HIPOK(hipStreamSynchronize((hipStream_t)stream));
+    for (size_t k = 0; k + 1 < c.used; k += 2) {
+        float ms = 0;
+        HIPOK(hipEventElapsedTime(&ms, c.ev[k], c.ev[k + 1]));
+        c.total_ms += ms;
+        c.launches += 1;
+    }
+    c.used = 0;
+    if (total_ms) *total_ms = c.total_ms;
+    if (launches) *launches = c.launches;
+    c.total_ms = 0; c.launches = 0;
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ plan
+extern "C" int cliora_plan_create(int B, int L, int D, int share, int normalize, int R, cliora_plan** out) {
+    if (!out) return fail(CLIORA_EINVAL, "out is NULL");
+    cliora_plan* pl = new (std::nothrow) cliora_plan();
+    if (!pl) return fail(CLIORA_ENOMEM, "host allocation failed");
+    const std::string e = build_plan(pl->p, B, L, D, share, normalize, R);
+    if (!e.empty()) { delete pl; return fail(CLIORA_EINVAL, e); }
+    *out = pl;
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_plan_create_ex(int B, int L, int D, int share, int normalize, int R, int arch, cliora_plan** out) {
+    if (!out) return fail(CLIORA_EINVAL, "out is NULL");
+    cliora_plan* pl = new (std::nothrow) cliora_plan();
+    if (!pl) return fail(CLIORA_ENOMEM, "host allocation failed");
+    const std::string e = build_plan(pl->p, B, L, D, share, normalize, R, arch);
+    if (!e.empty()) { delete pl; return fail(CLIORA_EINVAL, e); }
+    *out = pl;
+    return CLIORA_OK;
+}
+
+extern "C" void cliora_plan_destroy(cliora_plan* plan) {
+    if (!plan) return;
+    if (plan->p.d_tables) (void)hipFree(plan->p.d_tables);
+    delete plan;
+}
+
+extern "C" size_t cliora_plan_fwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.fwd.total * sizeof(float) : 0; }
+extern "C" size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.bwd.total * sizeof(float) : 0; }
+
+extern "C" int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count) {
+    if (!plan || !name || !data || !count) return fail(CLIORA_EINVAL, "NULL argument");
+    const std::vector<int32_t>* v = find_table(plan->p, name);
+    if (!v) return fail(CLIORA_EINVAL, std::string("unknown table ") + name);
+    *data = v->data();
+    *count = v->size();
+    return CLIORA_OK;
+}
+
+extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
+    if (!plan) return 0;
+    const Plan& p = plan->p;
+    size_t n = p.pair_a_in.size() + p.pair_b_in.size() + p.pair_a_out.size() + p.pair_b_out.size() + p.lvl_base_in.size() +
+               p.arow.size() + p.brow.size() + p.trow.size();
+    for (int r = 0; r < N_ROLES; ++r) n += p.uses[r].off.size() + 3 * p.uses[r].row.size();
+    return n * sizeof(int32_t);
+}
+
+int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
+    int dev = 0;
+    HIPOK(hipGetDevice(&dev));
+    if (plan->uploaded) {
+        if (dev != plan->device)
+            return fail(CLIORA_EINVAL, "plan tables live on device " + std::to_string(plan->device) + " but the current device is " +
+                                           std::to_string(dev) + " (call under the tensors' device)");
+        return CLIORA_OK;
+    }
+    std::vector<int32_t> flat = flatten_tables(plan->p);
+    HIPOK(hipMalloc((void**)&plan->p.d_tables, flat.size() * sizeof(int32_t)));
+    HIPOK(hipMemcpyAsync(plan->p.d_tables, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPOK(hipStreamSynchronize(st));   // `flat` dies at scope exit
+    plan->p.d_tables_count = flat.size();
+    plan->uploaded = true;
+    plan->device = dev;
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ hooks / CKY
+extern "C" int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_ws, int level, const float** scores, const float** h,
+                                         size_t* rows, size_t* ldh) {
+    if (!plan || !fwd_ws || !scores || !h || !rows || !ldh) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (level < 1 || level >= p.L) return fail(CLIORA_EINVAL, "level out of range");
+    const size_t r0 = (size_t)p.row_base_in(level);
+    *scores = (const float*)fwd_ws + p.fwd.sp + r0;
+    *h = (const float*)fwd_ws + p.fwd.y + r0 * p.Dp;
+    *rows = (size_t)p.B * (p.L - level) * level;
+    *ldh = (size_t)p.Dp;
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_ws, int level, const float** scores, const float** h,
+                                          size_t* rows, size_t* ldh) {
+    if (!plan || !fwd_ws || !scores || !h || !rows || !ldh) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (level < 0 || level > p.L - 2) return fail(CLIORA_EINVAL, "level out of range");
+    const size_t r0 = (size_t)p.row_base_out(level);
+    *scores = (const float*)fwd_ws + p.fwd.sp + r0;
+    *h = (const float*)fwd_ws + p.fwd.y + r0 * p.Dp;
+    *rows = (size_t)p.B * (p.L - level) * (p.L - level - 1);
+    *ldh = (size_t)p.Dp;
+    return CLIORA_OK;
+}
+
+// One wavefront per sentence.  val[] (chart of best scores) lives in LDS; leaves start at 1
+// (analysis/cky.py:24-25, 39).  Candidate = (val_l + val_r) + (s_n - max_n s) in fp32, in that
+// order (cky.py:83, utils.py:89-90); argmax keeps the first maximum (cky.py:86).
+__global__ __launch_bounds__(64) void cky_kernel(int L, int C, const int32_t* __restrict__ level_off_tab_a, const int32_t* __restrict__ pair_a,
+                                                 const int32_t* __restrict__ pair_b, const int32_t* __restrict__ lvl_base, int B,
+                                                 const float* __restrict__ Sp, int32_t* __restrict__ split) {
+    extern __shared__ float val[];
+    (void)level_off_tab_a;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int c = lane; c < C; c += 64) val[c] = 1.f;
+    for (int c = lane; c < L; c += 64) split[(size_t)b * C + c] = -1;
+    __syncthreads();
+    int off = L;   // cell id of (level 1, pos 0)
+    for (int level = 1; level < L; ++level) {
+        const int Lc = L - level, N = level;
+        for (int pos = 0; pos < Lc; ++pos) {
+            const int loc = lvl_base[level] + pos * N;
+            const size_t row0 = (size_t)B * lvl_base[level] + ((size_t)b * Lc + pos) * N;
+            const bool an = lane < N;
+            const float s = an ? Sp[row0 + lane] : -INFINITY;
+            const float smax = wave_max(s);
+            float cand = -INFINITY;
+            if (an) cand = (val[pair_a[loc + lane]] + val[pair_b[loc + lane]]) + (s - smax);
+            float best = cand; int bi = an ? lane : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            __syncthreads();
+            if (lane == 0) { val[off + pos] = best; split[(size_t)b * C + off + pos] = bi; }
+            __syncthreads();
+        }
+        off += Lc;
+    }
+}
+
+extern "C" int cliora_cky_decode(cliora_plan* plan, void* fwd_ws, int32_t* split_out, void* stream) {
+    if (!plan || !fwd_ws || !split_out) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "cky called before forward");
+    OKR(cliora_plan_ready(plan, (hipStream_t)stream));
+    Plan& p = plan->p;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cky_kernel, dim3(p.B), dim3(64), p.C * sizeof(float), st, p.L, p.C, (const int32_t*)nullptr,
+                       p.d_tables + p.dev.pair_a_in, p.d_tables + p.dev.pair_b_in, p.d_tables + p.dev.lvl_base_in, p.B,
+                       (const float*)fwd_ws + p.fwd.sp, split_out);
+    LAUNCHOK("cky_kernel");
+    return CLIORA_OK;
+}
+
+extern "C" const char* cliora_last_error(void) { return g_cliora_err.c_str(); }
+extern "C" int cliora_set_mfma_mode(int mode) {
+    const int prev = split_bf16() ? CLIORA_MFMA_SPLIT_BF16 : CLIORA_MFMA_F32;
+    g_cliora_split_bf16 = mode == CLIORA_MFMA_F32 ? 0 : 1;
+    return prev;
+}
+
+extern "C" const char* cliora_version(void) { return "cliora_amd 0.2 (gfx950)"; }

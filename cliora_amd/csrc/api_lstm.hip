@@ -1,0 +1,229 @@
+// C ABI, DioraTreeLSTM unit (parity unpinned, see lstm_kernels.hpp).
+#include "api_common.hpp"
+#include "lstm_kernels.hpp"
+
+// ------------------------------------------------------------------ DioraTreeLSTM (parity unpinned, see lstm_kernels.hpp)
+extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, float* inside_h, float* inside_c,
+                                   float* inside_s, float* outside_h, float* outside_c, float* outside_s, void* fwd_ws,
+                                   size_t fwd_ws_bytes, int run_outside, void* stream) {
+    if (!plan || !P || !x_span || !inside_h || !inside_c || !inside_s || !outside_h || !outside_c || !outside_s || !fwd_ws)
+        return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.arch != 1) return fail(CLIORA_EINVAL, "not a TreeLSTM plan (create it with cliora_plan_create_ex(..., arch = 1))");
+    if (!P->lstm_w || !P->lstm_u || !P->lstm_b || !P->in_mat || !P->root_h || !P->root_c) return fail(CLIORA_EINVAL, "missing TreeLSTM parameter");
+    if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    OKR(cliora_plan_ready(plan, st));
+    const Dev dv = dev_views(p);
+    float* ws = (float*)fwd_ws;
+    const FwdLayout& f = p.fwd;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, ldpi = 11 * Dp, ldpo = 5 * Dp;
+    const size_t DD = (size_t)Dp * Dp;
+    const bool padded = D != Dp;
+    float *IH = padded ? ws + f.ihp : inside_h, *OH = padded ? ws + f.ohp : outside_h;
+    float *IC = padded ? ws + f.icp : inside_c, *OC = padded ? ws + f.ocp : outside_c;
+    float *IS = inside_s, *OS = outside_s;
+    const float* X = padded ? ws + f.xp : x_span;
+    {
+        CopyTable t; t.n = 0;
+        for (int g = 0; g < 3; ++g) {
+            add_copy(t, ws + f.wl + g * DD, Dp, Dp, Dp, P->lstm_w, D, D, D, g * D, 0, 0);
+            add_copy(t, ws + f.wlT + g * Dp, 3 * Dp, Dp, Dp, P->lstm_w, D, D, D, g * D, 0, 1);
+            add_copy(t, ws + f.bl + g * Dp, Dp, 1, Dp, P->lstm_b, 5 * D, 1, D, 0, g * D, 0);
+        }
+        for (int g = 0; g < 5; ++g) {
+            add_copy(t, ws + f.wcat + g * DD, Dp, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, 0, 0);          // PL gate g: U[:, :D]
+            add_copy(t, ws + f.wcat + (5 + g) * DD, Dp, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 0);    // PR gate g: U[:, D:]
+            add_copy(t, ws + f.bcat + g * Dp, Dp, 1, Dp, P->lstm_b, 5 * D, 1, D, 0, g * D, 0);
+        }
+        add_copy(t, ws + f.wcat + 10 * DD, Dp, Dp, Dp, P->in_mat, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.bcat + 5 * Dp, Dp, 1, 6 * Dp, nullptr, 0, 0, 0, 0, 0, 0);
+        add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
+        add_copy(t, ws + f.rootc, Dp, 1, Dp, P->root_c, D, 1, D, 0, 0, 0);
+        if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+        CopyTable u; u.n = 0;
+        for (int g = 0; g < 5; ++g) {
+            add_copy(u, ws + f.wcatT + g * Dp, ldpi, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, 0, 1);
+            add_copy(u, ws + f.wcatT + (5 + g) * Dp, ldpi, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 1);
+            add_copy(u, ws + f.w1ro + g * DD, Dp, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 0);
+            add_copy(u, ws + f.w1roT + g * Dp, ldpo, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 1);
+        }
+        add_copy(u, ws + f.wcatT + 10 * Dp, ldpi, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
+        OKR(run_copies(st, u));
+        {
+            ImageList pj;
+            pj.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
+            pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+            pj.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
+            OKR(build_frag_images(st, pj));
+        }
+    }
+    // leaves
+    OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, 3 * Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, 3 * Dp, ws + f.bl, 0, 3 * Dp}));
+    hipLaunchKernelGGL(lstm_leaf_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, ws + f.t, p.normalize, IH, IC, ws + f.nrmi,
+                       ws + f.nrmic, IS);
+    LAUNCHOK("lstm_leaf_fwd");
+    if (L > 1)
+        OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
+    for (int level = 1; level < L; ++level) {
+        const LevelArgs g = level_args(p, level, false);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, IH, IS, IS,
+                           ws + f.sp, ws + f.pp, IS);
+        LAUNCHOK("pair_scores_fwd");
+        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
+                           ws + f.pi + 5 * Dp, ldpi, IC, IC, 1.0f, ws + f.y, ws + f.x);
+        LAUNCHOK("lstm_pair_fwd");
+        hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, IH, IC,
+                           ws + f.nrmi, ws + f.nrmic);
+        LAUNCHOK("lstm_aggregate_fwd");
+        if (level < L - 1)
+            OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+                                   StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
+    }
+    if (run_outside) {
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH, ws + f.nrmo, OS);
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootc, 0, B, 1, C, C - 1, Dp, p.normalize, OC, ws + f.nrmoc, OS);
+        LAUNCHOK("unit_norm_rows(root)");
+        if (L > 1)
+            OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
+        for (int level = L - 2; level >= 0; --level) {
+            const LevelArgs g = level_args(p, level, true);
+            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, OH, IS, OS,
+                               ws + f.sp, ws + f.pp, OS);
+            LAUNCHOK("pair_scores_fwd(out)");
+            hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
+                               ws + f.po, ldpo, IC, OC, 0.0f, ws + f.y, ws + f.x);
+            LAUNCHOK("lstm_pair_fwd(out)");
+            hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, OH, OC,
+                               ws + f.nrmo, ws + f.nrmoc);
+            LAUNCHOK("lstm_aggregate_fwd(out)");
+            if (level >= 1)
+                OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                                       StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));
+        }
+    } else {
+        HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(OC, 0, (size_t)B * C * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
+    }
+    if (padded) {
+        CopyTable t; t.n = 0;
+        add_copy(t, inside_h, D, B * C, D, IH, Dp, B * C, D, 0, 0, 0);
+        add_copy(t, outside_h, D, B * C, D, OH, Dp, B * C, D, 0, 0, 0);
+        add_copy(t, inside_c, D, B * C, D, IC, Dp, B * C, D, 0, 0, 0);
+        add_copy(t, outside_c, D, B * C, D, OC, Dp, B * C, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* inside_h,
+                                    const float* inside_c, const float* inside_s, const float* outside_h, const float* outside_c,
+                                    const float* outside_s, const float* d_ih, const float* d_ic, const float* d_is, const float* d_oh,
+                                    const float* d_oc, const float* d_os, void* fwd_ws, size_t fwd_ws_bytes, void* bwd_ws,
+                                    size_t bwd_ws_bytes, float* d_x_span, const cliora_params* G, int ran_outside, void* stream) {
+    (void)P;
+    if (!plan || !x_span || !inside_h || !inside_c || !inside_s || !outside_h || !outside_c || !outside_s || !fwd_ws || !bwd_ws || !G)
+        return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.arch != 1) return fail(CLIORA_EINVAL, "not a TreeLSTM plan");
+    if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    if (bwd_ws_bytes < p.bwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "backward workspace too small");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "backward called before forward");
+    hipStream_t st = (hipStream_t)stream;
+    OKR(cliora_plan_ready(plan, st));
+    const Dev dv = dev_views(p);
+    float* ws = (float*)fwd_ws;
+    float* wb = (float*)bwd_ws;
+    const FwdLayout& f = p.fwd;
+    const BwdLayout& bw = p.bwd;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, ldpi = 11 * Dp, ldpo = 5 * Dp;
+    const size_t DD = (size_t)Dp * Dp;
+    const bool padded = D != Dp;
+    const float *IH = padded ? ws + f.ihp : inside_h, *OH = padded ? ws + f.ohp : outside_h;
+    const float *IC = padded ? ws + f.icp : inside_c, *OC = padded ? ws + f.ocp : outside_c;
+    const float *IS = inside_s, *OS = outside_s;
+    const float* X = padded ? ws + f.xp : x_span;
+    float *VH = wb + bw.vh, *VC = wb + bw.vc, *dG = wb + bw.dg, *dGc = wb + bw.dgc, *dStot = wb + bw.dstot;
+    float *DA = wb + bw.da, *DCA = wb + bw.dz, *DCB = wb + bw.dcb, *DS = wb + bw.ds, *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
+    const float *Y = ws + f.y, *Xc = ws + f.x, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po;
+
+    if (ran_outside) {
+        for (int level = 0; level <= L - 1; ++level) {
+            const LevelArgs g = level_args(p, level, true);
+            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            hipLaunchKernelGGL(lstm_gather_bwd_out, dim3(ncell, (7 * Dp / 4 + 255) / 256), dim3(256), 0, st, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os,
+                               dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VH, VC, dStot);
+            LAUNCHOK("lstm_gather_bwd_out");
+            if (level >= 1)
+                OKR(launch_rows_direct(st, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
+                                       StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+            if (level == L - 1) {
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VC, OC, ws + f.nrmoc, p.normalize, wb + bw.grootc);
+                LAUNCHOK("root_bwd");
+                break;
+            }
+            hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, VC, OH, OC, ws + f.nrmo, ws + f.nrmoc, p.normalize, Y, Xc,
+                               Sp, Pp, OS, dStot, dG, dGc, DS);
+            LAUNCHOK("lstm_scores_bwd(out)");
+            hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
+                               PO, ldpo, IC, OC, 0.0f, Xc, Pp, dG, dGc, DA, DCA, DCB);
+            LAUNCHOK("lstm_pair_bwd(out)");
+        }
+        OKR(launch_tn(st, B * C, ldpo, Dp, Dp, PlainRowsA{dPO, ldpo}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+                      (float*)nullptr));
+    } else {
+        HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, 5 * DD * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.grootc, 0, (size_t)Dp * sizeof(float), st));
+    }
+    for (int level = L - 1; level >= 0; --level) {
+        const LevelArgs g = level_args(p, level, false);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(lstm_gather_bwd_in, dim3(ncell, (13 * Dp / 4 + 255) / 256), dim3(256), 0, st, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA],
+                           dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
+        LAUNCHOK("lstm_gather_bwd_in");
+        if (level <= L - 2)
+            OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                                   StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (level == 0) break;
+        hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic, p.normalize, Y, Xc, Sp,
+                           Pp, IS, dStot, dG, dGc, DS);
+        LAUNCHOK("lstm_scores_bwd(in)");
+        hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
+                           PI + 5 * Dp, ldpi, IC, IC, 1.0f, Xc, Pp, dG, dGc, DA, DCA, DCB);
+        LAUNCHOK("lstm_pair_bwd(in)");
+    }
+    hipLaunchKernelGGL(lstm_leaf_bwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic,
+                       p.normalize, ws + f.t, dU);
+    LAUNCHOK("lstm_leaf_bwd");
+    if (d_x_span)
+        OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), 3 * Dp, Dp, B * L, PlainRowsA{dU, 3 * Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+    OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
+    OKR(launch_tn(st, B * L, 3 * Dp, Dp, Dp, PlainRowsA{dU, 3 * Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
+    {
+        CopyTable t; t.n = 0;
+        for (int g = 0; g < 5; ++g) {
+            if (G->lstm_u) {
+                add_copy(t, G->lstm_u + (size_t)g * D * 2 * D, 2 * D, D, D, wb + bw.gwcat + g * DD, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->lstm_u + (size_t)g * D * 2 * D + D, 2 * D, D, D, wb + bw.gwcat + (5 + g) * DD, Dp, D, D, 0, 0, 0,
+                         wb + bw.gw1ro + g * DD, Dp, D, D, 0, 0, 0);
+            }
+            if (G->lstm_b) {
+                if (g < 3) add_copy(t, G->lstm_b + g * D, D, 1, D, wb + bw.gbcat + g * Dp, Dp, 1, D, 0, 0, 0, wb + bw.gbl + g * Dp, Dp, 1, D, 0, 0, 0);
+                else add_copy(t, G->lstm_b + g * D, D, 1, D, wb + bw.gbcat + g * Dp, Dp, 1, D, 0, 0, 0);
+            }
+        }
+        for (int g = 0; g < 3; ++g)
+            if (G->lstm_w) add_copy(t, G->lstm_w + (size_t)g * D * D, D, D, D, wb + bw.gwl + g * DD, Dp, D, D, 0, 0, 0);
+        if (G->in_mat) add_copy(t, G->in_mat, D, D, D, wb + bw.gwcat + 10 * DD, Dp, D, D, 0, 0, 1);
+        if (G->root_h) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
+        if (G->root_c) add_copy(t, G->root_c, D, 1, D, wb + bw.grootc, Dp, 1, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}

@@ -1,0 +1,332 @@
+// C ABI, DioraMLP / CLIORA chart unit: forward / backward sequencing of the level kernels.
+// See include/cliora_chart.h for the contract and the reference lines it replaces.
+#include "api_common.hpp"
+#include "vl_kernels.hpp"
+
+// ------------------------------------------------------------------ forward
+extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
+                                    const float* drop_mask, float* inside_h, float* inside_s, float* outside_h,
+                                    float* outside_s, float* inside_c, void* fwd_ws, size_t fwd_ws_bytes, int run_outside,
+                                    void* stream) {
+    if (!plan || !P || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws)
+        return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    const bool vl = p.R > 0;
+    if (p.arch != 0) return fail(CLIORA_EINVAL, "TreeLSTM plan: use cliora_lstm_forward");
+    if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
+    if (!vl && obj_span) return fail(CLIORA_EINVAL, "obj_span given to a text-only plan (R = 0)");
+    if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    OKR(cliora_plan_ready(plan, st));
+    const Dev dv = dev_views(p);
+    float* ws = (float*)fwd_ws;
+    const FwdLayout& f = p.fwd;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, nb = p.nblk, ldpi = nb * Dp;
+    const bool padded = D != Dp;
+    float* IH = padded ? ws + f.ihp : inside_h;
+    float* OH = padded ? ws + f.ohp : outside_h;
+    float* IS = inside_s;
+    float* OS = outside_s;
+    const float* X = padded ? ws + f.xp : x_span;
+    const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
+    const float* w1o = p.share ? P->in_w1 : P->out_w1;
+    if (!p.share && (!P->out_w1 || !P->out_b1 || !P->out_w2 || !P->out_b2 || !P->out_mat))
+        return fail(CLIORA_EINVAL, "share=0 needs the out_* parameters");
+
+    // ---- pack parameters into padded / concatenated / transposed layouts ----
+    {
+        CopyTable t; t.n = 0;
+        add_copy(t, ws + f.wl, Dp, Dp, Dp, P->leaf_w, D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.wlT, Dp, Dp, Dp, P->leaf_w, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.bl, Dp, 1, Dp, P->leaf_b, D, 1, D, 0, 0, 0);
+        // Wcat rows: [W1L_in ; W1R_in ; mat_in^T ; (W1L_out ; mat_out^T)]
+        add_copy(t, ws + f.wcat + 0 * (size_t)Dp * Dp, Dp, Dp, Dp, P->in_w1, 2 * D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.wcat + 1 * (size_t)Dp * Dp, Dp, Dp, Dp, P->in_w1, 2 * D, D, D, 0, D, 0);
+        add_copy(t, ws + f.wcat + 2 * (size_t)Dp * Dp, Dp, Dp, Dp, P->in_mat, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.wcatT + 0 * Dp, ldpi, Dp, Dp, P->in_w1, 2 * D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.wcatT + 1 * Dp, ldpi, Dp, Dp, P->in_w1, 2 * D, D, D, 0, D, 1);
+        add_copy(t, ws + f.wcatT + 2 * Dp, ldpi, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.bcat, Dp, 1, Dp, P->in_b1, D, 1, D, 0, 0, 0);
+        add_copy(t, ws + f.bcat + Dp, Dp, 1, 2 * Dp, nullptr, 0, 0, 0, 0, 0, 0);
+        if (!p.share) {
+            add_copy(t, ws + f.wcat + 3 * (size_t)Dp * Dp, Dp, Dp, Dp, P->out_w1, 2 * D, D, D, 0, 0, 0);
+            add_copy(t, ws + f.wcat + 4 * (size_t)Dp * Dp, Dp, Dp, Dp, P->out_mat, D, D, D, 0, 0, 1);
+            add_copy(t, ws + f.wcatT + 3 * Dp, ldpi, Dp, Dp, P->out_w1, 2 * D, D, D, 0, 0, 1);
+            add_copy(t, ws + f.wcatT + 4 * Dp, ldpi, Dp, Dp, P->out_mat, D, D, D, 0, 0, 0);
+            add_copy(t, ws + f.bcat + 3 * Dp, Dp, 1, Dp, P->out_b1, D, 1, D, 0, 0, 0);
+            add_copy(t, ws + f.bcat + 4 * Dp, Dp, 1, Dp, nullptr, 0, 0, 0, 0, 0, 0);
+            add_copy(t, ws + f.w2o, Dp, Dp, Dp, P->out_w2, D, D, D, 0, 0, 0);
+            add_copy(t, ws + f.w2oT, Dp, Dp, Dp, P->out_w2, D, D, D, 0, 0, 1);
+            add_copy(t, ws + f.b2o, Dp, 1, Dp, P->out_b2, D, 1, D, 0, 0, 0);
+        }
+        add_copy(t, ws + f.w1ro, Dp, Dp, Dp, w1o, 2 * D, D, D, 0, D, 0);
+        add_copy(t, ws + f.w1roT, Dp, Dp, Dp, w1o, 2 * D, D, D, 0, D, 1);
+        add_copy(t, ws + f.w2i, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 0);
+        add_copy(t, ws + f.w2iT, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 1);
+        add_copy(t, ws + f.b2i, Dp, 1, Dp, P->in_b2, D, 1, D, 0, 0, 0);
+        add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
+        if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
+        if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+        {   // built in either arithmetic mode (one small launch): the backward call may run under the other one
+            ImageList im;
+            im.add(ws + f.w2i, ws + f.w2i3, Dp, Dp, Dp); im.add(ws + f.w2iT, ws + f.w2iT3, Dp, Dp, Dp);
+            if (!p.share) { im.add(ws + f.w2o, ws + f.w2o3, Dp, Dp, Dp); im.add(ws + f.w2oT, ws + f.w2oT3, Dp, Dp, Dp); }
+            ImageList pj;
+            pj.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
+            pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+            pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
+            OKR(build_weight_images(st, im));
+            OKR(build_frag_images(st, pj));
+        }
+    }
+
+    // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
+    OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
+        LevelArgs g0 = level_args(p, 0, false);
+        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, PairScoreArgs{}, (const float*)nullptr, (const float*)nullptr,
+                           ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
+                           inside_c, D, IS);
+        LAUNCHOK("cell_attend_fwd(leaves)");
+    } else {
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, ws + f.t, Dp, B * L, L, C, 0, Dp, p.normalize,
+                           IH, ws + f.nrmi, IS);
+        LAUNCHOK("unit_norm_rows");
+    }
+    if (L > 1)
+        OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
+                        StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
+
+    // ---- inside pass (diora.py:295-331) ----
+    for (int level = 1; level < L; ++level) {
+        const LevelArgs g = level_args(p, level, false);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+            OKR(launch_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, nrows,
+                            ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi, ws + f.x, Dp},
+                            StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
+        }
+        if (vl) {   // cliora.py:140-157: aggregate, attention residual, second unit norm
+            // split scores + softmax + aggregate + attention in one launch
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L,
+                               PairScoreArgs{dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS, ws + f.sp, ws + f.pp, IS},
+                               ws + f.y, ws + f.pp, (const float*)nullptr,
+                               OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
+                               (float*)nullptr, D, IS);
+            LAUNCHOK("cell_attend_fwd");
+        } else {
+            hipLaunchKernelGGL(cell_scores_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
+                               IH, IS, IS, ws + f.sp, ws + f.pp, IS, ws + f.y, p.normalize, IH, ws + f.nrmi);
+            LAUNCHOK("cell_scores_aggregate_fwd");
+        }
+        if (level < L - 1)
+            OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+                            StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
+    }
+
+    // ---- outside pass (diora.py:337-398) ----
+    if (run_outside) {
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH,
+                           ws + f.nrmo, OS);
+        LAUNCHOK("unit_norm_rows(root)");
+        if (L > 1)
+            OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+        for (int level = L - 2; level >= 0; --level) {
+            const LevelArgs g = level_args(p, level, true);
+            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            {
+                ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+                OKR(launch_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, nrows,
+                                ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.x, Dp},
+                                StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
+            }
+            hipLaunchKernelGGL(cell_scores_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow,
+                               ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS, ws + f.sp, ws + f.pp, OS, ws + f.y, p.normalize, OH,
+                               ws + f.nrmo);
+            LAUNCHOK("cell_scores_aggregate_fwd(out)");
+            if (level >= 1)
+                OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                                StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
+        }
+    } else {
+        HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
+    }
+    if (padded) {
+        CopyTable t; t.n = 0;
+        add_copy(t, inside_h, D, B * C, D, IH, Dp, B * C, D, 0, 0, 0);
+        add_copy(t, outside_h, D, B * C, D, OH, Dp, B * C, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}
+
+// ------------------------------------------------------------------ backward
+extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
+                                     const float* drop_mask, const float* inside_h, const float* inside_s,
+                                     const float* outside_h, const float* outside_s, const float* d_inside_h,
+                                     const float* d_inside_s, const float* d_outside_h, const float* d_outside_s,
+                                     void* fwd_ws, size_t fwd_ws_bytes, void* bwd_ws, size_t bwd_ws_bytes, float* d_x_span,
+                                     float* d_obj_span, const cliora_params* G, int ran_outside, void* stream) {
+    (void)P;
+    if (!plan || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws || !bwd_ws || !G)
+        return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    const bool vl = p.R > 0;
+    if (p.arch != 0) return fail(CLIORA_EINVAL, "TreeLSTM plan: use cliora_lstm_backward");
+    if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
+    if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    if (bwd_ws_bytes < p.bwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "backward workspace too small");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "backward called before forward");
+    hipStream_t st = (hipStream_t)stream;
+    OKR(cliora_plan_ready(plan, st));
+    const Dev dv = dev_views(p);
+    float* ws = (float*)fwd_ws;
+    float* wb = (float*)bwd_ws;
+    const FwdLayout& f = p.fwd;
+    const BwdLayout& bw = p.bwd;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, nb = p.nblk, ldpi = nb * Dp;
+    const bool padded = D != Dp;
+    const float* IH = padded ? ws + f.ihp : inside_h;
+    const float* OH = padded ? ws + f.ohp : outside_h;
+    const float* IS = inside_s;
+    const float* OS = outside_s;
+    const float* X = padded ? ws + f.xp : x_span;
+    float *VH = wb + bw.vh, *dG = wb + bw.dg, *dStot = wb + bw.dstot, *DA = wb + bw.da, *DS = wb + bw.ds;
+    float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
+    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *Xp = ws + f.x;
+    float* DZ = wb + bw.dz;
+    const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
+    // CLIORA: the unit-norm / softmax backward of the inside cells works on u = unit(aggregate), not on h
+    const float* IHn = vl ? ws + f.att_u : IH;
+    const float* nrmIn = vl ? ws + f.att_nrmu : ws + f.nrmi;
+
+    if (ran_outside) {
+        for (int level = 0; level <= L - 1; ++level) {
+            const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
+            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            hipLaunchKernelGGL(cell_gather_bwd_out, dim3(ncell), dim3(256), 0, st, g, D, d_outside_h,
+                               level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
+            LAUNCHOK("cell_gather_bwd_out");
+            if (level >= 1)
+                OKR(launch_rows_direct(st, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                                StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+            if (level == L - 1) {
+                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+                LAUNCHOK("root_bwd");
+                break;
+            }
+            hipLaunchKernelGGL(cell_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, Y, Sp, Pp,
+                               OS, dStot, dG, DS);
+            LAUNCHOK("cell_scores_bwd(out)");
+            {
+                ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
+                OKR(launch_compose(st, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+                                ComposeBwdE{Xp, DA, g.rowbase, Dp}));
+            }
+        }
+        if (!p.share) {
+            ProfScope ps(CLIORA_KCLASS_WGRAD, st);
+            OKR(launch_tn_pairs(st, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
+                                wb + bw.gw2o, wb + bw.gb2o));
+        }
+        OKR(launch_tn(st, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+                      (float*)nullptr));
+    } else {
+        HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
+    }
+
+    for (int level = L - 1; level >= 0; --level) {
+        const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, st, g, D, d_inside_h,
+                           level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside,
+                           DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
+        LAUNCHOK("cell_gather_bwd_in");
+        if (level <= L - 2)
+            OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                            StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (vl) {
+            hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
+                               drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
+            LAUNCHOK("cell_attend_bwd");
+        }
+        if (level == 0) break;
+        hipLaunchKernelGGL(cell_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, Y, Sp, Pp, IS,
+                           dStot, dG, DS);
+        LAUNCHOK("cell_scores_bwd(in)");
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
+            OKR(launch_compose(st, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
+                            ComposeBwdE{Xp, DA, g.rowbase, Dp}));
+        }
+    }
+    // leaves
+    hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
+    LAUNCHOK("leaf_bwd_pre");
+    if (d_x_span)
+        OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+    {
+        // shared weights: inside and outside pair rows are one contiguous range -> one launch
+        ProfScope ps(CLIORA_KCLASS_WGRAD, st);
+        const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
+        OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+        if (p.share) {
+            HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
+            HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
+        }
+    }
+    OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat,
+                  wb + bw.gbcat));
+    OKR(launch_tn(st, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
+
+    if (vl && d_obj_span) {
+        float* dO = padded ? wb + bw.dobjp : d_obj_span;
+        hipLaunchKernelGGL(obj_grad_reduce, dim3(B, (p.R + 3) / 4), dim3(256), 0, st, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo,
+                           wb + bw.dsc, dO);
+        LAUNCHOK("obj_grad_reduce");
+    }
+    // ---- scatter packed gradients back to the reference parameter shapes ----
+    {
+        CopyTable t; t.n = 0;
+        const size_t DD = (size_t)Dp * Dp;
+        if (vl && d_obj_span && padded) add_copy(t, d_obj_span, D, B * p.R, D, wb + bw.dobjp, Dp, B * p.R, D, 0, 0, 0);
+        if (G->leaf_w) add_copy(t, G->leaf_w, D, D, D, wb + bw.gwl, Dp, D, D, 0, 0, 0);
+        if (G->leaf_b) add_copy(t, G->leaf_b, D, 1, D, wb + bw.gbl, Dp, 1, D, 0, 0, 0);
+        if (G->root_h) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
+        if (p.share) {
+            if (G->in_w1) {
+                add_copy(t, G->in_w1, 2 * D, D, D, wb + bw.gwcat, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->in_w1 + D, 2 * D, D, D, wb + bw.gwcat + DD, Dp, D, D, 0, 0, 0, wb + bw.gw1ro, Dp, D, D, 0, 0, 0);
+            }
+            if (G->in_b1) add_copy(t, G->in_b1, D, 1, D, wb + bw.gbcat, Dp, 1, D, 0, 0, 0);
+            if (G->in_mat) add_copy(t, G->in_mat, D, D, D, wb + bw.gwcat + 2 * DD, Dp, D, D, 0, 0, 1);
+            if (G->in_w2) add_copy(t, G->in_w2, D, D, D, wb + bw.gw2i, Dp, D, D, 0, 0, 0, wb + bw.gw2o, Dp, D, D, 0, 0, 0);
+            if (G->in_b2) add_copy(t, G->in_b2, D, 1, D, wb + bw.gb2i, Dp, 1, D, 0, 0, 0, wb + bw.gb2o, Dp, 1, D, 0, 0, 0);
+        } else {
+            if (G->in_w1) {
+                add_copy(t, G->in_w1, 2 * D, D, D, wb + bw.gwcat, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->in_w1 + D, 2 * D, D, D, wb + bw.gwcat + DD, Dp, D, D, 0, 0, 0);
+            }
+            if (G->in_b1) add_copy(t, G->in_b1, D, 1, D, wb + bw.gbcat, Dp, 1, D, 0, 0, 0);
+            if (G->in_mat) add_copy(t, G->in_mat, D, D, D, wb + bw.gwcat + 2 * DD, Dp, D, D, 0, 0, 1);
+            if (G->in_w2) add_copy(t, G->in_w2, D, D, D, wb + bw.gw2i, Dp, D, D, 0, 0, 0);
+            if (G->in_b2) add_copy(t, G->in_b2, D, 1, D, wb + bw.gb2i, Dp, 1, D, 0, 0, 0);
+            if (G->out_w1) {
+                add_copy(t, G->out_w1, 2 * D, D, D, wb + bw.gwcat + 3 * DD, Dp, D, D, 0, 0, 0);
+                add_copy(t, G->out_w1 + D, 2 * D, D, D, wb + bw.gw1ro, Dp, D, D, 0, 0, 0);
+            }
+            if (G->out_b1) add_copy(t, G->out_b1, D, 1, D, wb + bw.gbcat + 3 * Dp, Dp, 1, D, 0, 0, 0);
+            if (G->out_mat) add_copy(t, G->out_mat, D, D, D, wb + bw.gwcat + 4 * DD, Dp, D, D, 0, 0, 1);
+            if (G->out_w2) add_copy(t, G->out_w2, D, D, D, wb + bw.gw2o, Dp, D, D, 0, 0, 0);
+            if (G->out_b2) add_copy(t, G->out_b2, D, 1, D, wb + bw.gb2o, Dp, 1, D, 0, 0, 0);
+        }
+        OKR(run_copies(st, t));
+    }
+    return CLIORA_OK;
+}

@@ -44,7 +44,7 @@ struct CopyDesc { float* dst; int ldd, drows, dcols; CopySrc s[2]; };
 constexpr int MAX_COPY = 32;
 struct CopyTable { CopyDesc d[MAX_COPY]; int n; };
 
-__global__ void copy2d_multi(CopyTable tab) {
+static __global__ void copy2d_multi(CopyTable tab) {
     const CopyDesc& d = tab.d[blockIdx.y];
     const long long total = (long long)d.drows * d.dcols;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -67,7 +67,7 @@ __global__ void copy2d_multi(CopyTable tab) {
 // src row = (b*rows_per_b + p) * src_ld (src_ld = 0 broadcasts one row: the root vector, diora.py:337-356)
 // also writes the raw norm and zeroes the cell's score.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void unit_norm_rows(const float* __restrict__ src, int src_ld, int nrows, int rows_per_b,
+static __global__ __launch_bounds__(256) void unit_norm_rows(const float* __restrict__ src, int src_ld, int nrows, int rows_per_b,
                                                       int C, int off, int Dp, int normalize,
                                                       float* __restrict__ H, float* __restrict__ nrm, float* __restrict__ S) {
     const int lane = threadIdx.x & 63;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void unit_norm_rows(const float* __restrict__ 
 // Per-split scores and their softmax for one level (diora.py:125-134 / 177-185):
 //   s_n = QL(a_n) . H(b_n) + S(a_n) + S(b_n);  p = softmax_n(s);  S(target) = sum_n p_n s_n
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+static __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
                                                        const float* __restrict__ QA, int ldA, const float* __restrict__ HB,
                                                        const float* SA, const float* SB,
                                                        float* __restrict__ Sp, float* __restrict__ Pp, float* Sout) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const int32_
 // Softmax-weighted sum of the per-split compose outputs + unit norm (diora.py:137-149):
 //   g = sum_n p_n y_n;  H(target) = g / max(||g||, eps)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ Pp,
+static __global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ Pp,
                                                           int normalize, float* __restrict__ H, float* __restrict__ nrm) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const flo
 //            order (fixed summation order), then the unit norm              (diora.py:145-149)
 // The wave's first y rows are fetched before phase 1: they do not depend on the scores.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_scores_aggregate_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+static __global__ __launch_bounds__(256) void cell_scores_aggregate_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
                                                                  const float* __restrict__ QA, int ldA, const float* __restrict__ HB,
                                                                  const float* SA, const float* SB,
                                                                  float* __restrict__ Sp, float* __restrict__ Pp, float* Sout,
@@ -341,7 +341,7 @@ __device__ __forceinline__ void wg_sum_pairs(float4 (*sh)[GATHER_SLOTS][64], int
     }
 }
 
-__global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
+static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
                                                           UseTab ina, UseTab inb, UseTab outa, int with_outside,
                                                           const float* __restrict__ DA, const float* __restrict__ DS,
                                                           const float* __restrict__ PI, int ldpi, int share,
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, co
 
 //   outside cell c (as parent in the outside pass):
 //     dPRo = sum DA[row];  vH = dH_ext + sum ds[row] * QLo(sibling);  vS = dS_ext + sum ds[row]
-__global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
+static __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
                                                            UseTab outb, const float* __restrict__ DA, const float* __restrict__ DS,
                                                            const float* __restrict__ PI, int ldpi, int blk_qlo,
                                                            float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ dStot) {
@@ -463,7 +463,7 @@ __device__ __forceinline__ void unit_norm_bwd(float4& v0, float4& v1, float4 h0,
 // softmax / score backward:   dp_n = dG . y_n
 //   ds_n = p_n [ (dp_n - sum_m p_m dp_m) + dS_tot (1 + s_n - S) ]
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ H,
+static __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ H,
                                                        const float* __restrict__ nrm, int normalize,
                                                        const float* __restrict__ Y, const float* __restrict__ Sp, const float* __restrict__ Pp,
                                                        const float* __restrict__ Schart, const float* __restrict__ dStot,
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float*
 }
 
 // leaves: H = unit(T), T = tanh(U)  (diora.py:58-63, 283-292):  dU = normbwd(vH) * (1 - T^2)
-__global__ __launch_bounds__(256) void leaf_bwd_pre(int B, int L, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
+static __global__ __launch_bounds__(256) void leaf_bwd_pre(int B, int L, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
                                                     const float* __restrict__ nrm, int normalize, const float* __restrict__ T,
                                                     float* __restrict__ dU) {
     const int lane = threadIdx.x & 63;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void leaf_bwd_pre(int B, int L, int C, int Dp,
 // owns columns lane, lane+64, ...; the row dot product is a wave reduction), the 16 partial vectors meet in LDS and are
 // added in wave order -- a fixed summation order, so the result is bitwise reproducible.
 constexpr int ROOT_WAVES = 16;
-__global__ __launch_bounds__(ROOT_WAVES * 64) void root_bwd(int B, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
+static __global__ __launch_bounds__(ROOT_WAVES * 64) void root_bwd(int B, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
                                                             const float* __restrict__ nrm, int normalize, float* __restrict__ groot) {
     __shared__ float part[ROOT_WAVES][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

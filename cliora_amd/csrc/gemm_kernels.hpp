@@ -42,6 +42,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Lane maps of a 16-row operand tile.  The MFMA wants lane l to hold row (l & 15), k-piece (l >> 4) -- but gfx950 coalesces
+// the addresses of CONSECUTIVE lanes, so a gather issued in that map is 64 separate 16-byte requests per instruction and runs at
+// about half the rate of the same bytes fetched with four consecutive lanes on 64 contiguous bytes of one row
+// (tools/ubench/gather_bench3.hip on MI355X: 9.1 -> 4.5 us for a 1 216-row level, 34.9 -> 23.1 us for 24 320 rows).
+// So operand rows are FETCHED in the quad-coalesced map (lane l: row l >> 2, piece l & 3), run through the producer's ALU
+// part there, and moved to the MFMA lanes with one ds_bpermute per dword (LDS crossbar, no LDS memory).
+__device__ __forceinline__ int fetch_row_of(int lane) { return lane >> 2; }
+__device__ __forceinline__ int fetch_piece_of(int lane) { return lane & 3; }
+__device__ __forceinline__ int mfma_src_addr(int lane) { return 4 * (4 * (lane & 15) + (lane >> 4)); }   // byte address of the source lane
+__device__ __forceinline__ float4 to_mfma_lanes(int src_addr, float4 v) {
+    float4 r;
+    r.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_addr, __builtin_bit_cast(int, v.x)));
+    r.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_addr, __builtin_bit_cast(int, v.y)));
+    r.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_addr, __builtin_bit_cast(int, v.z)));
+    r.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_addr, __builtin_bit_cast(int, v.w)));
+    return r;
+}
+
 constexpr int WS_THREADS = 256;   // tn_gemm workgroup size
 constexpr int WS_LDS_PAD = 0;   // the LDS image is the plain row-major block (written by LDS-DMA, lane-linear)
 
@@ -61,7 +79,7 @@ constexpr int WS_LDS_PAD = 0;   // the LDS image is the plain row-major block (w
 //   so the epilogue is one 16-byte access per lane per 16x16 tile.
 // ---------------------------------------------------------------------------------
 template <int CT, int SC, int WAVES, class AProd, class Epi>
-__global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restrict__ W, int ldw, int Kseg, int nseg, int nrows,
+static __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restrict__ W, int ldw, int Kseg, int nseg, int nrows,
                                                            AProd ap, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_w[];
     constexpr int T = WAVES * 64;
@@ -69,6 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
     const int col0 = blockIdx.y * (CT * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
+    const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);   // fetch-side lane map
     const int ntiles = (nrows + 15) >> 4;
     const float* bbase = lds_w + i * ldb + 4 * q;
     using Raw = typename AProd::Raw;
@@ -100,12 +119,12 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
         int tile = blockIdx.x * WAVES + wave;
         if (tile >= ntiles) return;
         const int nstages = Kseg / (16 * SC);
-        auto rowof = [&](int t) { const int r = t * 16 + i; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
+        auto rowof = [&](int t) { const int r = t * 16 + li; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
         auto ctx = ap.row(rowof(tile));
         auto ctxn = ctx;
         Raw cur[SC], nxt[SC];
 #pragma unroll
-        for (int j = 0; j < SC; ++j) cur[j] = ap.fetch(ctx, 16 * j + 4 * q);
+        for (int j = 0; j < SC; ++j) cur[j] = ap.fetch(ctx, 16 * j + 4 * lq);
         while (true) {
             const int ntile = tile + stride;
             const bool has_next = ntile < ntiles;
@@ -116,19 +135,20 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
                 const int ks = stg * 16 * SC;
                 if (stg + 1 < nstages) {
 #pragma unroll
-                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctx, ks + 16 * (SC + j) + 4 * q);
+                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctx, ks + 16 * (SC + j) + 4 * lq);
                     if (has_next && (stg + 2 == nstages || nstages == 1)) ctxn = ap.row(rowof(ntile));
                 } else if (has_next) {
                     if (nstages == 1) ctxn = ap.row(rowof(ntile));
 #pragma unroll
-                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctxn, 16 * j + 4 * q);
+                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctxn, 16 * j + 4 * lq);
                 }
 #pragma unroll
                 for (int j = 0; j < SC; ++j) {
-                    const float4 a = ap.finish(ctx, cur[j]);
+                    const float4 af = ap.finish(ctx, cur[j]);
                     // optional side output of the A fragment (materialises x / dz for the weight-gradient
                     // GEMM): each column block writes its 1/gridDim.y share of the k-chunks
-                    if (AProd::kSide && ((ks >> 4) + j) % (int)gridDim.y == (int)blockIdx.y) ap.side(ctx, ks + 16 * j + 4 * q, a);
+                    if (AProd::kSide && ((ks >> 4) + j) % (int)gridDim.y == (int)blockIdx.y) ap.side(ctx, ks + 16 * j + 4 * lq, af);
+                    const float4 a = to_mfma_lanes(psrc, af);
                     float4 b[CT];
 #pragma unroll
                     for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(bbase + c * 16 * ldb + ks + 16 * j);
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
     for (int tile0 = blockIdx.x * WAVES; tile0 < ntiles; tile0 += gridDim.x * WAVES) {
         const int tile = tile0 + wave;
         const bool active = tile < ntiles;       // inactive waves still take part in the barriers
-        int row = tile * 16 + i;
+        int row = tile * 16 + li;
         if (row >= nrows) row = nrows - 1;       // clamp: computed, never stored
         const auto ctx = ap.row(row);
         f32x4 acc[CT];
@@ -174,19 +194,20 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws(const float* __restri
             const int kbase = seg * Kseg;
             Raw cur[SC], nxt[SC];
 #pragma unroll
-            for (int j = 0; j < SC; ++j) cur[j] = ap.fetch(ctx, kbase + 16 * j + 4 * q);
+            for (int j = 0; j < SC; ++j) cur[j] = ap.fetch(ctx, kbase + 16 * j + 4 * lq);
             for (int ks = 0; ks < Kseg; ks += 16 * SC) {
                 const bool more = ks + 16 * SC < Kseg;
                 if (more) {
 #pragma unroll
-                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctx, kbase + ks + 16 * (SC + j) + 4 * q);
+                    for (int j = 0; j < SC; ++j) nxt[j] = ap.fetch(ctx, kbase + ks + 16 * (SC + j) + 4 * lq);
                 }
 #pragma unroll
                 for (int j = 0; j < SC; ++j) {
-                    const float4 a = ap.finish(ctx, cur[j]);
+                    const float4 af = ap.finish(ctx, cur[j]);
                     // optional side output of the A fragment (materialises x / dz for the weight-gradient
                     // GEMM): each column block writes its 1/gridDim.y share of the k-chunks
-                    if (AProd::kSide && ((ks >> 4) + j) % (int)gridDim.y == (int)blockIdx.y) ap.side(ctx, kbase + ks + 16 * j + 4 * q, a);
+                    if (AProd::kSide && ((ks >> 4) + j) % (int)gridDim.y == (int)blockIdx.y) ap.side(ctx, kbase + ks + 16 * j + 4 * lq, af);
+                    const float4 a = to_mfma_lanes(psrc, af);
                     float4 b[CT];
 #pragma unroll
                     for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(bbase + c * 16 * ldb + ks + 16 * j);
@@ -259,7 +280,7 @@ __device__ __forceinline__ void split_bf16x8(const float4 a, const float4 b, u32
 constexpr int MAX_IMAGES = 12;
 struct SplitImageTab { const float* src[MAX_IMAGES]; uint32_t* dst[MAX_IMAGES]; int nrows[MAX_IMAGES], ldw[MAX_IMAGES], K[MAX_IMAGES]; };
 // grid = (ceil(max S / 256), max nrows, nmat); image m: row stride S = roundup32(K[m]) + WS3_PAD dwords
-__global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
+static __global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
     const int m = blockIdx.z;
     const int K = tab.K[m], Kp = (K + 31) / 32 * 32, S = Kp + WS3_PAD;
     if ((int)blockIdx.y >= tab.nrows[m]) return;
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
 
 // fp32 fragment image for rows_gemm_ksplit<.., FRAG = true>: float4 index ((ct * K/16 + ch) * 64 + lane) holds
 // W[ct*16 + (lane & 15)][ch*16 + 4*(lane >> 4) .. +3].  Same table as split_weight_image; grid = (ceil(max nrows*K/4 / 256), 1, nmat).
-__global__ __launch_bounds__(256) void frag_weight_image(SplitImageTab tab) {
+static __global__ __launch_bounds__(256) void frag_weight_image(SplitImageTab tab) {
     const int m = blockIdx.z;
     const int K = tab.K[m], nch = K >> 4;
     const size_t n4 = (size_t)tab.nrows[m] * K / 4;
@@ -320,7 +341,7 @@ __device__ __forceinline__ T pick_pod(bool c, const T& a, const T& b) {
 }
 
 template <int CT, int WAVES, int PD, int K16, class AProd, class Epi>
-__global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __restrict__ Wimg, int S_, int K_, int nrows, AProd ap, Epi epi) {
+static __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __restrict__ Wimg, int S_, int K_, int nrows, AProd ap, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
     constexpr int T = WAVES * 64;
     // K16 > 0: the reduction length K = 16*K16 is a compile-time constant -- the k-step loop unrolls completely and every
@@ -332,6 +353,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
     const int S = KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
+    const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);   // fetch-side lane map
     const int Kp = S - WS3_PAD, half = Kp >> 1;
     const int col0 = blockIdx.y * (CT * 16);
     {
@@ -356,15 +378,15 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
     int wfrag_off = i * S + 4 * g;
     const int gy = gridDim.y, by = blockIdx.y;
     using Raw = typename AProd::Raw;
-    auto rowof = [&](int t) { const int r = t * 16 + i; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
-    // A lane's k at step s: 32s + 4g .. +3 and 32s + 16 + 4g .. +3 (the image's permutation).  K is a multiple of 16, so
+    auto rowof = [&](int t) { const int r = t * 16 + li; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
+    // A lane's k at step s: 32s + 4g .. +3 and 32s + 16 + 4g .. +3 (the image's permutation; g = the lane's k-piece).  K is a multiple of 16, so
     // the first run is always inside the row and the second is inside for every lane or for none; when it is not, the
     // first run is fetched twice and the duplicate is discarded.  EVERY ring slot issues exactly two fetches per turn,
     // whatever the step: the loads then stand in a fixed order, the waits before a step count the loads issued after its
     // own (vmcnt is in order) and never drain the ring -- a fetch behind a branch forces a full drain at the join.
     Raw ra[PD][2];
     auto issue = [&](int slot, const decltype(ap.row(0))& c, int s) {
-        const int k = 32 * s + 4 * g;
+        const int k = 32 * s + 4 * lg;
         ra[slot][0] = ap.fetch(c, k);
         ra[slot][1] = ap.fetch(c, k + (32 * s + 16 < K ? 16 : 0));
     };
@@ -390,16 +412,17 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
                 const int st = base + sl;
                 if (st < nsteps) {
                     const bool second = 32 * st + 16 < K;
-                    const float4 a0 = ap.finish(ctx, ra[sl][0]);
+                    const float4 f0 = ap.finish(ctx, ra[sl][0]);
                     // beyond K this is a second copy of the first run: finite, and its weights in the image are zero
-                    const float4 a1 = ap.finish(ctx, ra[sl][1]);
+                    const float4 f1 = ap.finish(ctx, ra[sl][1]);
                     // optional side output of the fp32 row fragment (x / dz for the weight-gradient GEMM)
                     if (AProd::kSide && side_turn == by) {
-                        const int k = 32 * st + 4 * g;
-                        ap.side(ctx, k, a0);
-                        if (second) ap.side(ctx, k + 16, a1);
+                        const int k = 32 * st + 4 * lg;
+                        ap.side(ctx, k, f0);
+                        if (second) ap.side(ctx, k + 16, f1);
                     }
                     side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
+                    const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
                     u32x4 xh, xl;
                     split_bf16x8(a0, a1, xh, xl);
                     u32x4 wh[CT], wl[CT];
@@ -449,12 +472,13 @@ __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __re
 // launches are bound by how fast ONE CU can pull its block's operands through its texture-address path).
 // ---------------------------------------------------------------------------------
 template <int RT, int CT, bool FRAG, class AProd, class Epi>
-__global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int nrg, int nrgp, int ncolblocks, int nrows,
+static __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int nrg, int nrgp, int ncolblocks, int nrows,
                                                         AProd ap, Epi epi) {
     __shared__ float4 part[4][RT * CT][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
+    const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);   // fetch-side lane map
     const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;   // row group fastest: see the launcher (XCD L2 reuse)
     if (rg >= nrg) return;
     const int col0 = cb * (CT * 16);
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
     using Ctx = decltype(ap.row(0));
     Ctx ctx[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((tile0 + r) * 16 + i, nrows - 1));
+    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((tile0 + r) * 16 + li, nrows - 1));
     const float* wrow = W + (size_t)(col0 + i) * K + 4 * q;
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
     auto load = [&](int slot, int ch) {
         const int k = 16 * (ch0 + ch);
 #pragma unroll
-        for (int r = 0; r < RT; ++r) ra[slot][r] = ap.fetch(ctx[r], k + 4 * q);
+        for (int r = 0; r < RT; ++r) ra[slot][r] = ap.fetch(ctx[r], k + 4 * lq);
 #pragma unroll
         for (int c = 0; c < CT; ++c)
             rw[slot][c] = FRAG ? reinterpret_cast<const float4*>(W)[((size_t)(cb * CT + c) * nchunks + ch0 + ch) * 64 + lane]
@@ -501,8 +525,10 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
                 for (int r = 0; r < RT; ++r) a[r] = ap.finish(ctx[r], ra[sl][r]);
                 if (AProd::kSide && (ch0 + base + sl) % ncolblocks == cb) {     // side output, shared out over the column blocks
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) ap.side(ctx[r], 16 * (ch0 + base + sl) + 4 * q, a[r]);
+                    for (int r = 0; r < RT; ++r) ap.side(ctx[r], 16 * (ch0 + base + sl) + 4 * lq, a[r]);
                 }
+#pragma unroll
+                for (int r = 0; r < RT; ++r) a[r] = to_mfma_lanes(psrc, a[r]);
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -547,12 +573,13 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict_
 // reloads unconditionally (clamped to the wave's last step) so the waits stay counted.
 // ---------------------------------------------------------------------------------
 template <int RT, int CT, class AProd, class Epi>
-__global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restrict__ Wimg, int S, int K, int nrg, int nrgp, int ncolblocks,
+static __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restrict__ Wimg, int S, int K, int nrg, int nrgp, int ncolblocks,
                                                          int nrows, AProd ap, Epi epi) {
     __shared__ float4 part[4][RT * CT][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
+    const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);   // fetch-side lane map
     const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;   // row group fastest: see the launcher (XCD L2 reuse)
     if (rg >= nrg) return;
     const int col0 = cb * (CT * 16);
@@ -566,7 +593,7 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restr
     using Ctx = decltype(ap.row(0));
     Ctx ctx[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((tile0 + r) * 16 + i, nrows - 1));
+    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((tile0 + r) * 16 + li, nrows - 1));
     const uint32_t* wrow = Wimg + (size_t)(col0 + i) * S + 4 * g;
     f32x4 acc[RT][CT];
 #pragma unroll
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restr
     Raw ra[PD][RT][2];
     u32x4 wh[PD][CT], wl[PD][CT];
     auto load = [&](int slot, int s) {             // s: absolute k-step
-        const int k = 32 * s + 4 * g;
+        const int k = 32 * s + 4 * lg;
         const int k2 = k + (32 * s + 16 < K ? 16 : 0);
 #pragma unroll
         for (int r = 0; r < RT; ++r) { ra[slot][r][0] = ap.fetch(ctx[r], k); ra[slot][r][1] = ap.fetch(ctx[r], k2); }
@@ -600,12 +627,12 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restr
                     u32x4 xh[RT], xl[RT];
 #pragma unroll
                     for (int r = 0; r < RT; ++r) {
-                        const float4 a0 = ap.finish(ctx[r], ra[sl][r][0]), a1 = ap.finish(ctx[r], ra[sl][r][1]);
+                        const float4 f0 = ap.finish(ctx[r], ra[sl][r][0]), f1 = ap.finish(ctx[r], ra[sl][r][1]);
                         if (AProd::kSide && s % ncolblocks == cb) {     // side output, shared out over the column blocks
-                            ap.side(ctx[r], 32 * s + 4 * g, a0);
-                            if (second) ap.side(ctx[r], 32 * s + 16 + 4 * g, a1);
+                            ap.side(ctx[r], 32 * s + 4 * lg, f0);
+                            if (second) ap.side(ctx[r], 32 * s + 16 + 4 * lg, f1);
                         }
-                        split_bf16x8(a0, a1, xh[r], xl[r]);
+                        split_bf16x8(to_mfma_lanes(psrc, f0), to_mfma_lanes(psrc, f1), xh[r], xl[r]);
                     }
 #pragma unroll
                     for (int r = 0; r < RT; ++r)
@@ -648,7 +675,7 @@ __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restr
 //   slab  : [nslices][Mi][Nj];  colsum (optional, COLSUM): [nslices][Mi] = sum_r A(r,i)
 // ---------------------------------------------------------------------------------
 template <int TI, int TJ, bool COLSUM, class AProd, class BProd>
-__global__ __launch_bounds__(WS_THREADS) void tn_gemm(int nrows, int rows_per_slice, int Mi, int Nj,
+static __global__ __launch_bounds__(WS_THREADS) void tn_gemm(int nrows, int rows_per_slice, int Mi, int Nj,
                                                       AProd ap, BProd bp,
                                                       float* __restrict__ slab, float* __restrict__ colsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -727,7 +754,7 @@ constexpr int TN_RS = 16;       // pair rows per stage (4 MFMA k-steps)
 constexpr int TN_NP = 12;       // LDS-DMA pieces per wave per stage, upper bound: (Mi/16 + NJT + 3) / 4
 
 template <int NIT, int NJT, bool COLSUM>
-__global__ __launch_bounds__(256) void tn_gemm_dma(const float* __restrict__ A, const float* __restrict__ B, int nrows,
+static __global__ __launch_bounds__(256) void tn_gemm_dma(const float* __restrict__ A, const float* __restrict__ B, int nrows,
                                                    int rows_per_slice, int Mi, int Nj, int nkb,
                                                    float* __restrict__ slab, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) float lds_t[];
@@ -873,7 +900,7 @@ __global__ __launch_bounds__(256) void tn_gemm_dma(const float* __restrict__ A, 
 constexpr int TN3_RS = 32;
 constexpr int TN3_NP = 20;      // LDS-DMA pieces per wave per stage, upper bound: (Mi + NJT*16) / 32
 template <int NIT, int NJT, bool COLSUM>
-__global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A, const float* __restrict__ B, int nrows,
+static __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A, const float* __restrict__ B, int nrows,
                                                     int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
                                                     float* __restrict__ slab, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) float lds_t[];
@@ -1059,7 +1086,7 @@ __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restrict__ A,
 }
 
 // out[e] = sum_s slab[s][e], fixed order.
-__global__ void slab_reduce(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out) {
+static __global__ void slab_reduce(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     float v = 0.f;

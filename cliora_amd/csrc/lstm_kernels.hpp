@@ -26,7 +26,7 @@ __device__ __forceinline__ float4 f4dsig(float4 g) { return make_float4(g.x * (1
 __device__ __forceinline__ float4 f4dtanh(float4 t) { return make_float4(1.f - t.x * t.x, 1.f - t.y * t.y, 1.f - t.z * t.z, 1.f - t.w * t.w); }
 
 // ---- leaves: ACT = x W^T + B[:3D] (3 blocks of Dp per row) -> h, c -> unit norm of both
-__global__ __launch_bounds__(256) void lstm_leaf_fwd(int B, int L, int C, int Dp, const float* __restrict__ ACT, int normalize,
+static __global__ __launch_bounds__(256) void lstm_leaf_fwd(int B, int L, int C, int Dp, const float* __restrict__ ACT, int normalize,
                                                      float* __restrict__ H, float* __restrict__ Cc, float* __restrict__ nrmH,
                                                      float* __restrict__ nrmC, float* __restrict__ S) {
     const int lane = threadIdx.x & 63;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void lstm_leaf_fwd(int B, int L, int C, int Dp
 }
 
 // ---- one span pair per wave: gates from PL(a) + PR(b), child cell states, -> Y = h, X = c
-__global__ __launch_bounds__(256) void lstm_pair_fwd(int rowbase, int nrows, int Dp, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+static __global__ __launch_bounds__(256) void lstm_pair_fwd(int rowbase, int nrows, int Dp, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
                                                      const float* __restrict__ PA, int ldA, const float* __restrict__ PB, int ldB,
                                                      const float* __restrict__ CA, const float* __restrict__ CB, float kf,
                                                      float* __restrict__ Y, float* __restrict__ X) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void lstm_pair_fwd(int rowbase, int nrows, int
 }
 
 // ---- softmax-weighted sums of h and c over the splits + unit norm of both (one workgroup per cell)
-__global__ __launch_bounds__(256) void lstm_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ X,
+static __global__ __launch_bounds__(256) void lstm_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ X,
                                                           const float* __restrict__ Pp, int normalize, float* __restrict__ H,
                                                           float* __restrict__ Cc, float* __restrict__ nrmH, float* __restrict__ nrmC) {
     // waves 0,1 aggregate h (columns split lane / lane+64 as elsewhere), waves 2,3 do the same for c
@@ -175,7 +175,7 @@ __device__ __forceinline__ float sum_ds(const UseTab& ut, int c, int b, const fl
     return acc;
 }
 
-__global__ __launch_bounds__(256) void lstm_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
+static __global__ __launch_bounds__(256) void lstm_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
                                                           const float* __restrict__ dS_ext, UseTab ina, UseTab inb, UseTab outa, int with_outside,
                                                           const float* __restrict__ DA, const float* __restrict__ DCA, const float* __restrict__ DCB,
                                                           const float* __restrict__ DS, const float* __restrict__ PI, int ldpi,
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void lstm_gather_bwd_in(LevelArgs g, int D, co
     }
 }
 
-__global__ __launch_bounds__(256) void lstm_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
+static __global__ __launch_bounds__(256) void lstm_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
                                                            const float* __restrict__ dS_ext, UseTab outb, const float* __restrict__ DA,
                                                            const float* __restrict__ DCB, const float* __restrict__ DS,
                                                            const float* __restrict__ PI, int ldpi, float* __restrict__ dPO,
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void lstm_gather_bwd_out(LevelArgs g, int D, c
 
 // ---- backward, unit-norm of both vectors + softmax/score backward (one workgroup per cell)
 //   dp_n = dGh . y_n + dGc . x_n
-__global__ __launch_bounds__(256) void lstm_scores_bwd(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ VC,
+static __global__ __launch_bounds__(256) void lstm_scores_bwd(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ VC,
                                                        const float* __restrict__ H, const float* __restrict__ Cc,
                                                        const float* __restrict__ nrmH, const float* __restrict__ nrmC, int normalize,
                                                        const float* __restrict__ Y, const float* __restrict__ X,
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void lstm_scores_bwd(LevelArgs g, const float*
 
 // ---- backward of one span pair (one wave per pair row): gates recomputed from PL(a) + PR(b)
 //   dh = p dGh(target), dc_in = p dGc(target);  out: DA (5 gate pre-activation grads), DCA = dc f0, DCB = dc f1
-__global__ __launch_bounds__(256) void lstm_pair_bwd(int rowbase, int nrows, int Dp, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+static __global__ __launch_bounds__(256) void lstm_pair_bwd(int rowbase, int nrows, int Dp, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
                                                      const int32_t* __restrict__ trow, const float* __restrict__ PA, int ldA,
                                                      const float* __restrict__ PB, int ldB, const float* __restrict__ CA,
                                                      const float* __restrict__ CB, float kf, const float* __restrict__ X,
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void lstm_pair_bwd(int rowbase, int nrows, int
 }
 
 // ---- leaves backward: unit-norm of h and c, then the leaf gates -> dACT (3 blocks)
-__global__ __launch_bounds__(256) void lstm_leaf_bwd(int B, int L, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ VC,
+static __global__ __launch_bounds__(256) void lstm_leaf_bwd(int B, int L, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ VC,
                                                      const float* __restrict__ H, const float* __restrict__ Cc,
                                                      const float* __restrict__ nrmH, const float* __restrict__ nrmC, int normalize,
                                                      const float* __restrict__ ACT, float* __restrict__ dACT) {

@@ -33,7 +33,7 @@ struct PairScoreArgs {
     float *Sp, *Pp, *Sout;
 };
 
-__global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, PairScoreArgs sc, const float* __restrict__ Y, const float* __restrict__ Pp,
+static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, PairScoreArgs sc, const float* __restrict__ Y, const float* __restrict__ Pp,
                                                        const float* __restrict__ T, const float* __restrict__ OBJ, int R,
                                                        const float* __restrict__ mask, int normalize,
                                                        float* __restrict__ H, float* __restrict__ nrmV, float* __restrict__ U,
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, PairS
 // which are handed U / |g| instead of H / |v|), DCTX = dv, and per region PMo = p*mask, DSC = dsc
 // for the per-sentence reduction of d obj (obj_grad_reduce).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __restrict__ VH, const float* __restrict__ H,
+static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __restrict__ VH, const float* __restrict__ H,
                                                        const float* __restrict__ nrmV, int normalize, const float* __restrict__ OBJ,
                                                        int R, const float* __restrict__ mask, const float* __restrict__ PK,
                                                        float* __restrict__ DCTX, float* __restrict__ PMo, float* __restrict__ DSC) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __res
 
 // d obj[b][k][:] = sum over the inside cells of sentence b of  pm[cell][k] * dctx[cell][:] + dsc[cell][k] * u[cell][:]
 // One workgroup per (sentence, 4 regions): wave w owns region 4*blockIdx.y + w; cells in chart order.
-__global__ __launch_bounds__(256) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
+static __global__ __launch_bounds__(256) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
                                                        const float* __restrict__ PMo, const float* __restrict__ DSC,
                                                        float* __restrict__ dOBJ) {
     const int lane = threadIdx.x & 63;
@@ -391,7 +391,7 @@ struct ScoreGrad2A {
 };
 
 // out[r][:D] = unit-norm backward of V[r] through Hn[r] = X[r] / max(|X[r]|, eps)
-__global__ __launch_bounds__(256) void rows_unit_bwd(int nrows, int Dp, int D, const float* __restrict__ V, const float* __restrict__ Hn,
+static __global__ __launch_bounds__(256) void rows_unit_bwd(int nrows, int Dp, int D, const float* __restrict__ V, const float* __restrict__ Hn,
                                                      const float* __restrict__ nrm, int normalize, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);

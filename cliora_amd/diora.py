@@ -33,123 +33,62 @@ def _param_struct(tensors):
     return st
 
 
-_side_streams = {}
-
-
-def _streams(device, n):
-    """n-1 side streams (cached per device) next to the current stream."""
-    key = (device.index, n)
-    if key not in _side_streams:
-        _side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n - 1)]
-    return _side_streams[key]
-
-
-def default_chunks(B):
-    """Sentences are independent through the whole recursion, and a single level of a 64-sentence
-    chart cannot fill 256 CUs (39 dependent levels, a few hundred to a few thousand rows each).
-    Splitting the batch into sub-batches that run on separate HIP streams lets the level kernels
-    of one sub-batch fill the gaps of the other.  CLIORA_CHART_CHUNKS overrides."""
-    import os
-    env = os.environ.get('CLIORA_CHART_CHUNKS')
-    if env:
-        return max(1, min(int(env), B))
-    return 1      # measured on MI355X (r01): 2 sub-batches 8.7 ms/step vs 8.2 ms single-stream at B=64 -- host launch bound
-
-
 class ChartFunction(torch.autograd.Function):
     """One autograd node for the whole inside-outside chart.
 
     forward  -> cliora_chart_forward   (replaces diora.py:283-398 as executed by DioraBase.forward)
     backward -> cliora_chart_backward  (replaces what autograd replays through those lines)
-    Inputs: plan (for one sub-batch), number of sub-batches, holder (list that receives the forward
-    workspaces), run_outside, x_span, then the parameter tensors in _lib.PARAM_FIELDS order (None
-    for the out_* set when the weights are shared).
+    Inputs: plan, holder (list that receives the forward workspace), run_outside, x_span, then the parameter
+    tensors in _lib.PARAM_FIELDS order (None for the out_* set when the weights are shared).
+    Every C-ABI call runs under the tensors' device (the plan's index tables and the kernels' LDS attribute are per device).
     """
 
     @staticmethod
-    def forward(ctx, plan, nchunks, holder, run_outside, x_span, *params):
+    def forward(ctx, plan, holder, run_outside, x_span, *params):
         if not x_span.is_cuda:
             raise _lib.ChartLibError('the chart path runs on the GPU only (got a CPU tensor)')
-        Bc, L, D, Cc = plan.B, plan.L, plan.D, plan.C
-        B = Bc * nchunks
+        B, L, D, Cc = plan.B, plan.L, plan.D, plan.C
         x_span = x_span.contiguous().float()
         ptens = {n: (p.detach().contiguous() if p is not None else None) for n, p in zip(_lib.PARAM_FIELDS, params)}
         dev = x_span.device
-        inside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
-        inside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
-        outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
-        outside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
-        wss = [torch.empty(plan.fwd_bytes, device=dev, dtype=torch.uint8) for _ in range(nchunks)]
-        pst = _param_struct(ptens)
-        main = torch.cuda.current_stream(dev)
-        streams = [main] + _streams(dev, nchunks)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for c in range(nchunks):
-            st = streams[c]
-            if c:
-                st.wait_event(ready)
-            lo = c * Bc
+        with torch.cuda.device(dev):
+            inside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
+            inside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
+            outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
+            outside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
+            ws = torch.empty(plan.fwd_bytes, device=dev, dtype=torch.uint8)
+            pst = _param_struct(ptens)
             rc = _lib.lib().cliora_chart_forward(
-                plan.handle, C.byref(pst), _ptr(x_span[lo:]), None, None, _ptr(inside_h[lo:]), _ptr(inside_s[lo:]),
-                _ptr(outside_h[lo:]), _ptr(outside_s[lo:]), None, _ptr(wss[c]), plan.fwd_bytes, int(run_outside),
-                C.c_void_p(st.cuda_stream))
+                plan.handle, C.byref(pst), _ptr(x_span), None, None, _ptr(inside_h), _ptr(inside_s),
+                _ptr(outside_h), _ptr(outside_s), None, _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
             _lib.check(rc, 'cliora_chart_forward')
-        for c in range(1, nchunks):
-            ev = torch.cuda.Event()
-            ev.record(streams[c])
-            main.wait_event(ev)
-        ctx.plan, ctx.nchunks, ctx.run_outside, ctx.wss, ctx.ptens = plan, nchunks, int(run_outside), wss, ptens
+        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside), ws, ptens
         ctx.save_for_backward(x_span, inside_h, inside_s, outside_h, outside_s)
         ctx.set_materialize_grads(False)
         holder.clear()
-        holder.extend(wss)
+        holder.append(ws)
         return inside_h, inside_s, outside_h, outside_s
 
     @staticmethod
     def backward(ctx, d_ih, d_is, d_oh, d_os):
-        plan, nchunks = ctx.plan, ctx.nchunks
-        Bc = plan.B
+        plan = ctx.plan
         x_span, inside_h, inside_s, outside_h, outside_s = ctx.saved_tensors
         dev = x_span.device
         cont = lambda g: g.contiguous().float() if g is not None else None
         d_ih, d_is, d_oh, d_os = cont(d_ih), cont(d_is), cont(d_oh), cont(d_os)
-        sl = lambda t, lo: _ptr(t[lo:]) if t is not None else None
-        d_x = torch.empty_like(x_span)
-        grads = []
-        pst = _param_struct(ctx.ptens)
-        main = torch.cuda.current_stream(dev)
-        streams = [main] + _streams(dev, nchunks)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        keep = []
-        for c in range(nchunks):
-            st = streams[c]
-            if c:
-                st.wait_event(ready)
-            lo = c * Bc
+        with torch.cuda.device(dev):
+            d_x = torch.empty_like(x_span)
+            pst = _param_struct(ctx.ptens)
             g = {n: (torch.empty_like(t) if t is not None else None) for n, t in ctx.ptens.items()}
             wsb = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)
             gst = _param_struct(g)
             rc = _lib.lib().cliora_chart_backward(
-                plan.handle, C.byref(pst), _ptr(x_span[lo:]), None, None, _ptr(inside_h[lo:]), _ptr(inside_s[lo:]),
-                _ptr(outside_h[lo:]), _ptr(outside_s[lo:]), sl(d_ih, lo), sl(d_is, lo), sl(d_oh, lo), sl(d_os, lo),
-                _ptr(ctx.wss[c]), plan.fwd_bytes, _ptr(wsb), plan.bwd_bytes, _ptr(d_x[lo:]), None, C.byref(gst),
-                ctx.run_outside, C.c_void_p(st.cuda_stream))
+                plan.handle, C.byref(pst), _ptr(x_span), None, None, _ptr(inside_h), _ptr(inside_s),
+                _ptr(outside_h), _ptr(outside_s), _ptr(d_ih), _ptr(d_is), _ptr(d_oh), _ptr(d_os),
+                _ptr(ctx.ws), plan.fwd_bytes, _ptr(wsb), plan.bwd_bytes, _ptr(d_x), None, C.byref(gst),
+                ctx.run_outside, _stream())
             _lib.check(rc, 'cliora_chart_backward')
-            grads.append(g)
-            keep.append(wsb)
-        for c in range(1, nchunks):
-            ev = torch.cuda.Event()
-            ev.record(streams[c])
-            main.wait_event(ev)
-        total = grads[0]
-        for g in grads[1:]:                      # sub-batch gradients add up (fixed order)
-            for n, t in g.items():
-                if t is not None:
-                    total[n] = total[n] + t
-        del keep                                  # scratch is released only after `main` waits on every side stream
-        return (None, None, None, None, d_x) + tuple(total[n] for n in _lib.PARAM_FIELDS)
+        return (None, None, None, d_x) + tuple(g[n] for n in _lib.PARAM_FIELDS)
 
 
 # --------------------------------------------------------------------------------------
@@ -193,7 +132,6 @@ class DioraBase(nn.Module):
         self.ninput = 2
         self.index = None
         self.charts = None
-        self.chunks = None      # sub-batches run on separate HIP streams; None = default_chunks(B)
         self.init_parameters()
         self.reset_parameters()
         self.reset()
@@ -255,7 +193,6 @@ class DioraBase(nn.Module):
         self.vg_atten_score = None
         self._wss = None
         self._plan = None
-        self._nchunks = 1
 
     def _hook_overridden(self, name):
         return name in self.__dict__ or getattr(type(self), name) is not getattr(DioraBase, name)
@@ -280,19 +217,16 @@ class DioraBase(nn.Module):
         B, L, D = x_span.shape
         assert D == self.size
         dev_index = x_span.device.index if x_span.is_cuda else -1
-        nchunks = self.chunks if self.chunks else default_chunks(B)
-        if B % nchunks:
-            nchunks = 1
-        plan = _lib.get_plan(B // nchunks, L, D, self.share, self.normalize, 0, dev_index)
+        plan = _lib.get_plan(B, L, D, self.share, self.normalize, 0, dev_index)
         holder = []
-        ih, is_, oh, os_ = ChartFunction.apply(plan, nchunks, holder, bool(self.outside), x_span, *self._param_tensors())
+        ih, is_, oh, os_ = ChartFunction.apply(plan, holder, bool(self.outside), x_span, *self._param_tensors())
         ch = Chart()
         ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s = ih, is_, oh, os_
         # DioraMLP's cell state is identically zero (diora.py:60-61, 70)
         ch.inside_c = torch.zeros_like(ih)
         ch.outside_c = torch.zeros_like(oh)
         self.chart = ch
-        self._wss, self._plan, self._nchunks = holder, plan, nchunks
+        self._wss, self._plan = holder, plan
         self.init_with_batch(ih[:, :L], ch.inside_c[:, :L])
         self._serve_hooks(L)
         return None
@@ -360,8 +294,9 @@ class DioraBase(nn.Module):
         plan = self._plan
         parts = []
         for ws in self._wss:
-            split = torch.empty((plan.B, plan.C), device=ws.device, dtype=torch.int32)
-            _lib.check(_lib.lib().cliora_cky_decode(plan.handle, _ptr(ws), _ptr(split), _stream()), 'cliora_cky_decode')
+            with torch.cuda.device(ws.device):
+                split = torch.empty((plan.B, plan.C), device=ws.device, dtype=torch.int32)
+                _lib.check(_lib.lib().cliora_cky_decode(plan.handle, _ptr(ws), _ptr(split), _stream()), 'cliora_cky_decode')
             parts.append(split)
         sp = torch.cat(parts, 0).cpu().numpy()
         off = self.index.get_offset(plan.L)

@@ -37,6 +37,7 @@ class LSTMChartFunction(torch.autograd.Function):
     NAMES = ('lstm_w', 'lstm_u', 'lstm_b', 'in_mat', 'root_h', 'root_c')
 
     @staticmethod
+    @_lib.on_device(lambda ctx, plan, holder, run_outside, x_span, *a: x_span)
     def forward(ctx, plan, holder, run_outside, x_span, *params):
         if not x_span.is_cuda:
             raise _lib.ChartLibError('the chart path runs on the GPU only (got a CPU tensor)')
@@ -59,6 +60,7 @@ class LSTMChartFunction(torch.autograd.Function):
         return ih, ic, is_, oh, oc, os_
 
     @staticmethod
+    @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
     def backward(ctx, *cots):
         plan = ctx.plan
         x_span, ih, ic, is_, oh, oc, os_ = ctx.saved_tensors
@@ -103,7 +105,7 @@ class DioraTreeLSTM(DioraBase):
         ch = Chart()
         ch.inside_h, ch.inside_c, ch.inside_s, ch.outside_h, ch.outside_c, ch.outside_s = ih, ic, is_, oh, oc, os_
         self.chart = ch
-        self._wss, self._plan, self._nchunks = holder, plan, 1
+        self._wss, self._plan = holder, plan
         self.init_with_batch(ih[:, :L], ic[:, :L])
         if self._hook_overridden('outside_hook'):
             # the TreeLSTM pair rows keep (h, c) of the outside splits in this library's own order only
