@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLIORA_CHART_LIB') or os.path.join(HERE, 'libcliora_chart.so')   # override: kernel experiments only
 
 NORM = {'none': 0, 'unit': 1}
+FWD_NO_BACKWARD = 2      # include/cliora_chart.h: flag bit of cliora_chart_forward's run_outside word
 KCLASS = {'compose_fwd': 0, 'compose_bwd': 1, 'wgrad': 2}
 
 PARAM_FIELDS = ('leaf_w', 'leaf_b', 'in_w1', 'in_b1', 'in_w2', 'in_b2', 'in_mat',

@@ -1,7 +1,104 @@
 // C ABI, DioraMLP / CLIORA chart unit: forward / backward sequencing of the level kernels.
 // See include/cliora_chart.h for the contract and the reference lines it replaces.
 #include "api_common.hpp"
+#include "level_kernels.hpp"
 #include "vl_kernels.hpp"
+
+// ------------------------------------------------------------------ fused level kernels (level_kernels.hpp)
+struct ComposeGeom { int TG, SP, ntask, gx; };
+// Tasks of level_compose_fwd: TG cell tiles per workgroup (8 / TG waves each), the split range cut in SP parts.
+static ComposeGeom compose_geom(int ncell, int N, int ncb) {
+    const int G = (ncell + 15) / 16;
+    const int cap = std::max(1, 256 / ncb);                       // one workgroup per CU (the weight block fills LDS)
+    // Measured on MI355X (round 2, rocprof per-level traces): a round of tasks costs a ~5.8 us latency chain (index loads, ring
+    // fill, epilogue, reduction) plus ~2.8 us of MFMA / VALU / LDS issue per tile on the busiest SIMD (waves w and w+4 share
+    // one); rounds do not overlap.  Pick the cheapest geometry, fewer parts on a tie.
+    ComposeGeom best{1, 1, G, 1};
+    double best_t = 1e30;
+    for (int TG : {1, 2, 4, 8}) {
+        const int wpg = 8 / TG;
+        const int groups = (G + TG - 1) / TG;
+        for (int SP = 1; SP <= HP_PARTS && SP <= std::max(1, N); SP *= 2) {
+            const int np = (N + SP - 1) / SP;
+            const int ntask = groups * SP;
+            const int rounds = (ntask + cap - 1) / cap;
+            const int depth = (np + wpg - 1) / wpg;
+            const int busy = TG * std::min(wpg, np);
+            int simd = depth * (busy > 4 ? 2 : 1);
+            if (busy > 4 && wpg == 8 && np % 8 != 0 && np % 8 <= 4) simd -= 1;     // the last sweep reaches one wave of each pair only
+            const double t = rounds * (5.8 + 2.8 * simd) + 0.3 * (SP - 1);
+            if (t < best_t - 1e-9) { best_t = t; best = ComposeGeom{TG, SP, ntask, std::min(ntask, cap)}; }
+        }
+    }
+    ComposeGeom q = best;
+    // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8 the column blocks
+    // that gather the same operand rows share one XCD's L2 (speed only, never correctness)
+    if (q.gx >= 8 && (q.gx + 7) / 8 * 8 <= cap) q.gx = (q.gx + 7) / 8 * 8;
+    return q;
+}
+
+template <int CT, int K16, bool SIDE>
+static int launch_level_compose_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* PA, int lda,
+                                     const float* PB, int ldb, const float* bias, const float* Pp, float* HP, size_t hp_stride, int Dp,
+                                     uint32_t* ymask, float* Y, float* X, int* SP_out) {
+    const size_t lds = (size_t)CT * 16 * S * sizeof(uint32_t) + (size_t)LC_SLOTS * CT * 64 * sizeof(float4);
+    OKR(cliora_ensure_max_lds((const void*)level_compose_fwd<CT, K16, SIDE>));
+    const ComposeGeom q = compose_geom(lv.ncell, lv.N, ncb);
+    hipLaunchKernelGGL((level_compose_fwd<CT, K16, SIDE>), dim3(q.gx, ncb), dim3(512), lds, st, Wimg, S, K, lv, PA, lda, PB, ldb, bias, Pp,
+                       q.TG, q.SP, q.ntask, HP, hp_stride, Dp, ymask, Y, X);
+    LAUNCHOK("level_compose_fwd");
+    *SP_out = q.SP;
+    return CLIORA_OK;
+}
+
+// y = relu(W2 relu(PL(a) + PR(b)) + b2) for every pair of the level and g = sum_n p_n y_n per cell, into HP (SP parts)
+static int launch_level_compose(hipStream_t st, const float* Wimg, int S, int Dp, int ct, int ncb, const PairLevel& lv, const float* PA, int lda,
+                                const float* PB, int ldb, const float* bias, const float* Pp, float* HP, size_t hp_stride,
+                                uint32_t* ymask, float* Y, float* X, int* SP_out) {
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(Wimg);
+#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, X, SP_out
+#define LC_CASE(c, k16) return X ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
+    if (ct == 5 && Dp == 400) LC_CASE(5, 25);
+    switch (ct) {
+        case 5: LC_CASE(5, 0);
+        case 4: LC_CASE(4, 0);
+        case 2: LC_CASE(2, 0);
+        default: LC_CASE(1, 0);
+    }
+#undef LC_CASE
+#undef LC_ARGS
+}
+
+template <int CT, int SP>
+static int launch_level_project_inst(hipStream_t st, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
+                                     size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm) {
+    const int nrg = (ncell + 15) / 16;
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;          // column blocks of one row group share an XCD
+    const int ncb = ncols / (16 * CT);
+    hipLaunchKernelGGL((level_project<CT, SP>), dim3(nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc, C, off, HP, hp_stride,
+                       normalize, bias, P, ldp, H, nrm);
+    LAUNCHOK("level_project");
+    return CLIORA_OK;
+}
+template <int CT>
+static int launch_level_project_sp(hipStream_t st, int SP, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off,
+                                   const float* HP, size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm) {
+    switch (SP) {
+        case 1: return launch_level_project_inst<CT, 1>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+        case 2: return launch_level_project_inst<CT, 2>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+        default: return launch_level_project_inst<CT, 4>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+    }
+}
+// h = unit(sum of the SP parts) for the level's cells (chart rows of H, raw norms) and P = h W^T + bias
+static int launch_level_project(hipStream_t st, int SP, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
+                                size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm) {
+    const int nt = ncols / 16, nrt = (ncell + 15) / 16;
+    if (g_ksplit_min_blocks < 0) { const char* e = getenv("CLIORA_KSPLIT_MIN_BLOCKS"); g_ksplit_min_blocks = e ? atoi(e) : 1000; }
+    // a block's MFMA work and operand bytes are fixed by its tile: wide tiles only when the launch still covers the chip
+    if (nt % 5 == 0 && nrt * (nt / 5) >= g_ksplit_min_blocks)
+        return launch_level_project_sp<5>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+    return launch_level_project_sp<1>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+}
 
 // ------------------------------------------------------------------ forward
 extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
@@ -98,10 +195,50 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
+    // The text-only module in split-bf16 arithmetic runs the fused level kernels (level_kernels.hpp): three launches per level,
+    // no per-pair rows in HBM.  (CLIORA's attention sits between the aggregate and the norm, and the exact-fp32 mode has its
+    // own GEMM kernels: both keep the round-1 sequence below.)
+    const bool keep = (run_outside & CLIORA_FWD_NO_BACKWARD) == 0;   // per-pair state for the backward
+    run_outside &= 1;
+    const bool fused = !vl && split_bf16();
+    const size_t hp_stride = (size_t)B * C * Dp;
+    float* HP = ws + f.hp;
+    uint32_t* YM = reinterpret_cast<uint32_t*>(ws + f.ymask);
+    auto pair_level = [&](int level, bool outside_pass) {
+        const LevelArgs g = level_args(p, level, outside_pass);
+        const int32_t* t = p.d_tables;
+        const size_t base = outside_pass ? p.lvl_base_out[level] : p.lvl_base_in[level];
+        PairLevel lv;
+        lv.pa = t + (outside_pass ? p.dev.pair_a_out : p.dev.pair_a_in) + base;
+        lv.pb = t + (outside_pass ? p.dev.pair_b_out : p.dev.pair_b_in) + base;
+        lv.Lc = g.Lc; lv.N = g.N; lv.C = C; lv.ncell = B * g.Lc; lv.rowbase = g.rowbase; lv.off = g.off;
+        return lv;
+    };
+
     // ---- inside pass (diora.py:295-331) ----
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
+        if (fused) {
+            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS,
+                               ws + f.sp, ws + f.pp, IS);
+            LAUNCHOK("pair_scores_fwd");
+            int SP = 1;
+            {
+                ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+                OKR(launch_level_compose(st, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi, ws + f.pi + Dp, ldpi,
+                                         ws + f.b2i, ws + f.pp, HP, hp_stride, keep ? YM : nullptr, keep ? ws + f.y : nullptr, keep ? ws + f.x : nullptr, &SP));
+            }
+            if (level < L - 1)
+                OKR(launch_level_project(st, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, ws + f.bcat,
+                                         ws + f.pi, ldpi, IH, ws + f.nrmi));
+            else {
+                hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
+                                   p.normalize, IH, ws + f.nrmi);
+                LAUNCHOK("level_finish");
+            }
+            continue;
+        }
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
             OKR(launch_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, nrows,
@@ -136,6 +273,26 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc, nrows = ncell * g.N;
+            if (fused) {
+                hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi,
+                                   OH, IS, OS, ws + f.sp, ws + f.pp, OS);
+                LAUNCHOK("pair_scores_fwd(out)");
+                int SP = 1;
+                {
+                    ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+                    OKR(launch_level_compose(st, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), ws + f.pi + (size_t)p.blk_plo * Dp, ldpi,
+                                             ws + f.po, Dp, ws + f.b2o, ws + f.pp, HP, hp_stride, keep ? YM : nullptr, keep ? ws + f.y : nullptr, keep ? ws + f.x : nullptr, &SP));
+                }
+                if (level >= 1)
+                    OKR(launch_level_project(st, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, nullptr,
+                                             ws + f.po, Dp, OH, ws + f.nrmo));
+                else {
+                    hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
+                                       p.normalize, OH, ws + f.nrmo);
+                    LAUNCHOK("level_finish(out)");
+                }
+                continue;
+            }
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
                 OKR(launch_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, nrows,

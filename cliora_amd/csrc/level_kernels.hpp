@@ -1,0 +1,366 @@
+// Fused per-level kernels of the DioraMLP chart recursion (gfx950).
+//
+// One chart level of one pass (cliora/net/diora.py:295-310 inside_func, :358-376 outside_func) is three launches:
+//
+//   pair_scores_fwd      split scores s_n = QL(a).h_b + s_a + s_b, their softmax p_n and the cell score   (chart_kernels.hpp)
+//   level_compose_fwd    for every split: x = relu(PL(a) + PR(b)), y = relu(W2 x + b2)   [split-bf16 MFMA, weights in LDS]
+//                        and, in the SAME kernel, the softmax-weighted sum over the splits of a cell
+//                            g = sum_n p_n y_n                                            (diora.py:137-146)
+//                        -- the softmax weights do not depend on the compose output, so the per-split rows y_n (and x_n) never
+//                        reach HBM; what is kept for the backward is one ReLU bit per element of y
+//   level_project        h = g / max(||g||, eps)  (utils.py:11-14) and the projections of the new cells
+//                            [PL | PR | QL] = h Wcat^T + bias                             (factored first compose layer + bilinear)
+//
+// Tile order.  A 16-row MFMA tile is (16 consecutive target cells t = b*Lc + p of the level) x (ONE split n): the N tiles of
+// a "cell tile" differ only in n, so the weighted sum over the splits is an element-wise FMA into a register accumulator --
+// no cross-lane reduction, no atomics, fixed summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chart_kernels.hpp"
+
+namespace cliora {
+
+struct PairLevel {
+    const int32_t *pa, *pb;   // operand cells (ids inside one sentence's chart) of the level's pairs: index p*N + n
+    int Lc, N, C, ncell;      // cells per sentence at the level, splits per cell, cells per chart, B*Lc
+    int rowbase;              // global pair row of (t, n) = rowbase + t*N + n, t = b*Lc + p
+    int off;                  // chart offset of the level: chart row of t = b*C + off + p
+};
+
+constexpr int LC_SLOTS = 4;   // LDS slots of the cross-wave reduction (one per writer of a round)
+
+// ---------------------------------------------------------------------------------
+// level_compose_fwd
+//   grid.y = column blocks of CT*16 output columns (the block's split-bf16 weight image stays in LDS);
+//   grid.x walks TASKS = (group of TG cell tiles) x (part s of SP of the split range).  The 8 waves of the workgroup are
+//   dealt WPG = 8 / TG waves per cell tile; wave r of a cell tile takes the splits n0 + r, n0 + r + WPG, ... and keeps
+//   sum p_n y_n in registers; the WPG partial sums meet in LDS in a fixed tree order.  Output: HP[s][chart row][Dp] (partial
+//   aggregates, summed over s by level_project), the ReLU bits of y, and on request the y rows (hooks) / x rows.
+//   Operand rows are fetched in the quad-coalesced lane map and moved to the MFMA lanes by ds_bpermute (gemm_kernels.hpp).
+// ---------------------------------------------------------------------------------
+template <int CT, int K16, bool SIDE>
+__global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
+                                                         const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
+                                                         const float* __restrict__ bias, const float* __restrict__ Pp,
+                                                         int TG, int SP, int ntask, float* __restrict__ HP, size_t hp_stride, int Dp,
+                                                         uint32_t* __restrict__ ymask, float* __restrict__ Y, float* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    constexpr int WAVES = 8, T = WAVES * 64, PD = 4;
+    constexpr bool KS = K16 > 0;
+    constexpr int UNROLL_STEPS = KS ? 64 : 1;
+    const int K = KS ? K16 * 16 : K_;
+    const int S = KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int Kp = S - WS3_PAD, half = Kp >> 1;
+    const int by = blockIdx.y, gy = gridDim.y;
+    const int col0 = by * (CT * 16);
+    {   // the block's weight image -> LDS (LDS-DMA, lane-linear); waited for below, after the first row contexts are on their way
+        const uint32_t* src = Wimg + (size_t)col0 * S;
+        const int n16 = CT * 16 * S / 4;
+        for (int e0 = wave * 64; e0 < n16; e0 += T) {
+            const int e = e0 + lane;
+            if (e < n16)
+                __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)e * 4),
+                                                 (__attribute__((address_space(3))) void*)(lds_img + e0 * 4), 16, 0, 0);
+        }
+    }
+    float4* red = reinterpret_cast<float4*>(lds_img + CT * 16 * S);      // [LC_SLOTS][CT][64]
+    float4 bv[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bv[c] = ld4(bias + col0 + c * 16 + 4 * g);
+    const int nsteps = Kp >> 5;
+    const int nsteps_p = (nsteps + PD - 1) / PD * PD;
+    int wfrag_off = i * S + 4 * g;
+    const int WPG = WAVES / TG;                      // waves per cell tile (1, 2, 4 or 8)
+    const int j = wave / WPG, r = wave - j * WPG;
+    const int G = (lv.ncell + 15) >> 4;
+    const int Ns = (lv.N + SP - 1) / SP;
+
+    struct Ctx { const float *pa, *pb; float* xo; };
+    auto rowctx = [&](int gt, int n) {               // fetch-lane view of tile (gt, n)
+        const int t = min(gt * 16 + li, lv.ncell - 1);            // clamp: computed, masked out by p = 0 and never stored
+        const int b = t / lv.Lc, p = t - b * lv.Lc;
+        const int idx = p * lv.N + n;
+        const size_t ca = (size_t)b * lv.C + lv.pa[idx], cb = (size_t)b * lv.C + lv.pb[idx];
+        return Ctx{PA + ca * lda, PB + cb * ldb, SIDE ? X + ((size_t)lv.rowbase + (size_t)t * lv.N + n) * Dp : nullptr};
+    };
+    Raw2 ra[PD][2];
+    auto issue = [&](int slot, const Ctx& c, int s) {
+        const int k = 32 * s + 4 * lg;
+        const int k2 = k + (32 * s + 16 < K ? 16 : 0);
+        ra[slot][0] = Raw2{ld4(c.pa + k), ld4(c.pb + k)};
+        ra[slot][1] = Raw2{ld4(c.pa + k2), ld4(c.pb + k2)};
+    };
+    auto relu_add = [](const Raw2& q) {
+        return make_float4(fmaxf(q.u.x + q.v.x, 0.f), fmaxf(q.u.y + q.v.y, 0.f), fmaxf(q.u.z + q.v.z, 0.f), fmaxf(q.u.w + q.v.w, 0.f));
+    };
+
+    bool staged = false;
+    for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
+        const int gg = task / SP, s = task - gg * SP;
+        const int gt = gg * TG + j;                  // this wave's cell tile
+        const bool have = gt < G;
+        const int n0 = s * Ns, n1 = min(lv.N, n0 + Ns);
+        f32x4 hacc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) hacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool work = have && n0 + r < n1;
+        Ctx ctx = rowctx(min(gt, G - 1), work ? n0 + r : n0);        // index loads overlap the weight staging
+        if (!staged) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            staged = true;
+        }
+        if (work) {
+            int n = n0 + r;
+#pragma unroll
+            for (int sl = 0; sl < PD; ++sl) issue(sl, ctx, sl < nsteps ? sl : 0);
+            while (true) {
+                const int nn = n + WPG;
+                const bool has_next = nn < n1;
+                const Ctx ctxn = rowctx(gt, has_next ? nn : n);
+                // MFMA-lane view of the tile: row i is target cell ti, pair row prow
+                const int ti = gt * 16 + i;
+                const bool ok = ti < lv.ncell;
+                const size_t prow = (size_t)lv.rowbase + (size_t)min(ti, lv.ncell - 1) * lv.N + n;
+                const float pn = ok ? Pp[prow] : 0.f;
+                f32x4 acc[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(wfrag_off));          // keep the weight-fragment LDS reads inside the tile loop
+                const uint32_t* wfrag = lds_img + wfrag_off;
+                int side_turn = 0;
+#pragma unroll UNROLL_STEPS
+                for (int base = 0; base < nsteps_p; base += PD) {
+#pragma unroll
+                    for (int sl = 0; sl < PD; ++sl) {
+                        const int st = base + sl;
+                        if (st < nsteps) {
+                            const bool second = 32 * st + 16 < K;
+                            const float4 f0 = relu_add(ra[sl][0]);
+                            const float4 f1 = relu_add(ra[sl][1]);   // beyond K: a second copy of the first run, zero weights in the image
+                            if (SIDE && side_turn == by) {
+                                const int k = 32 * st + 4 * lg;
+                                st4(ctx.xo + k, f0);
+                                if (second) st4(ctx.xo + k + 16, f1);
+                            }
+                            side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
+                            const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
+                            u32x4 xh, xl;
+                            split_bf16x8(a0, a1, xh, xl);
+                            u32x4 wh[CT], wl[CT];
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) {
+                                wh[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st);
+                                wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
+                            }
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], xh, acc[c]);
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xl, acc[c]);
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xh, acc[c]);
+                        }
+                        const int nst = st + PD;
+                        const bool in_cur = nst < nsteps;
+                        issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
+                        // hipcc otherwise sinks each refill down to its use PD steps later (one exposed memory latency per
+                        // k-step instead of PD steps of cover): a slot's loads are issued HERE
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // epilogue of the tile: y = relu(acc + b2); g += p_n y; ReLU bits; optional y rows
+                uint32_t bits = 0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const float y0 = fmaxf(acc[c][0] + bv[c].x, 0.f), y1 = fmaxf(acc[c][1] + bv[c].y, 0.f);
+                    const float y2 = fmaxf(acc[c][2] + bv[c].z, 0.f), y3 = fmaxf(acc[c][3] + bv[c].w, 0.f);
+                    hacc[c][0] = fmaf(pn, y0, hacc[c][0]); hacc[c][1] = fmaf(pn, y1, hacc[c][1]);
+                    hacc[c][2] = fmaf(pn, y2, hacc[c][2]); hacc[c][3] = fmaf(pn, y3, hacc[c][3]);
+                    bits |= ((y0 > 0.f ? 1u : 0u) | (y1 > 0.f ? 2u : 0u) | (y2 > 0.f ? 4u : 0u) | (y3 > 0.f ? 8u : 0u)) << (4 * c);
+                    if (Y && ok) st4(Y + prow * Dp + col0 + c * 16 + 4 * g, make_float4(y0, y1, y2, y3));
+                }
+                if (ymask && ok) ymask[(prow * gy + by) * 4 + g] = bits;
+                if (!has_next) break;
+                ctx = ctxn;
+                n = nn;
+            }
+        }
+        // ---- sum over the WPG waves of a cell tile: fixed tree.  In the round of `stride` the waves r < 2*stride still hold
+        // data; r >= stride park their accumulators in LDS (slot j*stride + r - stride < 4), r < stride add their partner's.
+        // WPG is the same for every wave of the launch, so every wave takes the same barriers.
+#pragma unroll
+        for (int stride = 4; stride >= 1; stride >>= 1) {
+            if (WPG >= 2 * stride) {
+                const bool holding = r < 2 * stride;
+                const bool writer = holding && r >= stride;
+                if (writer) {
+                    const int slot = j * stride + (r - stride);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) red[(slot * CT + c) * 64 + lane] = make_float4(hacc[c][0], hacc[c][1], hacc[c][2], hacc[c][3]);
+                }
+                __syncthreads();
+                if (holding && !writer) {
+                    const int slot = j * stride + r;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const float4 v = red[(slot * CT + c) * 64 + lane];
+                        hacc[c][0] += v.x; hacc[c][1] += v.y; hacc[c][2] += v.z; hacc[c][3] += v.w;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (have && r == 0) {
+            const int ti = gt * 16 + i;
+            if (ti < lv.ncell) {
+                const int b = ti / lv.Lc, p = ti - b * lv.Lc;
+                float* o = HP + (size_t)s * hp_stride + ((size_t)b * lv.C + lv.off + p) * Dp + col0 + 4 * g;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) st4(o + c * 16, make_float4(hacc[c][0], hacc[c][1], hacc[c][2], hacc[c][3]));
+            }
+        }
+    }
+}
+
+// sum of the SP partial aggregates of one chart row, fixed order
+template <int SP>
+__device__ __forceinline__ float4 sum_parts(const float* hp, size_t hp_stride, int k) {
+    float4 a = ld4(hp + k);
+#pragma unroll
+    for (int s = 1; s < SP; ++s) a = f4add(a, ld4(hp + (size_t)s * hp_stride + k));
+    return a;
+}
+
+// ---------------------------------------------------------------------------------
+// level_project: unit norm of the level's aggregates + projection of the new cells, one launch.
+//   rows = the level's cells (r = b*Lc + p), A(r, :) = sum_s HP[s][chart row]  (the un-normalised g of level_compose_fwd);
+//   out[chart row][col] = (sum_k A(r,k) W[col][k]) / max(||A(r,:)||, eps) + bias[col]      -- the projection is linear, so the
+//   norm is applied to the accumulators: ||A|| is summed while the row streams through as the MFMA operand (no extra pass).
+//   The column-block-0 workgroups also write H = A / max(||A||, eps) (the chart output) and the raw norm.
+//   Same split-K structure as rows_gemm_ksplit<1, CT, FRAG>: one workgroup = 16 rows x CT*16 columns, the four waves split
+//   the reduction, weights from the fragment image (frag_weight_image), exact fp32 MFMA.
+// ---------------------------------------------------------------------------------
+template <int CT, int SP>
+__global__ __launch_bounds__(256) void level_project(const float* __restrict__ Wfrag, int K, int nrg, int nrgp, int ncolblocks,
+                                                     int ncell, int Lc, int C, int off, const float* __restrict__ HP, size_t hp_stride,
+                                                     int normalize, const float* __restrict__ bias, float* __restrict__ P, int ldp,
+                                                     float* __restrict__ H, float* __restrict__ nrm) {
+    __shared__ float4 part[4][CT][64];
+    __shared__ float sh_ss[4][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;
+    if (rg >= nrg) return;
+    const int col0 = cb * (CT * 16);
+    const int nchunks = K >> 4;
+    const int cbase = nchunks / 4, crem = nchunks % 4;
+    const int ch0 = wave * cbase + min(wave, crem);
+    const int nch = cbase + (wave < crem ? 1 : 0);
+    auto crow_of = [&](int r) { const int rc = min(r, ncell - 1); const int b = rc / Lc; return (size_t)b * C + off + (rc - b * Lc); };
+    const float* hp = HP + crow_of(rg * 16 + li) * K;
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int PD = 4;
+    float4 ra[PD];
+    float4 rw[PD][CT];
+    auto load = [&](int slot, int ch) {
+        ra[slot] = sum_parts<SP>(hp, hp_stride, 16 * (ch0 + ch) + 4 * lq);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) rw[slot][c] = reinterpret_cast<const float4*>(Wfrag)[((size_t)(cb * CT + c) * nchunks + ch0 + ch) * 64 + lane];
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl)
+        if (sl < nch) load(sl, sl);
+    float ss = 0.f;
+    for (int base = 0; base < nch; base += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+            if (base + sl < nch) {
+                ss += f4dot(ra[sl], ra[sl]);
+                const float4 a = to_mfma_lanes(psrc, ra[sl]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma16(rw[sl][c].x, a.x, acc[c]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma16(rw[sl][c].y, a.y, acc[c]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma16(rw[sl][c].z, a.z, acc[c]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma16(rw[sl][c].w, a.w, acc[c]);
+                if (base + sl + PD < nch) load(sl, base + sl + PD);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) part[wave][c][lane] = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    ss += __shfl_xor(ss, 1);                 // the four fetch lanes of a row
+    ss += __shfl_xor(ss, 2);
+    if (lq == 0) sh_ss[wave][li] = ss;
+    __syncthreads();
+    auto den_of = [&](int r16, float* raw) {
+        const float nr = sqrtf(((sh_ss[0][r16] + sh_ss[1][r16]) + sh_ss[2][r16]) + sh_ss[3][r16]);
+        if (raw) *raw = nr;
+        return normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+    };
+    const float den = den_of(i, nullptr);
+    const int row = rg * 16 + i;
+    for (int t = wave; t < CT; t += 4) {
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                               ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        v = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+        const int col = col0 + t * 16 + 4 * q;
+        if (bias) v = f4add(v, ld4(bias + col));
+        if (row < ncell) st4(P + crow_of(row) * ldp + col, v);
+    }
+    if (cb == 0 && H) {                       // chart output of the level: wave w writes rows w, w+4, ...
+        const int nv = K >> 2;
+        for (int rr = wave; rr < 16; rr += 4) {
+            const int r = rg * 16 + rr;
+            if (r >= ncell) break;
+            float nr;
+            const float d = den_of(rr, &nr);
+            const size_t crow = crow_of(r);
+            const float* src = HP + crow * K;
+            for (int v4 = lane; v4 < nv; v4 += 64) {
+                const float4 a = sum_parts<SP>(src, hp_stride, 4 * v4);
+                st4(H + crow * K + 4 * v4, make_float4(a.x / d, a.y / d, a.z / d, a.w / d));
+            }
+            if (lane == 0) nrm[crow] = nr;
+        }
+    }
+}
+
+// levels whose cells need no projection (inside root, outside leaves): sum the partial aggregates, unit norm, chart row.
+__global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, int off, int Dp, const float* __restrict__ HP,
+                                                    size_t hp_stride, int SP, int normalize, float* __restrict__ H,
+                                                    float* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= ncell) return;
+    const int b = r / Lc;
+    const size_t crow = (size_t)b * C + off + (r - b * Lc);
+    const int nv = Dp >> 2;
+    float4 v0 = f4zero(), v1 = f4zero();
+    for (int s = 0; s < SP; ++s) {
+        const float* src = HP + (size_t)s * hp_stride + crow * Dp;
+        if (lane < nv) v0 = f4add(v0, ld4(src + 4 * lane));
+        if (lane + 64 < nv) v1 = f4add(v1, ld4(src + 4 * (lane + 64)));
+    }
+    const float nr = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
+    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+    float* h = H + crow * Dp;
+    if (lane < nv) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
+    if (lane + 64 < nv) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
+    if (lane == 0) nrm[crow] = nr;
+}
+
+}  // namespace cliora

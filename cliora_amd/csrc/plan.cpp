@@ -161,6 +161,16 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.x = take(Rt * Dp);
         f.sp = take(Rt);
         f.pp = take(Rt);
+        {   // column block of the weight-stationary compose kernels: the most 16-column tiles whose split-bf16 image
+            // (+ the cross-wave reduction slots) fits the CU's 160 KiB of LDS
+            const int nt = (int)(Dp / 16);
+            f.ct3 = 1;
+            for (int ct : {5, 4, 2, 1})
+                if (nt % ct == 0 && (size_t)ct * 16 * f.S3 * 4 + (size_t)4 * ct * 1024 <= 160 * 1024) { f.ct3 = ct; break; }
+            f.ncb3 = nt / f.ct3;
+        }
+        f.hp = take(arch == 0 ? (size_t)HP_PARTS * BC * Dp : 0);
+        f.ymask = take(arch == 0 ? Rt * f.ncb3 * 4 : 0);
         f.nrmi = take(BC);
         f.nrmo = take(BC);
         f.icp = take(lstm * BC * Dp); f.ocp = take(lstm * BC * Dp);
@@ -227,6 +237,7 @@ std::vector<int32_t> flatten_tables(Plan& p) {
         p.dev.use_partner[r] = put(p.uses[r].partner);
     }
     p.dev.lvl_base_in = put(p.lvl_base_in);
+    p.dev.lvl_base_out = put(p.lvl_base_out);
     p.dev.arow = put(p.arow); p.dev.brow = put(p.brow); p.dev.trow = put(p.trow);
     if (flat.empty()) flat.push_back(0);
     return flat;

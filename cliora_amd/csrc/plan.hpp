@@ -19,6 +19,7 @@ constexpr int ROLE_INB = 1;   // inside cell used as RIGHT child in the inside p
 constexpr int ROLE_OUTA = 2;  // inside cell used as SIBLING in the outside pass
 constexpr int ROLE_OUTB = 3;  // outside cell used as PARENT in the outside pass
 constexpr int N_ROLES = 4;
+constexpr int HP_PARTS = 4;   // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
 
 struct UseList {
     std::vector<int32_t> off;      // C+1, CSR offsets per cell
@@ -45,6 +46,9 @@ struct FwdLayout {
     size_t y;                           // per-pair compose output (R x Dp)
     size_t x;                           // per-pair first-layer activation relu(PL+PR) (R x Dp)
     size_t sp, pp;                      // per-pair score / softmax weight (R)
+    size_t hp;                          // partial aggregates of level_compose_fwd: HP_PARTS x (B*C x Dp), summed by level_project
+    size_t ymask;                       // ReLU bits of the compose output y: R x ncb3 x 4 words (word g of a column block: 4 bits per 16-column tile)
+    int ct3, ncb3;                      // column tiles per weight-stationary column block / number of such blocks (Dp = 16 * ct3 * ncb3)
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
     size_t icp, ocp, nrmic, nrmoc, rootc;   // TreeLSTM: cell-state charts (B*C x Dp), their norms, padded root c
     size_t att_u, att_pk, att_nrmu;     // CLIORA per inside cell: u = unit(aggregate) (B*C x Dp), region probabilities (B*C x 64), |aggregate| (B*C)
@@ -90,7 +94,7 @@ struct Plan {
     // device copies (filled lazily by the HIP side)
     int32_t* d_tables = nullptr;
     size_t d_tables_count = 0;
-    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in; } dev;
+    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out; } dev;
 
     int Lc(int level) const { return L - level; }
     int Nin(int level) const { return level; }

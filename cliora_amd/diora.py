@@ -62,7 +62,7 @@ class ChartFunction(torch.autograd.Function):
                 plan.handle, C.byref(pst), _ptr(x_span), None, None, _ptr(inside_h), _ptr(inside_s),
                 _ptr(outside_h), _ptr(outside_s), None, _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
             _lib.check(rc, 'cliora_chart_forward')
-        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside), ws, ptens
+        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside) & 1, ws, ptens
         ctx.save_for_backward(x_span, inside_h, inside_s, outside_h, outside_s)
         ctx.set_materialize_grads(False)
         holder.clear()
@@ -219,7 +219,13 @@ class DioraBase(nn.Module):
         dev_index = x_span.device.index if x_span.is_cuda else -1
         plan = _lib.get_plan(B, L, D, self.share, self.normalize, 0, dev_index)
         holder = []
-        ih, is_, oh, os_ = ChartFunction.apply(plan, holder, bool(self.outside), x_span, *self._param_tensors())
+        # eval / torch.no_grad: nothing will ask for the backward, so the per-pair state is not written -- unless a hook
+        # override wants the per-split tensors (analysis/utils.py:67-95)
+        params = self._param_tensors()
+        needs_grad = torch.is_grad_enabled() and (x_span.requires_grad or any(t is not None and t.requires_grad for t in params))
+        hooks = self._hook_overridden('inside_hook') or self._hook_overridden('outside_hook')
+        flags = int(bool(self.outside)) | (0 if (needs_grad or hooks) else _lib.FWD_NO_BACKWARD)
+        ih, is_, oh, os_ = ChartFunction.apply(plan, holder, flags, x_span, *params)
         ch = Chart()
         ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s = ih, is_, oh, os_
         # DioraMLP's cell state is identically zero (diora.py:60-61, 70)

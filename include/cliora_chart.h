@@ -96,7 +96,10 @@ int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t**
  *   inside_h/outside_h (B,C,D), inside_s/outside_s (B,C)   out
  *   inside_c   (B,C,D)   out, CLIORA only (else NULL): unit(context) at the leaves, 0 above
  * For DioraMLP the c charts are identically zero (diora.py:70); the caller zero-fills
- * them once, they are not touched here. */
+ * them once, they are not touched here.
+ * run_outside is a flag word: bit 0 = run the outside pass; CLIORA_FWD_NO_BACKWARD = no backward call will follow
+ * (torch.no_grad / eval): the per-pair state the backward needs is not written (hooks need the default). */
+#define CLIORA_FWD_NO_BACKWARD 2
 int cliora_chart_forward(cliora_plan* plan, const cliora_params* params,
                          const float* x_span, const float* obj_span, const float* drop_mask,
                          float* inside_h, float* inside_s, float* outside_h, float* outside_s,
