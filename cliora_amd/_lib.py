@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CLIORA_CHART_LIB') or os.path.join(HERE, 'libcliora_chart.so')   # override: kernel experiments only
 
 NORM = {'none': 0, 'unit': 1}
-FWD_NO_BACKWARD = 2      # include/cliora_chart.h: flag bit of cliora_chart_forward's run_outside word
+FWD_NO_BACKWARD = 2      # include/cliora_chart.h: flag bits of cliora_chart_forward's run_outside word
+FWD_PAIR_STATES = 4
 KCLASS = {'compose_fwd': 0, 'compose_bwd': 1, 'wgrad': 2}
 
 PARAM_FIELDS = ('leaf_w', 'leaf_b', 'in_w1', 'in_b1', 'in_w2', 'in_b2', 'in_mat',
@@ -58,6 +59,8 @@ def lib():
     L.cliora_plan_fwd_workspace_bytes.restype = sz
     L.cliora_plan_bwd_workspace_bytes.argtypes = [vp]
     L.cliora_plan_bwd_workspace_bytes.restype = sz
+    L.cliora_plan_pair_states_bytes.argtypes = [vp]
+    L.cliora_plan_pair_states_bytes.restype = sz
     L.cliora_plan_device_bytes.argtypes = [vp]
     L.cliora_plan_device_bytes.restype = sz
     L.cliora_plan_table.argtypes = [vp, C.c_char_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(sz)]
@@ -109,6 +112,7 @@ class Plan:
         self.handle = h
         self.fwd_bytes = lib().cliora_plan_fwd_workspace_bytes(h)
         self.bwd_bytes = lib().cliora_plan_bwd_workspace_bytes(h)
+        self.pair_bytes = lib().cliora_plan_pair_states_bytes(h)    # optional workspace tail: per-pair compose outputs for the hooks
         self.table_bytes = lib().cliora_plan_device_bytes(h)     # index tables: this much host memory, and as much HBM after the first forward
 
     def table(self, name):

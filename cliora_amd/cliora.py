@@ -40,13 +40,14 @@ class VLChartFunction(torch.autograd.Function):
         outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
         outside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
         inside_c = torch.zeros((B, Cc, D), device=dev, dtype=torch.float32)
-        ws = torch.empty(plan.fwd_bytes, device=dev, dtype=torch.uint8)
+        nbytes = plan.fwd_bytes + (plan.pair_bytes if int(run_outside) & _lib.FWD_PAIR_STATES else 0)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         pst = _param_struct(ptens)
         rc = _lib.lib().cliora_chart_forward(plan.handle, C.byref(pst), _ptr(x_span), _ptr(obj_span), _ptr(drop_mask),
                                             _ptr(inside_h), _ptr(inside_s), _ptr(outside_h), _ptr(outside_s), _ptr(inside_c),
-                                            _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
+                                            _ptr(ws), nbytes, int(run_outside), _stream())
         _lib.check(rc, 'cliora_chart_forward')
-        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens, ctx.drop_mask = plan, int(run_outside), ws, ptens, drop_mask
+        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens, ctx.drop_mask = plan, int(run_outside) & 1, ws, ptens, drop_mask
         ctx.save_for_backward(x_span, obj_span, inside_h, inside_s, outside_h, outside_s)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(inside_c)
@@ -167,8 +168,11 @@ class DioraMLP(DioraBase):
             if mask is None:   # same distribution as nn.Dropout(0.1) on the (.., R) probabilities
                 mask = F.dropout(torch.ones((B, plan.C, R), device=x_span.device), DROPOUT_P, True)
         holder = []
-        ih, is_, oh, os_, ic = VLChartFunction.apply(plan, holder, bool(self.outside), x_span, obj_embed_span, mask,
-                                                     *self._param_tensors())
+        params = self._param_tensors()
+        needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [x_span, obj_embed_span] + list(params))
+        hooks = self._hook_overridden('inside_hook') or self._hook_overridden('outside_hook')
+        flags = int(bool(self.outside)) | (0 if needs_grad else _lib.FWD_NO_BACKWARD) | (_lib.FWD_PAIR_STATES if hooks else 0)
+        ih, is_, oh, os_, ic = VLChartFunction.apply(plan, holder, flags, x_span, obj_embed_span, mask, *params)
         ch = Chart()
         ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s, ch.inside_c = ih, is_, oh, os_, ic
         ch.outside_c = torch.zeros_like(oh)

@@ -75,6 +75,7 @@ extern "C" void cliora_plan_destroy(cliora_plan* plan) {
 }
 
 extern "C" size_t cliora_plan_fwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.fwd.total * sizeof(float) : 0; }
+extern "C" size_t cliora_plan_pair_states_bytes(const cliora_plan* plan) { return plan ? plan->p.fwd.pair_h_floats * sizeof(float) : 0; }
 extern "C" size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.bwd.total * sizeof(float) : 0; }
 
 extern "C" int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count) {
@@ -122,7 +123,7 @@ extern "C" int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_ws, 
     if (level < 1 || level >= p.L) return fail(CLIORA_EINVAL, "level out of range");
     const size_t r0 = (size_t)p.row_base_in(level);
     *scores = (const float*)fwd_ws + p.fwd.sp + r0;
-    *h = (const float*)fwd_ws + p.fwd.y + r0 * p.Dp;
+    *h = (const float*)fwd_ws + p.fwd.pair_h + r0 * p.Dp;
     *rows = (size_t)p.B * (p.L - level) * level;
     *ldh = (size_t)p.Dp;
     return CLIORA_OK;
@@ -135,7 +136,7 @@ extern "C" int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_ws,
     if (level < 0 || level > p.L - 2) return fail(CLIORA_EINVAL, "level out of range");
     const size_t r0 = (size_t)p.row_base_out(level);
     *scores = (const float*)fwd_ws + p.fwd.sp + r0;
-    *h = (const float*)fwd_ws + p.fwd.y + r0 * p.Dp;
+    *h = (const float*)fwd_ws + p.fwd.pair_h + r0 * p.Dp;
     *rows = (size_t)p.B * (p.L - level) * (p.L - level - 1);
     *ldh = (size_t)p.Dp;
     return CLIORA_OK;

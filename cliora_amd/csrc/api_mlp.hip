@@ -37,27 +37,34 @@ static ComposeGeom compose_geom(int ncell, int N, int ncb) {
     return q;
 }
 
-template <int CT, int K16, bool SIDE>
+// LDS of the compose kernels: the column block's weight image (split-bf16: S dwords per column; exact fp32: K) + reduction slots
+static size_t compose_lds_bytes(int ct, int S, bool with_slots) {
+    return (size_t)ct * 16 * S * sizeof(uint32_t) + (with_slots ? (size_t)LC_SLOTS * ct * 64 * sizeof(float4) : 0);
+}
+
+template <int CT, int K16, bool F32>
 static int launch_level_compose_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* PA, int lda,
                                      const float* PB, int ldb, const float* bias, const float* Pp, float* HP, size_t hp_stride, int Dp,
-                                     uint32_t* ymask, float* Y, float* X, int* SP_out) {
-    const size_t lds = (size_t)CT * 16 * S * sizeof(uint32_t) + (size_t)LC_SLOTS * CT * 64 * sizeof(float4);
-    OKR(cliora_ensure_max_lds((const void*)level_compose_fwd<CT, K16, SIDE>));
+                                     uint32_t* ymask, float* Y, int* SP_out) {
+    OKR(cliora_ensure_max_lds((const void*)level_compose_fwd<CT, K16, F32>));
     const ComposeGeom q = compose_geom(lv.ncell, lv.N, ncb);
-    hipLaunchKernelGGL((level_compose_fwd<CT, K16, SIDE>), dim3(q.gx, ncb), dim3(512), lds, st, Wimg, S, K, lv, PA, lda, PB, ldb, bias, Pp,
-                       q.TG, q.SP, q.ntask, HP, hp_stride, Dp, ymask, Y, X);
+    hipLaunchKernelGGL((level_compose_fwd<CT, K16, F32>), dim3(q.gx, ncb), dim3(512), compose_lds_bytes(CT, S, true), st, Wimg, S, K, lv, PA, lda,
+                       PB, ldb, bias, Pp, q.TG, q.SP, q.ntask, HP, hp_stride, Dp, ymask, Y);
     LAUNCHOK("level_compose_fwd");
     *SP_out = q.SP;
     return CLIORA_OK;
 }
 
-// y = relu(W2 relu(PL(a) + PR(b)) + b2) for every pair of the level and g = sum_n p_n y_n per cell, into HP (SP parts)
-static int launch_level_compose(hipStream_t st, const float* Wimg, int S, int Dp, int ct, int ncb, const PairLevel& lv, const float* PA, int lda,
-                                const float* PB, int ldb, const float* bias, const float* Pp, float* HP, size_t hp_stride,
-                                uint32_t* ymask, float* Y, float* X, int* SP_out) {
-    const uint32_t* I = reinterpret_cast<const uint32_t*>(Wimg);
-#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, X, SP_out
-#define LC_CASE(c, k16) return X ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
+// y = relu(W2 relu(PL(a) + PR(b)) + b2) for every pair of the level and g = sum_n p_n y_n per cell, into HP (SP parts).
+// W: the plain fp32 weight (exact mode), Wimg: its split-bf16 image.
+static int launch_level_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
+                                const float* PA, int lda, const float* PB, int ldb, const float* bias, const float* Pp, float* HP,
+                                size_t hp_stride, uint32_t* ymask, float* Y, int* SP_out) {
+    const bool f32 = !split_bf16();
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? W : Wimg);
+    const int S = f32 ? Dp : S3;
+#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, SP_out
+#define LC_CASE(c, k16) return f32 ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
     if (ct == 5 && Dp == 400) LC_CASE(5, 25);
     switch (ct) {
         case 5: LC_CASE(5, 0);
@@ -67,6 +74,43 @@ static int launch_level_compose(hipStream_t st, const float* Wimg, int S, int Dp
     }
 #undef LC_CASE
 #undef LC_ARGS
+}
+
+template <int CT, int K16, bool F32>
+static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* dG,
+                                         const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB, int ldb,
+                                         float* DA, float* DZ, float* X, float* DPP) {
+    OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32>));
+    const int ntiles = (lv.ncell + 15) / 16 * lv.N;
+    const int cap = std::max(1, 256 / ncb);
+    const int passes = (ntiles + 8 * cap - 1) / (8 * cap);
+    int gx = (ntiles + 8 * passes - 1) / (8 * passes);
+    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;      // column blocks of the same tiles on one XCD
+    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false), st, Wimg, S, K, lv, dG, ymask,
+                       Pp, PA, lda, PB, ldb, K, DA, DZ, X, DPP);
+    LAUNCHOK("level_compose_bwd");
+    return CLIORA_OK;
+}
+
+// backward of the level's compose layer: DA, DZ, X rows and the partial dG.y_n (see level_compose_bwd).  WT: plain fp32 W2^T.
+static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float* WTimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
+                                    const float* dG, const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB,
+                                    int ldb, float* DA, float* DZ, float* X, float* DPP) {
+    if (lv.N <= 0 || lv.ncell <= 0) return CLIORA_OK;
+    const bool f32 = !split_bf16();
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? WT : WTimg);
+    const int S = f32 ? Dp : S3;
+#define LB_ARGS st, I, S, Dp, ncb, lv, dG, ymask, Pp, PA, lda, PB, ldb, DA, DZ, X, DPP
+#define LB_CASE(c, k16) return f32 ? launch_level_compose_bwd_inst<c, k16, true>(LB_ARGS) : launch_level_compose_bwd_inst<c, k16, false>(LB_ARGS)
+    if (ct == 5 && Dp == 400) LB_CASE(5, 25);
+    switch (ct) {
+        case 5: LB_CASE(5, 0);
+        case 4: LB_CASE(4, 0);
+        case 2: LB_CASE(2, 0);
+        default: LB_CASE(1, 0);
+    }
+#undef LB_CASE
+#undef LB_ARGS
 }
 
 template <int CT, int SP>
@@ -183,6 +227,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
         hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, PairScoreArgs{}, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (size_t)0, 0,
                            ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                            inside_c, D, IS);
         LAUNCHOK("cell_attend_fwd(leaves)");
@@ -195,15 +240,20 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
-    // The text-only module in split-bf16 arithmetic runs the fused level kernels (level_kernels.hpp): three launches per level,
-    // no per-pair rows in HBM.  (CLIORA's attention sits between the aggregate and the norm, and the exact-fp32 mode has its
-    // own GEMM kernels: both keep the round-1 sequence below.)
-    const bool keep = (run_outside & CLIORA_FWD_NO_BACKWARD) == 0;   // per-pair state for the backward
-    run_outside &= 1;
-    const bool fused = !vl && split_bf16();
+    // Every level runs the fused kernels of level_kernels.hpp: split scores -> compose + aggregate -> norm + projection.
+    // No per-pair row reaches HBM; the backward gets one ReLU bit per element of y (skipped when no backward will follow).
+    const int flags = run_outside;
+    run_outside = flags & 1;
+    const bool keep = (flags & CLIORA_FWD_NO_BACKWARD) == 0;
+    float* PH = nullptr;                               // per-pair compose outputs, only for the hooks
+    if (flags & CLIORA_FWD_PAIR_STATES) {
+        if (fwd_ws_bytes < (p.fwd.total + p.fwd.pair_h_floats) * sizeof(float))
+            return fail(CLIORA_ENOMEM, "forward workspace has no room for the pair states (cliora_plan_pair_states_bytes)");
+        PH = ws + f.pair_h;
+    }
     const size_t hp_stride = (size_t)B * C * Dp;
     float* HP = ws + f.hp;
-    uint32_t* YM = reinterpret_cast<uint32_t*>(ws + f.ymask);
+    uint32_t* YM = keep ? reinterpret_cast<uint32_t*>(ws + f.ymask) : nullptr;
     auto pair_level = [&](int level, bool outside_pass) {
         const LevelArgs g = level_args(p, level, outside_pass);
         const int32_t* t = p.d_tables;
@@ -218,49 +268,32 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // ---- inside pass (diora.py:295-331) ----
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
-        if (fused) {
-            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS,
-                               ws + f.sp, ws + f.pp, IS);
-            LAUNCHOK("pair_scores_fwd");
-            int SP = 1;
-            {
-                ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                OKR(launch_level_compose(st, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi, ws + f.pi + Dp, ldpi,
-                                         ws + f.b2i, ws + f.pp, HP, hp_stride, keep ? YM : nullptr, keep ? ws + f.y : nullptr, keep ? ws + f.x : nullptr, &SP));
-            }
-            if (level < L - 1)
-                OKR(launch_level_project(st, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, ws + f.bcat,
-                                         ws + f.pi, ldpi, IH, ws + f.nrmi));
-            else {
-                hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
-                                   p.normalize, IH, ws + f.nrmi);
-                LAUNCHOK("level_finish");
-            }
-            continue;
-        }
+        const int ncell = B * g.Lc;
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS,
+                           ws + f.sp, ws + f.pp, IS);
+        LAUNCHOK("pair_scores_fwd");
+        int SP = 1;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-            OKR(launch_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, nrows,
-                            ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi, ldpi, ws + f.pi + Dp, ldpi, ws + f.x, Dp},
-                            StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2i, 2, Dp}));
+            OKR(launch_level_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi,
+                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HP, hp_stride, YM, PH, &SP));
         }
-        if (vl) {   // cliora.py:140-157: aggregate, attention residual, second unit norm
-            // split scores + softmax + aggregate + attention in one launch
-            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L,
-                               PairScoreArgs{dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS, ws + f.sp, ws + f.pp, IS},
-                               ws + f.y, ws + f.pp, (const float*)nullptr,
-                               OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
-                               (float*)nullptr, D, IS);
+        if (vl) {   // cliora.py:140-157: attention residual between the aggregate and the second unit norm, then the projections
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L, PairScoreArgs{}, (const float*)nullptr,
+                               (const float*)nullptr, HP, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
+                               ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
+            if (level < L - 1)
+                OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+                                StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
+        } else if (level < L - 1) {
+            OKR(launch_level_project(st, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, ws + f.bcat,
+                                     ws + f.pi, ldpi, IH, ws + f.nrmi));
         } else {
-            hipLaunchKernelGGL(cell_scores_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi,
-                               IH, IS, IS, ws + f.sp, ws + f.pp, IS, ws + f.y, p.normalize, IH, ws + f.nrmi);
-            LAUNCHOK("cell_scores_aggregate_fwd");
+            hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
+                               p.normalize, IH, ws + f.nrmi);
+            LAUNCHOK("level_finish");
         }
-        if (level < L - 1)
-            OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
-                            StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
     }
 
     // ---- outside pass (diora.py:337-398) ----
@@ -272,40 +305,24 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
-            const int ncell = B * g.Lc, nrows = ncell * g.N;
-            if (fused) {
-                hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi,
-                                   OH, IS, OS, ws + f.sp, ws + f.pp, OS);
-                LAUNCHOK("pair_scores_fwd(out)");
-                int SP = 1;
-                {
-                    ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                    OKR(launch_level_compose(st, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), ws + f.pi + (size_t)p.blk_plo * Dp, ldpi,
-                                             ws + f.po, Dp, ws + f.b2o, ws + f.pp, HP, hp_stride, keep ? YM : nullptr, keep ? ws + f.y : nullptr, keep ? ws + f.x : nullptr, &SP));
-                }
-                if (level >= 1)
-                    OKR(launch_level_project(st, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, nullptr,
-                                             ws + f.po, Dp, OH, ws + f.nrmo));
-                else {
-                    hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
-                                       p.normalize, OH, ws + f.nrmo);
-                    LAUNCHOK("level_finish(out)");
-                }
-                continue;
-            }
+            const int ncell = B * g.Lc;
+            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi,
+                               OH, IS, OS, ws + f.sp, ws + f.pp, OS);
+            LAUNCHOK("pair_scores_fwd(out)");
+            int SP = 1;
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                OKR(launch_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, nrows,
-                                ComposeXA{dv.arow, dv.brow, g.rowbase, ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.x, Dp},
-                                StoreRowsE{ws + f.y + (size_t)g.rowbase * Dp, Dp, ws + f.b2o, 2, Dp}));
+                OKR(launch_level_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true),
+                                         ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HP, hp_stride, YM, PH, &SP));
             }
-            hipLaunchKernelGGL(cell_scores_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow,
-                               ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS, ws + f.sp, ws + f.pp, OS, ws + f.y, p.normalize, OH,
-                               ws + f.nrmo);
-            LAUNCHOK("cell_scores_aggregate_fwd(out)");
             if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
-                                StoreLevelE{ws + f.po, Dp, C, g.off, g.Lc, nullptr, 0}));
+                OKR(launch_level_project(st, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, nullptr,
+                                         ws + f.po, Dp, OH, ws + f.nrmo));
+            else {
+                hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
+                                   p.normalize, OH, ws + f.nrmo);
+                LAUNCHOK("level_finish(out)");
+            }
         }
     } else {
         HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
@@ -353,8 +370,19 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const float* X = padded ? ws + f.xp : x_span;
     float *VH = wb + bw.vh, *dG = wb + bw.dg, *dStot = wb + bw.dstot, *DA = wb + bw.da, *DS = wb + bw.ds;
     float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
-    const float *Y = ws + f.y, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *Xp = ws + f.x;
-    float* DZ = wb + bw.dz;
+    const float *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi;
+    float *DZ = wb + bw.dz, *Xp = wb + bw.x, *DPP = wb + bw.dpp;
+    const uint32_t* YM = reinterpret_cast<const uint32_t*>(ws + f.ymask);
+    auto pair_level = [&](int level, bool outside_pass) {
+        const LevelArgs g = level_args(p, level, outside_pass);
+        const int32_t* t = p.d_tables;
+        const size_t base = outside_pass ? p.lvl_base_out[level] : p.lvl_base_in[level];
+        PairLevel lv;
+        lv.pa = t + (outside_pass ? p.dev.pair_a_out : p.dev.pair_a_in) + base;
+        lv.pb = t + (outside_pass ? p.dev.pair_b_out : p.dev.pair_b_in) + base;
+        lv.Lc = g.Lc; lv.N = g.N; lv.C = C; lv.ncell = B * g.Lc; lv.rowbase = g.rowbase; lv.off = g.off;
+        return lv;
+    };
     const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
     // CLIORA: the unit-norm / softmax backward of the inside cells works on u = unit(aggregate), not on h
     const float* IHn = vl ? ws + f.att_u : IH;
@@ -363,7 +391,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     if (ran_outside) {
         for (int level = 0; level <= L - 1; ++level) {
             const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
-            const int ncell = B * g.Lc, nrows = ncell * g.N;
+            const int ncell = B * g.Lc;
             hipLaunchKernelGGL(cell_gather_bwd_out, dim3(ncell), dim3(256), 0, st, g, D, d_outside_h,
                                level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
             LAUNCHOK("cell_gather_bwd_out");
@@ -375,14 +403,16 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                 LAUNCHOK("root_bwd");
                 break;
             }
-            hipLaunchKernelGGL(cell_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, Y, Sp, Pp,
-                               OS, dStot, dG, DS);
-            LAUNCHOK("cell_scores_bwd(out)");
+            hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, dG);
+            LAUNCHOK("cell_dnorm(out)");
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-                OKR(launch_compose(st, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
-                                ComposeBwdE{Xp, DA, g.rowbase, Dp}));
+                OKR(launch_level_compose_bwd(st, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dG, YM, Pp,
+                                             PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, DA, DZ, Xp, DPP));
             }
+            hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, f.ct3, dG, ws + f.b2o, YM, DPP, Sp, Pp, OS,
+                               dStot, DS);
+            LAUNCHOK("cell_dsoftmax(out)");
         }
         if (!p.share) {
             ProfScope ps(CLIORA_KCLASS_WGRAD, st);
@@ -400,7 +430,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
 
     for (int level = L - 1; level >= 0; --level) {
         const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        const int ncell = B * g.Lc;
         hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, st, g, D, d_inside_h,
                            level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside,
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
@@ -414,14 +444,16 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("cell_attend_bwd");
         }
         if (level == 0) break;
-        hipLaunchKernelGGL(cell_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, Y, Sp, Pp, IS,
-                           dStot, dG, DS);
-        LAUNCHOK("cell_scores_bwd(in)");
+        hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, dG);
+        LAUNCHOK("cell_dnorm(in)");
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-            OKR(launch_compose(st, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, nrows, ComposeDzA{dv.trow, g.rowbase, dG, Y, Pp, Dp, DZ},
-                            ComposeBwdE{Xp, DA, g.rowbase, Dp}));
+            OKR(launch_level_compose_bwd(st, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
+                                         PI + Dp, ldpi, DA, DZ, Xp, DPP));
         }
+        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, f.ct3, dG, ws + f.b2i, YM, DPP, Sp, Pp, IS,
+                           dStot, DS);
+        LAUNCHOK("cell_dsoftmax(in)");
     }
     // leaves
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);

@@ -37,57 +37,109 @@ constexpr int LC_SLOTS = 4;   // LDS slots of the cross-wave reduction (one per 
 //   grid.x walks TASKS = (group of TG cell tiles) x (part s of SP of the split range).  The 8 waves of the workgroup are
 //   dealt WPG = 8 / TG waves per cell tile; wave r of a cell tile takes the splits n0 + r, n0 + r + WPG, ... and keeps
 //   sum p_n y_n in registers; the WPG partial sums meet in LDS in a fixed tree order.  Output: HP[s][chart row][Dp] (partial
-//   aggregates, summed over s by level_project), the ReLU bits of y, and on request the y rows (hooks) / x rows.
+//   aggregates, summed over s by level_project), the ReLU bits of y, and on request the y rows (hooks).
 //   Operand rows are fetched in the quad-coalesced lane map and moved to the MFMA lanes by ds_bpermute (gemm_kernels.hpp).
 // ---------------------------------------------------------------------------------
-template <int CT, int K16, bool SIDE>
+// F32 = true: the exact-fp32 arithmetic mode (cliora_set_mfma_mode): the LDS image is the plain fp32 weight block ([CT*16][K],
+// passed through Wimg with S_ = K) and a 32-deep k-step is eight v_mfma_f32_16x16x4_f32 per column tile instead of three bf16 ones.
+template <int CT, bool F32>
+__device__ __forceinline__ void kstep_mfma(const uint32_t* wimg, int i, int g, int S, int half, int st, bool second, const float4& a0,
+                                           const float4& a1, f32x4 (&acc)[CT]) {
+    if constexpr (F32) {
+        const float* wf = reinterpret_cast<const float*>(wimg) + i * S + 4 * g + 32 * st;
+        float4 b0[CT], b1[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            b0[c] = *reinterpret_cast<const float4*>(wf + c * 16 * S);
+            b1[c] = second ? *reinterpret_cast<const float4*>(wf + c * 16 * S + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].x, a0.x, acc[c]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].y, a0.y, acc[c]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].z, a0.z, acc[c]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].w, a0.w, acc[c]);
+        if (second) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].x, a1.x, acc[c]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].y, a1.y, acc[c]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].z, a1.z, acc[c]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].w, a1.w, acc[c]);
+        }
+    } else {
+        const uint32_t* wfrag = wimg + i * S + 4 * g;
+        u32x4 xh, xl;
+        split_bf16x8(a0, a1, xh, xl);
+        u32x4 wh[CT], wl[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            wh[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st);
+            wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], xh, acc[c]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xl, acc[c]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xh, acc[c]);
+    }
+}
+
+// the block's weight image -> LDS (LDS-DMA, lane-linear); the caller waits (vmcnt(0) + barrier) before the first use
+__device__ __forceinline__ void stage_weight_image(const uint32_t* src, uint32_t* lds, int ndwords, int wave, int lane, int nthreads) {
+    const int n16 = ndwords / 4;
+    for (int e0 = wave * 64; e0 < n16; e0 += nthreads) {
+        const int e = e0 + lane;
+        if (e < n16)
+            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)e * 4), (__attribute__((address_space(3))) void*)(lds + e0 * 4), 16, 0, 0);
+    }
+}
+
+template <int CT, int K16, bool F32>
 __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
                                                          const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
                                                          const float* __restrict__ bias, const float* __restrict__ Pp,
                                                          int TG, int SP, int ntask, float* __restrict__ HP, size_t hp_stride, int Dp,
-                                                         uint32_t* __restrict__ ymask, float* __restrict__ Y, float* __restrict__ X) {
+                                                         uint32_t* __restrict__ ymask, float* __restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
     constexpr int WAVES = 8, T = WAVES * 64, PD = 4;
     constexpr bool KS = K16 > 0;
     constexpr int UNROLL_STEPS = KS ? 64 : 1;
     const int K = KS ? K16 * 16 : K_;
-    const int S = KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_;
+    const int S = F32 ? K : (KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_);     // row stride of the LDS image in dwords
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
-    const int Kp = S - WS3_PAD, half = Kp >> 1;
+    const int Kp = F32 ? (K + 31) / 32 * 32 : S - WS3_PAD, half = Kp >> 1;
     const int by = blockIdx.y, gy = gridDim.y;
     const int col0 = by * (CT * 16);
-    {   // the block's weight image -> LDS (LDS-DMA, lane-linear); waited for below, after the first row contexts are on their way
-        const uint32_t* src = Wimg + (size_t)col0 * S;
-        const int n16 = CT * 16 * S / 4;
-        for (int e0 = wave * 64; e0 < n16; e0 += T) {
-            const int e = e0 + lane;
-            if (e < n16)
-                __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)e * 4),
-                                                 (__attribute__((address_space(3))) void*)(lds_img + e0 * 4), 16, 0, 0);
-        }
-    }
+    // waited for below, after the first row contexts are on their way
+    stage_weight_image(Wimg + (size_t)col0 * S, lds_img, CT * 16 * S, wave, lane, T);
     float4* red = reinterpret_cast<float4*>(lds_img + CT * 16 * S);      // [LC_SLOTS][CT][64]
     float4 bv[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) bv[c] = ld4(bias + col0 + c * 16 + 4 * g);
     const int nsteps = Kp >> 5;
     const int nsteps_p = (nsteps + PD - 1) / PD * PD;
-    int wfrag_off = i * S + 4 * g;
+    int wimg_off = 0;
     const int WPG = WAVES / TG;                      // waves per cell tile (1, 2, 4 or 8)
     const int j = wave / WPG, r = wave - j * WPG;
     const int G = (lv.ncell + 15) >> 4;
     const int Ns = (lv.N + SP - 1) / SP;
 
-    struct Ctx { const float *pa, *pb; float* xo; };
+    struct Ctx { const float *pa, *pb; };
     auto rowctx = [&](int gt, int n) {               // fetch-lane view of tile (gt, n)
         const int t = min(gt * 16 + li, lv.ncell - 1);            // clamp: computed, masked out by p = 0 and never stored
         const int b = t / lv.Lc, p = t - b * lv.Lc;
         const int idx = p * lv.N + n;
         const size_t ca = (size_t)b * lv.C + lv.pa[idx], cb = (size_t)b * lv.C + lv.pb[idx];
-        return Ctx{PA + ca * lda, PB + cb * ldb, SIDE ? X + ((size_t)lv.rowbase + (size_t)t * lv.N + n) * Dp : nullptr};
+        return Ctx{PA + ca * lda, PB + cb * ldb};
     };
     Raw2 ra[PD][2];
     auto issue = [&](int slot, const Ctx& c, int s) {
@@ -132,9 +184,8 @@ __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restr
                 f32x4 acc[CT];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                asm volatile("" : "+v"(wfrag_off));          // keep the weight-fragment LDS reads inside the tile loop
-                const uint32_t* wfrag = lds_img + wfrag_off;
-                int side_turn = 0;
+                asm volatile("" : "+v"(wimg_off));           // keep the weight-fragment LDS reads inside the tile loop
+                const uint32_t* wimg = lds_img + wimg_off;
 #pragma unroll UNROLL_STEPS
                 for (int base = 0; base < nsteps_p; base += PD) {
 #pragma unroll
@@ -144,27 +195,8 @@ __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restr
                             const bool second = 32 * st + 16 < K;
                             const float4 f0 = relu_add(ra[sl][0]);
                             const float4 f1 = relu_add(ra[sl][1]);   // beyond K: a second copy of the first run, zero weights in the image
-                            if (SIDE && side_turn == by) {
-                                const int k = 32 * st + 4 * lg;
-                                st4(ctx.xo + k, f0);
-                                if (second) st4(ctx.xo + k + 16, f1);
-                            }
-                            side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
                             const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
-                            u32x4 xh, xl;
-                            split_bf16x8(a0, a1, xh, xl);
-                            u32x4 wh[CT], wl[CT];
-#pragma unroll
-                            for (int c = 0; c < CT; ++c) {
-                                wh[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st);
-                                wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
-                            }
-#pragma unroll
-                            for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], xh, acc[c]);
-#pragma unroll
-                            for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xl, acc[c]);
-#pragma unroll
-                            for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xh, acc[c]);
+                            kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, a0, a1, acc);
                         }
                         const int nst = st + PD;
                         const bool in_cur = nst < nsteps;
@@ -361,6 +393,211 @@ __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, in
     if (lane < nv) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
     if (lane + 64 < nv) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
     if (lane == 0) nrm[crow] = nr;
+}
+
+// ---------------------------------------------------------------------------------
+// Backward of one level's compose layer.  Per tile (16 target cells t, one split n), with dG = d loss / d g (the aggregate):
+//   A rows    dzu = dG[t] masked by the ReLU bits of y_n            (K = the z dimension; p_n is applied afterwards)
+//   GEMM      u = dzu W2                                              (W2^T block stays in LDS)
+//   epilogue  xs = PL(a) + PR(b) for the block's columns (re-gathered: x is not kept by the forward), x = relu(xs)
+//             DA  = p_n u [xs > 0]      -> the per-pair gradient the cell gathers sum (cell_gather_bwd_*)
+//             X   = x, DZ = p_n dzu     -> operands of the weight gradient dW2 = DZ^T X (DZ from the fetch lanes, 1/gridDim.y each)
+//             DPP[row][block] = sum over the block's columns of u x: since y = relu(z), dG . y_n = (dG masked) . z_n
+//                                = u . x_n + (dG masked) . b2  -- the softmax backward gets its dp_n without y_n (cell_dsoftmax)
+// Tiles are independent here (no reduction over the splits): waves walk the level's tiles (g-major) with a stride.
+// ---------------------------------------------------------------------------------
+template <int CT, int K16, bool F32>
+__global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
+                                                         const float* __restrict__ dG, const uint32_t* __restrict__ ymask,
+                                                         const float* __restrict__ Pp, const float* __restrict__ PA, int lda,
+                                                         const float* __restrict__ PB, int ldb, int Dp, float* __restrict__ DA,
+                                                         float* __restrict__ DZ, float* __restrict__ X, float* __restrict__ DPP) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    constexpr int WAVES = 8, T = WAVES * 64, PD = 4;
+    constexpr bool KS = K16 > 0;
+    constexpr int UNROLL_STEPS = KS ? 64 : 1;
+    const int K = KS ? K16 * 16 : K_;
+    const int S = F32 ? K : (KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int Kp = F32 ? (K + 31) / 32 * 32 : S - WS3_PAD, half = Kp >> 1;
+    const int by = blockIdx.y, gy = gridDim.y;
+    const int col0 = by * (CT * 16);
+    stage_weight_image(Wimg + (size_t)col0 * S, lds_img, CT * 16 * S, wave, lane, T);
+    const int nsteps = Kp >> 5;
+    const int nsteps_p = (nsteps + PD - 1) / PD * PD;
+    int wimg_off = 0;
+    const int G = (lv.ncell + 15) >> 4;
+    const int ntiles = G * lv.N;
+    const int stride = gridDim.x * WAVES;
+
+    struct Ctx { const float* gp; const uint32_t* mp; float* zo; float pn; };
+    auto rowctx = [&](int tile) {                    // fetch-lane view of tile = gt * N + n
+        const int gt = tile / lv.N, n = tile - gt * lv.N;
+        const int t = min(gt * 16 + li, lv.ncell - 1);
+        const int b = t / lv.Lc, p = t - b * lv.Lc;
+        const size_t prow = (size_t)lv.rowbase + (size_t)t * lv.N + n;
+        return Ctx{dG + ((size_t)b * lv.C + lv.off + p) * Dp, ymask + prow * gy * 4 + lg, DZ + prow * Dp, Pp[prow]};
+    };
+    struct Slot { float4 g0, g1; uint32_t m0, m1; };
+    Slot ra[PD];
+    auto issue = [&](int slot, const Ctx& c, int s) {
+        const int k = 32 * s + 4 * lg;
+        const bool second = 32 * s + 16 < K;
+        const int k2 = k + (second ? 16 : 0);
+        ra[slot].g0 = ld4(c.gp + k);
+        ra[slot].g1 = ld4(c.gp + k2);
+        // column k of z lives in column block k / (CT*16), 16-column tile (k / 16) % CT, word g = (k % 16) / 4 = lg
+        ra[slot].m0 = c.mp[((2 * s) / CT) * 4];
+        ra[slot].m1 = c.mp[((2 * s + (second ? 1 : 0)) / CT) * 4];
+    };
+    auto masked = [](const float4& v, uint32_t nib) {
+        return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
+    };
+
+    int tile = blockIdx.x * WAVES + wave;
+    const bool work = tile < ntiles;
+    Ctx ctx = rowctx(work ? tile : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!work) return;
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) issue(sl, ctx, sl < nsteps ? sl : 0);
+    while (true) {
+        const int ntile = tile + stride;
+        const bool has_next = ntile < ntiles;
+        const Ctx ctxn = rowctx(has_next ? ntile : tile);
+        // MFMA-lane view: row i = target cell ti; its operand cells for the epilogue re-gather of xs = PL(a) + PR(b)
+        const int gt = tile / lv.N, n = tile - gt * lv.N;
+        const int ti = gt * 16 + i;
+        const bool ok = ti < lv.ncell;
+        const int tc = min(ti, lv.ncell - 1);
+        const int eb = tc / lv.Lc, ep = tc - eb * lv.Lc;
+        const size_t prow = (size_t)lv.rowbase + (size_t)tc * lv.N + n;
+        const float pn = Pp[prow];
+        const float* xa = PA + ((size_t)eb * lv.C + lv.pa[ep * lv.N + n]) * lda + col0 + 4 * g;
+        const float* xb = PB + ((size_t)eb * lv.C + lv.pb[ep * lv.N + n]) * ldb + col0 + 4 * g;
+        f32x4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(wimg_off));
+        const uint32_t* wimg = lds_img + wimg_off;
+        int side_turn = 0;
+#pragma unroll UNROLL_STEPS
+        for (int base = 0; base < nsteps_p; base += PD) {
+#pragma unroll
+            for (int sl = 0; sl < PD; ++sl) {
+                const int st = base + sl;
+                if (st < nsteps) {
+                    const bool second = 32 * st + 16 < K;
+                    const float4 f0 = masked(ra[sl].g0, ra[sl].m0 >> (4 * ((2 * st) % CT)));
+                    const float4 f1 = masked(ra[sl].g1, ra[sl].m1 >> (4 * ((2 * st + (second ? 1 : 0)) % CT)));
+                    if (side_turn == by) {
+                        const int k = 32 * st + 4 * lg;
+                        st4(ctx.zo + k, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
+                        if (second) st4(ctx.zo + k + 16, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
+                    }
+                    side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
+                    const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
+                    kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, a0, a1, acc);
+                }
+                const int nst = st + PD;
+                const bool in_cur = nst < nsteps;
+                issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
+                __builtin_amdgcn_sched_barrier(0);          // keep the refill here (see level_compose_fwd)
+            }
+        }
+        // epilogue
+        float dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float4 pa4 = ld4(xa + c * 16), pb4 = ld4(xb + c * 16);
+            const float xs0 = pa4.x + pb4.x, xs1 = pa4.y + pb4.y, xs2 = pa4.z + pb4.z, xs3 = pa4.w + pb4.w;
+            const float4 x = make_float4(fmaxf(xs0, 0.f), fmaxf(xs1, 0.f), fmaxf(xs2, 0.f), fmaxf(xs3, 0.f));
+            dp = fmaf(acc[c][0], x.x, dp); dp = fmaf(acc[c][1], x.y, dp); dp = fmaf(acc[c][2], x.z, dp); dp = fmaf(acc[c][3], x.w, dp);
+            if (ok) {
+                const size_t o = prow * Dp + col0 + c * 16 + 4 * g;
+                st4(DA + o, make_float4(x.x > 0.f ? pn * acc[c][0] : 0.f, x.y > 0.f ? pn * acc[c][1] : 0.f,
+                                        x.z > 0.f ? pn * acc[c][2] : 0.f, x.w > 0.f ? pn * acc[c][3] : 0.f));
+                st4(X + o, x);
+            }
+        }
+        dp += __shfl_xor(dp, 16);
+        dp += __shfl_xor(dp, 32);
+        if (ok && g == 0) DPP[prow * gy + by] = dp;
+        if (!has_next) break;
+        ctx = ctxn;
+        tile = ntile;
+    }
+}
+
+// dG = unit-norm backward of the level's cells: the gradient with respect to the aggregate g (H = g / max(||g||, eps)).
+// One wave per cell.  CLIORA passes u = unit(g) and ||g|| (the attention residual sits between g and H).
+static __global__ __launch_bounds__(256) void cell_dnorm(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ H,
+                                                         const float* __restrict__ nrm, int normalize, float* __restrict__ dG) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
+    if (a0) { v0 = ld4(VH + crow * Dp + 4 * lane); h0 = ld4(H + crow * Dp + 4 * lane); }
+    if (a1) { v1 = ld4(VH + crow * Dp + 4 * (lane + 64)); h1 = ld4(H + crow * Dp + 4 * (lane + 64)); }
+    unit_norm_bwd(v0, v1, h0, h1, nrm[crow], normalize);
+    if (a0) st4(dG + crow * Dp + 4 * lane, v0);
+    if (a1) st4(dG + crow * Dp + 4 * (lane + 64), v1);
+}
+
+// Softmax / score backward of the level's cells (diora.py:125-149 differentiated), one wave per cell:
+//   dp_n = sum_blocks DPP[row][block] + sum_j dG_j b2_j [y_nj > 0]      (= dG . y_n, see level_compose_bwd)
+//   ds_n = p_n [ (dp_n - sum_m p_m dp_m) + dS_tot (1 + s_n - S) ]
+// ymask word w of a pair row covers columns (w / 4) * ct * 16 + tile * 16 + (w % 4) * 4 + j, bit tile * 4 + j.
+static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb, int ct, const float* __restrict__ dG, const float* __restrict__ b2,
+                                                            const uint32_t* __restrict__ ymask, const float* __restrict__ DPP,
+                                                            const float* __restrict__ Sp, const float* __restrict__ Pp,
+                                                            const float* __restrict__ Schart, const float* __restrict__ dStot,
+                                                            float* __restrict__ DS) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.B * g.Lc || g.N == 0) return;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    const size_t row0 = (size_t)g.rowbase + (size_t)t * g.N;
+    const int nw = ncb * 4;
+    float bias_dot = 0.f;                            // lane n ends up with (dG masked by y_n) . b2
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const int w = w0 + lane;
+        const bool aw = w < nw;
+        float q[20];                                 // dG_j b2_j of the word's columns (ct <= 5 tiles x 4)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int col = (w >> 2) * ct * 16 + c * 16 + (w & 3) * 4;
+            float4 gq = f4zero(), bq = f4zero();
+            if (aw && c < ct) { gq = ld4(dG + crow * g.Dp + col); bq = ld4(b2 + col); }
+            q[4 * c + 0] = gq.x * bq.x; q[4 * c + 1] = gq.y * bq.y; q[4 * c + 2] = gq.z * bq.z; q[4 * c + 3] = gq.w * bq.w;
+        }
+        for (int n = 0; n < g.N; ++n) {
+            const uint32_t m = aw ? ymask[(row0 + n) * nw + w] : 0u;
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) sacc += ((m >> k) & 1u) ? q[k] : 0.f;
+            sacc = wave_sum(sacc);
+            if (lane == n) bias_dot += sacc;
+        }
+    }
+    const bool an = lane < g.N;
+    float dp = an ? bias_dot : 0.f;
+    if (an)
+        for (int cb = 0; cb < ncb; ++cb) dp += DPP[(row0 + lane) * ncb + cb];
+    const float pn = an ? Pp[row0 + lane] : 0.f;
+    const float sn = an ? Sp[row0 + lane] : 0.f;
+    const float mean = wave_sum(pn * dp);
+    const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + sn - Schart[crow]));
+    if (an) DS[row0 + lane] = ds;
 }
 
 }  // namespace cliora

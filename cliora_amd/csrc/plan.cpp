@@ -157,8 +157,8 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.t = take(BL * nlf * Dp);
         f.pi = take(BC * nb * Dp);
         f.po = take(BC * npo * Dp);
-        f.y = take(Rt * Dp);
-        f.x = take(Rt * Dp);
+        f.y = take(lstm * Rt * Dp);
+        f.x = take(lstm * Rt * Dp);
         f.sp = take(Rt);
         f.pp = take(Rt);
         {   // column block of the weight-stationary compose kernels: the most 16-column tiles whose split-bf16 image
@@ -179,6 +179,8 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
         f.total = o;
+        f.pair_h = o;                               // optional tail (hooks)
+        f.pair_h_floats = arch == 0 ? align64(Rt * Dp) : 0;
     }
     {
         BwdLayout& b = p.bwd;
@@ -187,6 +189,8 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
         b.da = take(Rt * (lstm ? 5 : 1) * Dp); b.ds = take(Rt);
         b.dz = take(Rt * Dp);
+        b.x = take(arch == 0 ? Rt * Dp : 0);
+        b.dpp = take(arch == 0 ? Rt * p.fwd.ncb3 : 0);
         b.dcb = take(lstm * Rt * Dp); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);
         b.dpi = take(BC * nb * Dp); b.dpo = take(BC * npo * Dp);
         b.du = take(BL * nlf * Dp); b.dxp = take(padded ? BL * Dp : 0);

@@ -43,8 +43,9 @@ struct FwdLayout {
     size_t objp;                        // padded obj (CLIORA, D != Dp)
     size_t t;                           // leaf tanh output (B*L x Dp)
     size_t pi, po;                      // projections of inside cells (B*C x nblk*Dp) / outside cells (B*C x Dp)
-    size_t y;                           // per-pair compose output (R x Dp)
-    size_t x;                           // per-pair first-layer activation relu(PL+PR) (R x Dp)
+    size_t y, x;                        // TreeLSTM only: per-pair h and c (R x Dp each).  DioraMLP keeps no per-pair rows
+    size_t pair_h;                      // DioraMLP hooks: per-pair compose outputs (R x Dp) in the OPTIONAL tail of the workspace (beyond `total`)
+    size_t pair_h_floats;               // size of that tail
     size_t sp, pp;                      // per-pair score / softmax weight (R)
     size_t hp;                          // partial aggregates of level_compose_fwd: HP_PARTS x (B*C x Dp), summed by level_project
     size_t ymask;                       // ReLU bits of the compose output y: R x ncb3 x 4 words (word g of a column block: 4 bits per 16-column tile)
@@ -59,6 +60,8 @@ struct BwdLayout {
     size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C)
     size_t da, ds;                      // per-pair grads (R x Dp), (R)
     size_t dz;                          // per-pair grad at the second pre-activation (R x Dp); TreeLSTM: d c_a per pair
+    size_t x;                           // DioraMLP: per-pair first-layer activation relu(PL+PR) (R x Dp), re-formed by level_compose_bwd for the weight gradient
+    size_t dpp;                         // DioraMLP: partial dG.y_n per pair row and column block (R x ncb3)
     size_t dcb, vc, dgc, grootc;        // TreeLSTM: d c_b per pair (R x Dp), cell-state grads per cell (B*C x Dp) x2, d root c
     size_t dpi, dpo;                    // grads of the projections
     size_t du, dxp;                     // leaf pre-activation grad, padded dx

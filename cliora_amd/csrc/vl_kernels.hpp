@@ -33,7 +33,10 @@ struct PairScoreArgs {
     float *Sp, *Pp, *Sout;
 };
 
+// HP != nullptr: the aggregate g = sum_n p_n y_n of the level's cells comes from level_compose_fwd as SP partial rows (HP), the
+// scores from pair_scores_fwd (Y, Pp and the fused scoring are then unused).
 static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, PairScoreArgs sc, const float* __restrict__ Y, const float* __restrict__ Pp,
+                                                       const float* __restrict__ HP, size_t hp_stride, int SP,
                                                        const float* __restrict__ T, const float* __restrict__ OBJ, int R,
                                                        const float* __restrict__ mask, int normalize,
                                                        float* __restrict__ H, float* __restrict__ nrmV, float* __restrict__ U,
@@ -64,6 +67,12 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
         if (a0) v0 = ld4(s + c0);
         if (a1) v1 = ld4(s + c1);
         if (tid == 0) S[crow] = 0.f;
+    } else if (HP) {                                  // every wave reads the whole (pre-aggregated) row: parts added in order
+        for (int sp = 0; sp < SP; ++sp) {
+            const float* src = HP + (size_t)sp * hp_stride + crow * Dp;
+            if (a0) v0 = f4add(v0, ld4(src + c0));
+            if (a1) v1 = f4add(v1, ld4(src + c1));
+        }
     } else {
         const int row0 = g.rowbase + t * g.N;
         const bool fused = sc.arow != nullptr;        // uniform

@@ -56,11 +56,12 @@ class ChartFunction(torch.autograd.Function):
             inside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
             outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
             outside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
-            ws = torch.empty(plan.fwd_bytes, device=dev, dtype=torch.uint8)
+            nbytes = plan.fwd_bytes + (plan.pair_bytes if int(run_outside) & _lib.FWD_PAIR_STATES else 0)
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             pst = _param_struct(ptens)
             rc = _lib.lib().cliora_chart_forward(
                 plan.handle, C.byref(pst), _ptr(x_span), None, None, _ptr(inside_h), _ptr(inside_s),
-                _ptr(outside_h), _ptr(outside_s), None, _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
+                _ptr(outside_h), _ptr(outside_s), None, _ptr(ws), nbytes, int(run_outside), _stream())
             _lib.check(rc, 'cliora_chart_forward')
         ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside) & 1, ws, ptens
         ctx.save_for_backward(x_span, inside_h, inside_s, outside_h, outside_s)
@@ -224,7 +225,7 @@ class DioraBase(nn.Module):
         params = self._param_tensors()
         needs_grad = torch.is_grad_enabled() and (x_span.requires_grad or any(t is not None and t.requires_grad for t in params))
         hooks = self._hook_overridden('inside_hook') or self._hook_overridden('outside_hook')
-        flags = int(bool(self.outside)) | (0 if (needs_grad or hooks) else _lib.FWD_NO_BACKWARD)
+        flags = int(bool(self.outside)) | (0 if needs_grad else _lib.FWD_NO_BACKWARD) | (_lib.FWD_PAIR_STATES if hooks else 0)
         ih, is_, oh, os_ = ChartFunction.apply(plan, holder, flags, x_span, *params)
         ch = Chart()
         ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s = ih, is_, oh, os_

@@ -100,6 +100,11 @@ int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t**
  * run_outside is a flag word: bit 0 = run the outside pass; CLIORA_FWD_NO_BACKWARD = no backward call will follow
  * (torch.no_grad / eval): the per-pair state the backward needs is not written (hooks need the default). */
 #define CLIORA_FWD_NO_BACKWARD 2
+/* CLIORA_FWD_PAIR_STATES: also write the un-aggregated compose outputs of every pair (what inside_hook / outside_hook receive,
+ * diora.py:295-334, 364-398) into the TAIL of the workspace: the caller then passes a workspace of
+ * cliora_plan_fwd_workspace_bytes() + cliora_plan_pair_states_bytes() bytes.  Without it no per-pair vector is stored. */
+#define CLIORA_FWD_PAIR_STATES 4
+size_t cliora_plan_pair_states_bytes(const cliora_plan* plan);
 int cliora_chart_forward(cliora_plan* plan, const cliora_params* params,
                          const float* x_span, const float* obj_span, const float* drop_mask,
                          float* inside_h, float* inside_s, float* outside_h, float* outside_s,
@@ -164,7 +169,8 @@ int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_h, const fl
  * for `level`: scores = (B, L-level, level) laid out exactly like the reference's
  * s.view(B, Lc, N, 1); h = the compose outputs, `rows` = B*(L-level)*level rows of D
  * valid floats with row stride `ldh`, same row order as the reference's h (M, D).
- * Both are device pointers into the fwd workspace. */
+ * Both are device pointers into the fwd workspace (h: into its CLIORA_FWD_PAIR_STATES tail; the forward must have run
+ * with that flag). */
 int cliora_inside_pair_states(const cliora_plan* plan, void* fwd_workspace, int level,
                               const float** scores, const float** h, size_t* rows, size_t* ldh);
 

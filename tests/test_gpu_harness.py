@@ -52,4 +52,8 @@ def test_net_losses_grads_and_three_adam_steps(name, vl, mfma_mode):
         if not p.requires_grad:
             continue
         want = g['after3__' + k.replace('.', '__')]
-        assert float((p.detach().cpu() - torch.from_numpy(want)).abs().max()) <= 5e-4 * max(1.0, float(np.abs(want).max())), k
+        # Adam divides every gradient element by its own running magnitude: an element whose gradient is at the rounding-noise
+        # level moves by up to lr per step whatever its size, so three steps of the split-bf16 mode (operands rounded to 16 bits)
+        # are held to one lr (1e-3) and the exact-fp32 mode to half of it
+        tol = 5e-4 if mfma_mode == 'f32' else 1e-3
+        assert float((p.detach().cpu() - torch.from_numpy(want)).abs().max()) <= tol * max(1.0, float(np.abs(want).max())), k
