@@ -24,6 +24,8 @@ struct cliora_plan {
     Plan p;
     bool uploaded = false;
     int device = -1;            // HIP device the index tables live on (set at upload; every later call must run there)
+    hipStream_t side = nullptr; // side stream of the backward: weight-gradient GEMMs run beside the level chain (fork / join by events)
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
 };
 
 extern thread_local std::string g_cliora_err;

@@ -78,8 +78,8 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
 
 template <int CT, int K16, bool F32>
 static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* dG,
-                                         const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB, int ldb,
-                                         float* DA, float* DZ, float* X, float* DPP) {
+                                         const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB, int ldb, const float* b2,
+                                         float* DA, float* DZ, float* X, float* DPP, float* DPB) {
     OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32>));
     const int ntiles = (lv.ncell + 15) / 16 * lv.N;
     const int cap = std::max(1, 256 / ncb);
@@ -87,7 +87,7 @@ static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, i
     int gx = (ntiles + 8 * passes - 1) / (8 * passes);
     if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;      // column blocks of the same tiles on one XCD
     hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false), st, Wimg, S, K, lv, dG, ymask,
-                       Pp, PA, lda, PB, ldb, K, DA, DZ, X, DPP);
+                       Pp, PA, lda, PB, ldb, b2, K, DA, DZ, X, DPP, DPB);
     LAUNCHOK("level_compose_bwd");
     return CLIORA_OK;
 }
@@ -95,12 +95,12 @@ static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, i
 // backward of the level's compose layer: DA, DZ, X rows and the partial dG.y_n (see level_compose_bwd).  WT: plain fp32 W2^T.
 static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float* WTimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
                                     const float* dG, const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB,
-                                    int ldb, float* DA, float* DZ, float* X, float* DPP) {
+                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB) {
     if (lv.N <= 0 || lv.ncell <= 0) return CLIORA_OK;
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? WT : WTimg);
     const int S = f32 ? Dp : S3;
-#define LB_ARGS st, I, S, Dp, ncb, lv, dG, ymask, Pp, PA, lda, PB, ldb, DA, DZ, X, DPP
+#define LB_ARGS st, I, S, Dp, ncb, lv, dG, ymask, Pp, PA, lda, PB, ldb, b2, DA, DZ, X, DPP, DPB
 #define LB_CASE(c, k16) return f32 ? launch_level_compose_bwd_inst<c, k16, true>(LB_ARGS) : launch_level_compose_bwd_inst<c, k16, false>(LB_ARGS)
     if (ct == 5 && Dp == 400) LB_CASE(5, 25);
     switch (ct) {
@@ -371,7 +371,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     float *VH = wb + bw.vh, *dG = wb + bw.dg, *dStot = wb + bw.dstot, *DA = wb + bw.da, *DS = wb + bw.ds;
     float *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
     const float *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi;
-    float *DZ = wb + bw.dz, *Xp = wb + bw.x, *DPP = wb + bw.dpp;
+    float *DZ = wb + bw.dz, *Xp = wb + bw.x, *DPP = wb + bw.dpp, *DPB = wb + bw.dpb;
     const uint32_t* YM = reinterpret_cast<const uint32_t*>(ws + f.ymask);
     auto pair_level = [&](int level, bool outside_pass) {
         const LevelArgs g = level_args(p, level, outside_pass);
@@ -408,10 +408,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
                 OKR(launch_level_compose_bwd(st, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dG, YM, Pp,
-                                             PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, DA, DZ, Xp, DPP));
+                                             PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB));
             }
-            hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, f.ct3, dG, ws + f.b2o, YM, DPP, Sp, Pp, OS,
-                               dStot, DS);
+            hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStot, DS);
             LAUNCHOK("cell_dsoftmax(out)");
         }
         if (!p.share) {
@@ -419,8 +418,13 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             OKR(launch_tn_pairs(st, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
                                 wb + bw.gw2o, wb + bw.gb2o));
         }
-        OKR(launch_tn(st, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+        // dW of the outside-cell projection does not feed the inside chain and needs no LDS: it runs on the side stream beside
+        // the (LDS-bound) level kernels.  The pair weight gradient (tn_gemm_dma3) fills every CU's LDS, so it stays in line.
+        HIPOK(hipEventRecord(plan->ev_fork[0], st));
+        HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[0], 0));
+        OKR(launch_tn(plan->side, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gw1ro,
                       (float*)nullptr));
+        HIPOK(hipEventRecord(plan->ev_join[0], plan->side));
     } else {
         HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
@@ -449,10 +453,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
             OKR(launch_level_compose_bwd(st, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
-                                         PI + Dp, ldpi, DA, DZ, Xp, DPP));
+                                         PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB));
         }
-        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, f.ct3, dG, ws + f.b2i, YM, DPP, Sp, Pp, IS,
-                           dStot, DS);
+        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
         LAUNCHOK("cell_dsoftmax(in)");
     }
     // leaves
@@ -460,6 +463,13 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
         OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
+    // weight gradients of the cell projections and of the leaf layer on the side stream, the inside pair rows' dW2 here
+    HIPOK(hipEventRecord(plan->ev_fork[1], st));
+    HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[1], 0));
+    OKR(launch_tn(plan->side, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwcat,
+                  wb + bw.gbcat));
+    OKR(launch_tn(plan->side, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
+    HIPOK(hipEventRecord(plan->ev_join[1], plan->side));
     {
         // shared weights: inside and outside pair rows are one contiguous range -> one launch
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);
@@ -470,9 +480,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
         }
     }
-    OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat,
-                  wb + bw.gbcat));
-    OKR(launch_tn(st, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
+    if (ran_outside) HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
+    HIPOK(hipStreamWaitEvent(st, plan->ev_join[1], 0));
 
     if (vl && d_obj_span) {
         float* dO = padded ? wb + bw.dobjp : d_obj_span;

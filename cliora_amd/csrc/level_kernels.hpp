@@ -402,16 +402,18 @@ __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, in
 //   epilogue  xs = PL(a) + PR(b) for the block's columns (re-gathered: x is not kept by the forward), x = relu(xs)
 //             DA  = p_n u [xs > 0]      -> the per-pair gradient the cell gathers sum (cell_gather_bwd_*)
 //             X   = x, DZ = p_n dzu     -> operands of the weight gradient dW2 = DZ^T X (DZ from the fetch lanes, 1/gridDim.y each)
-//             DPP[row][block] = sum over the block's columns of u x: since y = relu(z), dG . y_n = (dG masked) . z_n
-//                                = u . x_n + (dG masked) . b2  -- the softmax backward gets its dp_n without y_n (cell_dsoftmax)
+//             DPP[row][block] = sum over the block's columns of u x, DPB[row] = dzu . b2 (block 0, from the fetch lanes):
+//                                since y = relu(z), dG . y_n = (dG masked) . z_n = u . x_n + (dG masked) . b2
+//                                -- the softmax backward gets its dp_n without y_n (cell_dsoftmax)
 // Tiles are independent here (no reduction over the splits): waves walk the level's tiles (g-major) with a stride.
 // ---------------------------------------------------------------------------------
 template <int CT, int K16, bool F32>
 __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
                                                          const float* __restrict__ dG, const uint32_t* __restrict__ ymask,
                                                          const float* __restrict__ Pp, const float* __restrict__ PA, int lda,
-                                                         const float* __restrict__ PB, int ldb, int Dp, float* __restrict__ DA,
-                                                         float* __restrict__ DZ, float* __restrict__ X, float* __restrict__ DPP) {
+                                                         const float* __restrict__ PB, int ldb, const float* __restrict__ b2, int Dp,
+                                                         float* __restrict__ DA, float* __restrict__ DZ, float* __restrict__ X,
+                                                         float* __restrict__ DPP, float* __restrict__ DPB) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
     constexpr int WAVES = 8, T = WAVES * 64, PD = 4;
     constexpr bool KS = K16 > 0;
@@ -433,13 +435,13 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
     const int ntiles = G * lv.N;
     const int stride = gridDim.x * WAVES;
 
-    struct Ctx { const float* gp; const uint32_t* mp; float* zo; float pn; };
+    struct Ctx { const float* gp; const uint32_t* mp; float* zo; float pn; float* bo; };
     auto rowctx = [&](int tile) {                    // fetch-lane view of tile = gt * N + n
         const int gt = tile / lv.N, n = tile - gt * lv.N;
         const int t = min(gt * 16 + li, lv.ncell - 1);
         const int b = t / lv.Lc, p = t - b * lv.Lc;
         const size_t prow = (size_t)lv.rowbase + (size_t)t * lv.N + n;
-        return Ctx{dG + ((size_t)b * lv.C + lv.off + p) * Dp, ymask + prow * gy * 4 + lg, DZ + prow * Dp, Pp[prow]};
+        return Ctx{dG + ((size_t)b * lv.C + lv.off + p) * Dp, ymask + prow * gy * 4 + lg, DZ + prow * Dp, Pp[prow], DPB + prow};
     };
     struct Slot { float4 g0, g1; uint32_t m0, m1; };
     Slot ra[PD];
@@ -479,12 +481,17 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
         const float pn = Pp[prow];
         const float* xa = PA + ((size_t)eb * lv.C + lv.pa[ep * lv.N + n]) * lda + col0 + 4 * g;
         const float* xb = PB + ((size_t)eb * lv.C + lv.pb[ep * lv.N + n]) * ldb + col0 + 4 * g;
+        float4 ea[CT], ebv[CT];                     // the epilogue's operands, on their way while the K loop runs
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { ea[c] = ld4(xa + c * 16); ebv[c] = ld4(xb + c * 16); }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("" : "+v"(wimg_off));
         const uint32_t* wimg = lds_img + wimg_off;
         int side_turn = 0;
+        float bdot = 0.f;                           // block 0: (dG masked by y_n) . b2 over this lane's k pieces
 #pragma unroll UNROLL_STEPS
         for (int base = 0; base < nsteps_p; base += PD) {
 #pragma unroll
@@ -499,6 +506,11 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
                         st4(ctx.zo + k, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
                         if (second) st4(ctx.zo + k + 16, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
                     }
+                    if (by == 0) {
+                        const int k = 32 * st + 4 * lg;
+                        bdot += f4dot(f0, ld4(b2 + k));
+                        if (second) bdot += f4dot(f1, ld4(b2 + k + 16));
+                    }
                     side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
                     const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
                     kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, a0, a1, acc);
@@ -510,10 +522,15 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
             }
         }
         // epilogue
+        if (by == 0) {                               // the four fetch lanes of a row hold its k pieces
+            bdot += __shfl_xor(bdot, 1);
+            bdot += __shfl_xor(bdot, 2);
+            if (lg == 0 && gt * 16 + li < lv.ncell) *ctx.bo = bdot;
+        }
         float dp = 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            const float4 pa4 = ld4(xa + c * 16), pb4 = ld4(xb + c * 16);
+            const float4 pa4 = ea[c], pb4 = ebv[c];
             const float xs0 = pa4.x + pb4.x, xs1 = pa4.y + pb4.y, xs2 = pa4.z + pb4.z, xs3 = pa4.w + pb4.w;
             const float4 x = make_float4(fmaxf(xs0, 0.f), fmaxf(xs1, 0.f), fmaxf(xs2, 0.f), fmaxf(xs3, 0.f));
             dp = fmaf(acc[c][0], x.x, dp); dp = fmaf(acc[c][1], x.y, dp); dp = fmaf(acc[c][2], x.z, dp); dp = fmaf(acc[c][3], x.w, dp);
@@ -553,11 +570,9 @@ static __global__ __launch_bounds__(256) void cell_dnorm(LevelArgs g, const floa
 }
 
 // Softmax / score backward of the level's cells (diora.py:125-149 differentiated), one wave per cell:
-//   dp_n = sum_blocks DPP[row][block] + sum_j dG_j b2_j [y_nj > 0]      (= dG . y_n, see level_compose_bwd)
+//   dp_n = sum_blocks DPP[row][block] + DPB[row]                        (= dG . y_n, see level_compose_bwd)
 //   ds_n = p_n [ (dp_n - sum_m p_m dp_m) + dS_tot (1 + s_n - S) ]
-// ymask word w of a pair row covers columns (w / 4) * ct * 16 + tile * 16 + (w % 4) * 4 + j, bit tile * 4 + j.
-static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb, int ct, const float* __restrict__ dG, const float* __restrict__ b2,
-                                                            const uint32_t* __restrict__ ymask, const float* __restrict__ DPP,
+static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb, const float* __restrict__ DPP, const float* __restrict__ DPB,
                                                             const float* __restrict__ Sp, const float* __restrict__ Pp,
                                                             const float* __restrict__ Schart, const float* __restrict__ dStot,
                                                             float* __restrict__ DS) {
@@ -567,30 +582,8 @@ static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const size_t row0 = (size_t)g.rowbase + (size_t)t * g.N;
-    const int nw = ncb * 4;
-    float bias_dot = 0.f;                            // lane n ends up with (dG masked by y_n) . b2
-    for (int w0 = 0; w0 < nw; w0 += 64) {
-        const int w = w0 + lane;
-        const bool aw = w < nw;
-        float q[20];                                 // dG_j b2_j of the word's columns (ct <= 5 tiles x 4)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const int col = (w >> 2) * ct * 16 + c * 16 + (w & 3) * 4;
-            float4 gq = f4zero(), bq = f4zero();
-            if (aw && c < ct) { gq = ld4(dG + crow * g.Dp + col); bq = ld4(b2 + col); }
-            q[4 * c + 0] = gq.x * bq.x; q[4 * c + 1] = gq.y * bq.y; q[4 * c + 2] = gq.z * bq.z; q[4 * c + 3] = gq.w * bq.w;
-        }
-        for (int n = 0; n < g.N; ++n) {
-            const uint32_t m = aw ? ymask[(row0 + n) * nw + w] : 0u;
-            float sacc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 20; ++k) sacc += ((m >> k) & 1u) ? q[k] : 0.f;
-            sacc = wave_sum(sacc);
-            if (lane == n) bias_dot += sacc;
-        }
-    }
     const bool an = lane < g.N;
-    float dp = an ? bias_dot : 0.f;
+    float dp = an ? DPB[row0 + lane] : 0.f;
     if (an)
         for (int cb = 0; cb < ncb; ++cb) dp += DPP[(row0 + lane) * ncb + cb];
     const float pn = an ? Pp[row0 + lane] : 0.f;

@@ -191,12 +191,14 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.dz = take(Rt * Dp);
         b.x = take(arch == 0 ? Rt * Dp : 0);
         b.dpp = take(arch == 0 ? Rt * p.fwd.ncb3 : 0);
+        b.dpb = take(arch == 0 ? Rt : 0);
         b.dcb = take(lstm * Rt * Dp); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);
         b.dpi = take(BC * nb * Dp); b.dpo = take(BC * npo * Dp);
         b.du = take(BL * nlf * Dp); b.dxp = take(padded ? BL * Dp : 0);
         // split-K slabs: at most 1024 wave-sized partial blocks of 80x80 per weight-gradient GEMM
         b.slab_floats = std::max((size_t)2048 * 80 * 80, (size_t)128 * (Dp * Dp + Dp));
         b.slab = take(b.slab_floats);
+        b.slab2 = take(arch == 0 ? b.slab_floats : 0);
         b.gwcat = take(nb * Dp * Dp); b.gbcat = take(nb * Dp); b.gw1ro = take(npo * Dp * Dp);
         b.gw2i = take(Dp * Dp); b.gb2i = take(Dp); b.gw2o = take(Dp * Dp); b.gb2o = take(Dp);
         b.gwl = take(nlf * Dp * Dp); b.gbl = take(nlf * Dp); b.groot = take(Dp);

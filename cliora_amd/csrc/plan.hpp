@@ -61,11 +61,11 @@ struct BwdLayout {
     size_t da, ds;                      // per-pair grads (R x Dp), (R)
     size_t dz;                          // per-pair grad at the second pre-activation (R x Dp); TreeLSTM: d c_a per pair
     size_t x;                           // DioraMLP: per-pair first-layer activation relu(PL+PR) (R x Dp), re-formed by level_compose_bwd for the weight gradient
-    size_t dpp;                         // DioraMLP: partial dG.y_n per pair row and column block (R x ncb3)
+    size_t dpp, dpb;                    // DioraMLP: partial dG.y_n per pair row and column block (R x ncb3), and its bias term (R)
     size_t dcb, vc, dgc, grootc;        // TreeLSTM: d c_b per pair (R x Dp), cell-state grads per cell (B*C x Dp) x2, d root c
     size_t dpi, dpo;                    // grads of the projections
     size_t du, dxp;                     // leaf pre-activation grad, padded dx
-    size_t slab;                        // split-K partial sums for the weight-gradient GEMMs
+    size_t slab, slab2;                 // split-K partial sums for the weight-gradient GEMMs (slab2: the side stream's)
     size_t gwcat, gbcat, gw1ro, gw2i, gb2i, gw2o, gb2o, gwl, gbl, groot;   // packed parameter grads
     size_t dctx, pmo, dsc, dobjp;       // CLIORA: d context (B*C x Dp), p*mask and d score per region (B*C x 64 each), d obj (B*R x Dp)
     size_t total;
