@@ -86,7 +86,7 @@ static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, i
     const int passes = (ntiles + 8 * cap - 1) / (8 * cap);
     int gx = (ntiles + 8 * passes - 1) / (8 * passes);
     if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;      // column blocks of the same tiles on one XCD
-    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false), st, Wimg, S, K, lv, dG, ymask,
+    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false) + (size_t)((K + 31) / 32 * 32) * sizeof(float), st, Wimg, S, K, lv, dG, ymask,
                        Pp, PA, lda, PB, ldb, b2, K, DA, DZ, X, DPP, DPB);
     LAUNCHOK("level_compose_bwd");
     return CLIORA_OK;

@@ -42,11 +42,29 @@ constexpr int LC_SLOTS = 4;   // LDS slots of the cross-wave reduction (one per 
 // ---------------------------------------------------------------------------------
 // F32 = true: the exact-fp32 arithmetic mode (cliora_set_mfma_mode): the LDS image is the plain fp32 weight block ([CT*16][K],
 // passed through Wimg with S_ = K) and a 32-deep k-step is eight v_mfma_f32_16x16x4_f32 per column tile instead of three bf16 ones.
+// MFMA operand of one 32-deep k-step of a 16-row tile, in the MFMA lanes: split-bf16 (hi, lo) -- or, in the exact-fp32 mode,
+// the two fp32 runs of four k as they are.  Prepared one k-step ahead of the MFMAs that consume it.
+struct StepOperand { u32x4 h, l; };
+template <bool F32>
+__device__ __forceinline__ StepOperand make_operand(int psrc, const float4& f0, const float4& f1) {
+    const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
+    StepOperand o;
+    if constexpr (F32) {
+        o.h = u32x4{__float_as_uint(a0.x), __float_as_uint(a0.y), __float_as_uint(a0.z), __float_as_uint(a0.w)};
+        o.l = u32x4{__float_as_uint(a1.x), __float_as_uint(a1.y), __float_as_uint(a1.z), __float_as_uint(a1.w)};
+    } else {
+        split_bf16x8(a0, a1, o.h, o.l);
+    }
+    return o;
+}
+
 template <int CT, bool F32>
-__device__ __forceinline__ void kstep_mfma(const uint32_t* wimg, int i, int g, int S, int half, int st, bool second, const float4& a0,
-                                           const float4& a1, f32x4 (&acc)[CT]) {
+__device__ __forceinline__ void kstep_mfma(const uint32_t* wimg, int i, int g, int S, int half, int st, bool second, const StepOperand& x,
+                                           f32x4 (&acc)[CT]) {
     if constexpr (F32) {
         const float* wf = reinterpret_cast<const float*>(wimg) + i * S + 4 * g + 32 * st;
+        const float a0[4] = {__uint_as_float(x.h[0]), __uint_as_float(x.h[1]), __uint_as_float(x.h[2]), __uint_as_float(x.h[3])};
+        const float a1[4] = {__uint_as_float(x.l[0]), __uint_as_float(x.l[1]), __uint_as_float(x.l[2]), __uint_as_float(x.l[3])};
         float4 b0[CT], b1[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -54,27 +72,25 @@ __device__ __forceinline__ void kstep_mfma(const uint32_t* wimg, int i, int g, i
             b1[c] = second ? *reinterpret_cast<const float4*>(wf + c * 16 * S + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].x, a0.x, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].x, a0[0], acc[c]);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].y, a0.y, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].y, a0[1], acc[c]);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].z, a0.z, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].z, a0[2], acc[c]);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].w, a0.w, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma16(b0[c].w, a0[3], acc[c]);
         if (second) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].x, a1.x, acc[c]);
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].x, a1[0], acc[c]);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].y, a1.y, acc[c]);
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].y, a1[1], acc[c]);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].z, a1.z, acc[c]);
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].z, a1[2], acc[c]);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].w, a1.w, acc[c]);
+            for (int c = 0; c < CT; ++c) acc[c] = mfma16(b1[c].w, a1[3], acc[c]);
         }
     } else {
         const uint32_t* wfrag = wimg + i * S + 4 * g;
-        u32x4 xh, xl;
-        split_bf16x8(a0, a1, xh, xl);
         u32x4 wh[CT], wl[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -82,11 +98,11 @@ __device__ __forceinline__ void kstep_mfma(const uint32_t* wimg, int i, int g, i
             wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
         }
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], xh, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], x.h, acc[c]);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xl, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], x.l, acc[c]);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xh, acc[c]);
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], x.h, acc[c]);
     }
 }
 
@@ -186,24 +202,26 @@ __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restr
                 for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 asm volatile("" : "+v"(wimg_off));           // keep the weight-fragment LDS reads inside the tile loop
                 const uint32_t* wimg = lds_img + wimg_off;
+                // Software pipeline over the k-steps: the operand of step st+1 (add, ReLU, lane move, split: VALU + LDS crossbar) is
+                // prepared beside the MFMAs of step st; the ring slot of step st (consumed one iteration earlier) is refilled with
+                // step st+PD -- or, in the tile's last PD steps, with the next tile's step of the same slot.  The scheduling barrier keeps
+                // each refill where it is written: hipcc otherwise sinks the loads to their use (one exposed latency per k-step).
+                StepOperand cur = make_operand<F32>(psrc, relu_add(ra[0][0]), relu_add(ra[0][1]));
 #pragma unroll UNROLL_STEPS
                 for (int base = 0; base < nsteps_p; base += PD) {
 #pragma unroll
                     for (int sl = 0; sl < PD; ++sl) {
                         const int st = base + sl;
                         if (st < nsteps) {
-                            const bool second = 32 * st + 16 < K;
-                            const float4 f0 = relu_add(ra[sl][0]);
-                            const float4 f1 = relu_add(ra[sl][1]);   // beyond K: a second copy of the first run, zero weights in the image
-                            const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
-                            kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, a0, a1, acc);
+                            StepOperand nxt = cur;
+                            if (st + 1 < nsteps) nxt = make_operand<F32>(psrc, relu_add(ra[(sl + 1) % PD][0]), relu_add(ra[(sl + 1) % PD][1]));
+                            kstep_mfma<CT, F32>(wimg, i, g, S, half, st, 32 * st + 16 < K, cur, acc);
+                            const int nst = st + PD;
+                            const bool in_cur = nst < nsteps;
+                            issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
+                            __builtin_amdgcn_sched_barrier(0);
+                            cur = nxt;
                         }
-                        const int nst = st + PD;
-                        const bool in_cur = nst < nsteps;
-                        issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
-                        // hipcc otherwise sinks each refill down to its use PD steps later (one exposed memory latency per
-                        // k-step instead of PD steps of cover): a slot's loads are issued HERE
-                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 // epilogue of the tile: y = relu(acc + b2); g += p_n y; ReLU bits; optional y rows
@@ -428,6 +446,10 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
     const int by = blockIdx.y, gy = gridDim.y;
     const int col0 = by * (CT * 16);
     stage_weight_image(Wimg + (size_t)col0 * S, lds_img, CT * 16 * S, wave, lane, T);
+    // b2 next to the image (Kp floats, zero beyond K): block 0 reads it per k-step for the bias term of dG . y_n -- from LDS, so
+    // that no fresh global load sits inside the loop (vmcnt is in order: waiting for one would drain the operand ring)
+    float* b2s = reinterpret_cast<float*>(lds_img + CT * 16 * S);
+    for (int k = threadIdx.x; k < Kp; k += T) b2s[k] = k < K ? b2[k] : 0.f;
     const int nsteps = Kp >> 5;
     const int nsteps_p = (nsteps + PD - 1) / PD * PD;
     int wimg_off = 0;
@@ -490,35 +512,40 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
         for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("" : "+v"(wimg_off));
         const uint32_t* wimg = lds_img + wimg_off;
-        int side_turn = 0;
         float bdot = 0.f;                           // block 0: (dG masked by y_n) . b2 over this lane's k pieces
+        // operand of k-step st from its ring slot: mask by the ReLU bits, this block's share of the DZ rows, block 0's bias dot
+        auto prep = [&](int st, const Slot& q) {
+            const bool second = 32 * st + 16 < K;
+            const float4 f0 = masked(q.g0, q.m0 >> (4 * ((2 * st) % CT)));
+            const float4 f1 = masked(q.g1, q.m1 >> (4 * ((2 * st + (second ? 1 : 0)) % CT)));
+            const int k = 32 * st + 4 * lg;
+            if (st % gy == by) {
+                st4(ctx.zo + k, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
+                if (second) st4(ctx.zo + k + 16, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
+            }
+            if (by == 0) {
+                bdot += f4dot(f0, *reinterpret_cast<const float4*>(b2s + k));
+                if (second) bdot += f4dot(f1, *reinterpret_cast<const float4*>(b2s + k + 16));
+            }
+            return make_operand<F32>(psrc, f0, f1);
+        };
+        // software pipeline over the k-steps, as in level_compose_fwd
+        StepOperand cur = prep(0, ra[0]);
 #pragma unroll UNROLL_STEPS
         for (int base = 0; base < nsteps_p; base += PD) {
 #pragma unroll
             for (int sl = 0; sl < PD; ++sl) {
                 const int st = base + sl;
                 if (st < nsteps) {
-                    const bool second = 32 * st + 16 < K;
-                    const float4 f0 = masked(ra[sl].g0, ra[sl].m0 >> (4 * ((2 * st) % CT)));
-                    const float4 f1 = masked(ra[sl].g1, ra[sl].m1 >> (4 * ((2 * st + (second ? 1 : 0)) % CT)));
-                    if (side_turn == by) {
-                        const int k = 32 * st + 4 * lg;
-                        st4(ctx.zo + k, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
-                        if (second) st4(ctx.zo + k + 16, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
-                    }
-                    if (by == 0) {
-                        const int k = 32 * st + 4 * lg;
-                        bdot += f4dot(f0, ld4(b2 + k));
-                        if (second) bdot += f4dot(f1, ld4(b2 + k + 16));
-                    }
-                    side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
-                    const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
-                    kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, a0, a1, acc);
+                    StepOperand nxt = cur;
+                    if (st + 1 < nsteps) nxt = prep(st + 1, ra[(sl + 1) % PD]);
+                    kstep_mfma<CT, F32>(wimg, i, g, S, half, st, 32 * st + 16 < K, cur, acc);
+                    const int nst = st + PD;
+                    const bool in_cur = nst < nsteps;
+                    issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nxt;
                 }
-                const int nst = st + PD;
-                const bool in_cur = nst < nsteps;
-                issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
-                __builtin_amdgcn_sched_barrier(0);          // keep the refill here (see level_compose_fwd)
             }
         }
         // epilogue
