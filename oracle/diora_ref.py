@@ -37,9 +37,9 @@ def _normalizer(mode):
 class Charts:
     """diora.py:7-23 (cliora.py:6-25): six zero-initialised chart tensors."""
 
-    def __init__(self, B, L, D):
+    def __init__(self, B, L, D, dtype=torch.float32):
         C = CL.n_cells(L)
-        z = lambda w: torch.full((B, C, w), 0, dtype=torch.float32)
+        z = lambda w: torch.full((B, C, w), 0, dtype=dtype)     # the reference is fp32; fp64 runs serve as the accuracy yardstick
         self.inside_h, self.inside_c, self.inside_s = z(D), z(D), z(1)
         self.outside_h, self.outside_c, self.outside_s = z(D), z(D), z(1)
 
@@ -115,7 +115,7 @@ def compose_mlp(W, a, b):
     """ComposeMLP.forward, diora.py:65-72: relu(W2 relu(W1 [a;b] + b1) + b2), c = 0."""
     x = torch.cat([a, b], 1)
     h = F.relu(F.linear(F.relu(F.linear(x, W['W1'], W['b1'])), W['W2'], W['b2']))
-    c = torch.full(h.shape, 0, dtype=torch.float32)
+    c = torch.full(h.shape, 0, dtype=h.dtype)
     return h, c
 
 
@@ -159,7 +159,7 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
     else:
         Win, Wout = _side(P, 'inside', share), _side(P, 'outside', share)
     off = CL.level_offsets(L)
-    ch = Charts(B, L, D)
+    ch = Charts(B, L, D, x_span.dtype)
     pair_s_in, pair_s_out, pair_h_out = {}, {}, {}
 
     # ---- leaves: diora.py:58-63,283-292 / cliora.py:71-80,290-301
@@ -176,7 +176,7 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
         h = h + cxt
         c = cxt
     else:
-        c = torch.full(h.shape, 0, dtype=torch.float32)
+        c = torch.full(h.shape, 0, dtype=h.dtype)
     h, c = nrm(h.view(B, L, D)), nrm(c.view(B, L, D))
     ch.inside_h[:, :L] = h
     ch.inside_c[:, :L] = c
@@ -212,7 +212,7 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
         if lstm:      # diora.py:346-350 with a root_vector_out_c parameter (the commented hint at diora.py:470-471)
             rc_ = nrm(P['root_vector_out_c'].view(1, 1, D).expand(B, 1, D))
         else:
-            rc_ = nrm(torch.full((B, 1, D), 0, dtype=torch.float32))
+            rc_ = nrm(torch.full((B, 1, D), 0, dtype=x_span.dtype))
         ch.outside_h[:, -1:] = rh_
         ch.outside_c[:, -1:] = rc_
         for level in range(L - 2, -1, -1):
@@ -348,6 +348,20 @@ def cky_trees(pair_s_in, B, L):
         n = bp[b][level][pos]
         return (build(b, n, pos), build(b, level - n - 1, pos + n + 1))
     return [build(b, L - 1, 0) for b in range(B)]
+
+
+def tree_score(pair_s_in, b, tree):
+    """CKY objective (cky.py:83) of a GIVEN tree of sentence b under the per-split scores: leaves count 1, a node adds
+    s_n - max_n s of its split.  cky_trees returns the maximiser; two trees whose scores differ by rounding noise are a tie."""
+    def walk(t):
+        if isinstance(t, int):
+            return t, t, 1.0
+        l0, l1, vl = walk(t[0])
+        r0, r1, vr = walk(t[1])
+        level, pos, n = r1 - l0, l0, l1 - l0
+        s = pair_s_in[level][b, pos, :, 0].detach().double()
+        return l0, r1, vl + vr + float(s[n] - s.max())
+    return walk(tree)[2]
 
 
 def tree_spans(tree):

@@ -63,8 +63,9 @@ def mfma_mode(request):
 
 def grad_tol(mode, strict):
     """Tolerance on the MEDIAN element error of a gradient, relative to the tensor's largest reference magnitude:
-    `strict` for exact fp32 products, 1e-3 in split-bf16 mode (measured medians 1e-6 ... 4e-4, tools/accuracy.py)."""
-    return strict if mode == 'f32' else max(strict, 1e-3)
+    `strict` for exact fp32 products, 5e-4 in split-bf16 mode (measured medians against fp64 at B 64 / L 20 / D 400: 1e-6 ... 1.3e-4,
+    profiles/r02_accuracy_fp64_bf16x3.json; three times the worst)."""
+    return strict if mode == 'f32' else max(strict, 5e-4)
 
 
 def grad_check(t, ref, mode, strict, what=''):
@@ -77,8 +78,9 @@ def grad_check(t, ref, mode, strict, what=''):
     ~2 M per step at B 32, L 14), and each such flip switches that unit's gradient path on or off -- the network is not
     differentiable there, the forward value barely moves, but single rows / columns of the weight gradients and single
     positions of dx move by up to a few percent of the tensor's scale (the reference's own fp32 run shows the same
-    against fp64, at a lower rate: test_gpu_parity._grad_ok).  So the check is statistical: median error within
-    grad_tol(), 99 % of the elements within 2e-2 of scale, every element within 1e-1.  A wrong kernel (a dropped
+    against fp64, at a lower rate: tests/test_gpu_configs.py::test_c2_full_size_gradients_vs_fp64 measures both).  So the check is
+    statistical: median error within grad_tol(), 99 % of the elements within 1e-2 of scale, every element within 5e-2
+    (measured at full size: 2e-3 and 7e-3; the small widths of the other tests sit higher, 3.7e-2 at D = 48).  A wrong kernel (a dropped
     k-step, a transposed tile) moves the median by orders of magnitude and fails the first bound."""
     import torch
     a = (t.detach().double().cpu() if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t)).double()).flatten()
@@ -91,5 +93,6 @@ def grad_check(t, ref, mode, strict, what=''):
     sub = d[:: max(1, d.numel() // 200000)]
     med, q99 = float(sub.median()), float(torch.quantile(sub, 0.99))
     assert med <= grad_tol(mode, strict) * scale, '%s: median err %.3e scale %.3e' % (what, med, scale)
-    assert q99 <= 2e-2 * scale, '%s: q99 err %.3e scale %.3e' % (what, q99, scale)
-    assert float(d.max()) <= 1e-1 * scale, '%s: max err %.3e scale %.3e' % (what, float(d.max()), scale)
+    if d.numel() >= 1000:          # on a 48-element bias the 99th percentile IS the maximum: the last bound covers it
+        assert q99 <= 1e-2 * scale, '%s: q99 err %.3e scale %.3e' % (what, q99, scale)
+    assert float(d.max()) <= 5e-2 * scale, '%s: max err %.3e scale %.3e' % (what, float(d.max()), scale)

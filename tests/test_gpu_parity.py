@@ -294,10 +294,19 @@ def test_limits_of_the_plan(D, B, L, mfma_mode):
     m.eval()
     with torch.no_grad():
         m(x.cuda(), x.cuda())
-    if mfma_mode == 'f32':     # tree identity needs every split comparison to agree: checked where products are exact
-        with torch.no_grad():
-            want = R.cky_trees(R.diora_forward(P, x, x, keep_pairs=True)['pair_s_in'], B, L)
-        assert [str(t) for t in m.cky()] == [str(t) for t in want]
+    with torch.no_grad():       # trees identical to the reference's in BOTH arithmetic modes
+        pair_s = R.diora_forward(P, x, x, keep_pairs=True)['pair_s_in']
+        want = R.cky_trees(pair_s, B, L)
+    got = m.cky()
+    for b in range(B):
+        if str(got[b]) == str(want[b]):
+            continue
+        # The one case seen to differ (split-bf16 mode, D = 16, L = 64, sentence 1): a 63-level chart where two splits of one
+        # cell score within rounding of each other.  Then the tree found must be a tie of the reference's under the REFERENCE's
+        # own scores (CKY objective within 1e-4), and only in the split mode.
+        assert mfma_mode == 'bf16x3', 'exact-fp32 mode must reproduce the trees'
+        gap = R.tree_score(pair_s, b, want[b]) - R.tree_score(pair_s, b, got[b])
+        assert 0.0 <= gap <= 1e-4, (b, gap)
 
 
 def test_outside_hook_receives_the_reference_states():
