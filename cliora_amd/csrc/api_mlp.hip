@@ -115,33 +115,36 @@ static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float
 
 template <int CT, int SP>
 static int launch_level_project_inst(hipStream_t st, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
-                                     size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm) {
+                                     size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm,
+                                     const ScoreArgs& sc) {
     const int nrg = (ncell + 15) / 16;
     const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;          // column blocks of one row group share an XCD
     const int ncb = ncols / (16 * CT);
-    hipLaunchKernelGGL((level_project<CT, SP>), dim3(nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc, C, off, HP, hp_stride,
-                       normalize, bias, P, ldp, H, nrm);
+    hipLaunchKernelGGL((level_project<CT, SP>), dim3(sc.nscore + nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc, C, off, HP,
+                       hp_stride, normalize, bias, P, ldp, H, nrm, sc);
     LAUNCHOK("level_project");
     return CLIORA_OK;
 }
 template <int CT>
 static int launch_level_project_sp(hipStream_t st, int SP, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off,
-                                   const float* HP, size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm) {
+                                   const float* HP, size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm,
+                                   const ScoreArgs& sc) {
     switch (SP) {
-        case 1: return launch_level_project_inst<CT, 1>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
-        case 2: return launch_level_project_inst<CT, 2>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
-        default: return launch_level_project_inst<CT, 4>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+        case 1: return launch_level_project_inst<CT, 1>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+        case 2: return launch_level_project_inst<CT, 2>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+        default: return launch_level_project_inst<CT, 4>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
     }
 }
-// h = unit(sum of the SP parts) for the level's cells (chart rows of H, raw norms) and P = h W^T + bias
+// h = unit(sum of the SP parts) for the level's cells (chart rows of H, raw norms) and P = h W^T + bias; sc: the next level's
+// scoring, in the same launch
 static int launch_level_project(hipStream_t st, int SP, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
-                                size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm) {
+                                size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm, const ScoreArgs& sc) {
     const int nt = ncols / 16, nrt = (ncell + 15) / 16;
     if (g_ksplit_min_blocks < 0) { const char* e = getenv("CLIORA_KSPLIT_MIN_BLOCKS"); g_ksplit_min_blocks = e ? atoi(e) : 1000; }
     // a block's MFMA work and operand bytes are fixed by its tile: wide tiles only when the launch still covers the chip
     if (nt % 5 == 0 && nrt * (nt / 5) >= g_ksplit_min_blocks)
-        return launch_level_project_sp<5>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
-    return launch_level_project_sp<1>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+        return launch_level_project_sp<5>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+    return launch_level_project_sp<1>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
 }
 
 // ------------------------------------------------------------------ forward
@@ -206,6 +209,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         add_copy(t, ws + f.w2iT, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 1);
         add_copy(t, ws + f.b2i, Dp, 1, Dp, P->in_b2, D, 1, D, 0, 0, 0);
         add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
+        add_copy(t, ws + f.matp, Dp, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
         if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
         OKR(run_copies(st, t));
@@ -217,6 +221,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             pj.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
             pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
             pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
+            pj.add(ws + f.matp, ws + f.matq3, Dp, Dp, Dp);
             OKR(build_weight_images(st, im));
             OKR(build_frag_images(st, pj));
         }
@@ -265,13 +270,40 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         return lv;
     };
 
+    // Scoring of target level T of a pass.  newest >= 0: the cells of that level are still partial aggregates (HP, SPn parts) --
+    // the scoring then rides in the projection launch of that level (level_project); newest < 0: every operand is final.
+    auto score_args = [&](int T, bool outside_pass, int newest, int SPn) {
+        ScoreArgs sc{};
+        sc.g = level_args(p, T, outside_pass);
+        sc.nscore = B * sc.g.Lc;
+        sc.arow = dv.arow; sc.brow = dv.brow;
+        sc.QA = ws + f.pi + (size_t)(outside_pass ? p.blk_qlo : 2) * Dp; sc.ldA = ldpi;
+        sc.HB = outside_pass ? OH : IH; sc.HA = IH;
+        sc.SA = IS; sc.SB = outside_pass ? OS : IS;
+        sc.Sp = ws + f.sp; sc.Pp = ws + f.pp; sc.Sout = outside_pass ? OS : IS;
+        sc.a_can_be_new = outside_pass ? 0 : 1;
+        sc.new_lo = sc.new_hi = 0;
+        if (newest >= 0) { sc.new_lo = p.level_offset[newest]; sc.new_hi = sc.new_lo + (L - newest); sc.HPn = HP; sc.hp_stride = hp_stride; sc.SPn = SPn; }
+        sc.normalize = p.normalize;
+        sc.QRleaf = ws + f.qrleaf; sc.L = L;
+        return sc;
+    };
+    auto launch_scores = [&](const ScoreArgs& sc) {
+        hipLaunchKernelGGL(level_scores, dim3(sc.nscore), dim3(256), 0, st, sc);
+        LAUNCHOK("level_scores");
+        return CLIORA_OK;
+    };
+
     // ---- inside pass (diora.py:295-331) ----
+    if (L > 1) {
+        // QR = M h of the leaves: the partner of a newest-level LEFT child is always a leaf (see level_project)
+        OKR(launch_rows_direct(st, ws + f.matp, PROJ_IMG(f.matq3), Dp, Dp, B * L, LevelRowsA{IH, Dp, C, 0, L},
+                               StoreRowsE{ws + f.qrleaf, Dp, nullptr, 0, Dp}));
+        OKR(launch_scores(score_args(1, false, -1, 0)));
+    }
     for (int level = 1; level < L; ++level) {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
-        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 2 * Dp, ldpi, IH, IS, IS,
-                           ws + f.sp, ws + f.pp, IS);
-        LAUNCHOK("pair_scores_fwd");
         int SP = 1;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
@@ -283,12 +315,14 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                (const float*)nullptr, HP, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
                                ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
-            if (level < L - 1)
+            if (level < L - 1) {
                 OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
-        } else if (level < L - 1) {
+                OKR(launch_scores(score_args(level + 1, false, -1, 0)));
+            }
+        } else if (level < L - 1) {      // norm + projection of this level, and the next level's scores in the same launch
             OKR(launch_level_project(st, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, ws + f.bcat,
-                                     ws + f.pi, ldpi, IH, ws + f.nrmi));
+                                     ws + f.pi, ldpi, IH, ws + f.nrmi, score_args(level + 1, false, level, SP)));
         } else {
             hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
                                p.normalize, IH, ws + f.nrmi);
@@ -303,21 +337,19 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
             OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+        if (L > 1) OKR(launch_scores(score_args(L - 2, true, -1, 0)));        // parents: the root only
         for (int level = L - 2; level >= 0; --level) {
             const LevelArgs g = level_args(p, level, true);
             const int ncell = B * g.Lc;
-            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi,
-                               OH, IS, OS, ws + f.sp, ws + f.pp, OS);
-            LAUNCHOK("pair_scores_fwd(out)");
             int SP = 1;
             {
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
                 OKR(launch_level_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true),
                                          ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HP, hp_stride, YM, PH, &SP));
             }
-            if (level >= 1)
+            if (level >= 1)      // the level below is scored in the same launch: its newest parents are this level's cells
                 OKR(launch_level_project(st, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, nullptr,
-                                         ws + f.po, Dp, OH, ws + f.nrmo));
+                                         ws + f.po, Dp, OH, ws + f.nrmo, score_args(level - 1, true, level, SP)));
             else {
                 hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
                                    p.normalize, OH, ws + f.nrmo);

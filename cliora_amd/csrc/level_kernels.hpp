@@ -296,18 +296,119 @@ __device__ __forceinline__ float4 sum_parts(const float* hp, size_t hp_stride, i
 //   Same split-K structure as rows_gemm_ksplit<1, CT, FRAG>: one workgroup = 16 rows x CT*16 columns, the four waves split
 //   the reduction, weights from the fragment image (frag_weight_image), exact fp32 MFMA.
 // ---------------------------------------------------------------------------------
+//
+// The split scores of the NEXT level ride in the same launch (ScoreArgs, blocks [0, sc.nscore)): they need the new cells' h
+// but none of their projections -- a pair has at most one operand on the newest level, and its partner is then a leaf:
+//   newest cell is the right child b:   s = QL(leaf a) . h_b                 (QL of the leaves is long there)
+//   newest cell is the left child a:    s = h_a . QR(leaf b),  QR = M h      (the leaves' QR is projected once per forward)
+// with h = g / max(||g||, eps) formed on the fly from the partial aggregates -- so the scoring leaves the critical path
+// (compose -> [projection || next scores] -> compose) instead of being a launch of its own between two compose kernels.
+struct ScoreArgs {
+    int nscore;                     // target cells of the level to score (0: no scoring in this launch)
+    LevelArgs g;                    // that level
+    const int32_t *arow, *brow;     // chart rows (b*C + cell) of the two operands of every pair row
+    const float* QA; int ldA;       // QL table of the a operands (row stride ldA)
+    const float* HB;                // H chart of the b operands
+    const float *SA, *SB;           // chart scores of the a / b operands
+    float *Sp, *Pp, *Sout;          // per-split score, softmax weight; the target cells' scores
+    int new_lo, new_hi;             // cells [new_lo, new_hi) of a sentence's chart are the newest level (not yet in HB / QA)
+    int a_can_be_new;               // inside pass: both operands live in the inside chart; outside pass: only the parent (b)
+    const float* HA;                // H chart of the a operands (inside pass: = HB)
+    const float* HPn; size_t hp_stride; int SPn; int normalize;   // partial aggregates of the newest cells; nullptr: HA / HB already hold them
+    const float* QRleaf;            // (B*L, Dp): M h of the leaves
+    int L;
+};
+
+// score + softmax of one target cell (pair_scores_fwd with the newest-level operands taken from the partial aggregates)
+__device__ __forceinline__ void score_cell(const ScoreArgs& sc, int t, float* sh_s) {
+    const LevelArgs& g = sc.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int row0 = g.rowbase + t * g.N;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const bool a0 = lane < nv, a1 = lane + 64 < nv;
+    const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    const int bC = b * g.C;
+    for (int n0 = wave; n0 < g.N; n0 += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 4 * j;
+            if (n >= g.N) break;                     // wave-uniform
+            const int ar = sc.arow[row0 + n], br = sc.brow[row0 + n];
+            const int ca = ar - bC, cb = br - bC;
+            const bool a_new = sc.a_can_be_new && ca >= sc.new_lo && ca < sc.new_hi;
+            const bool b_new = cb >= sc.new_lo && cb < sc.new_hi;
+            float4 u0 = f4zero(), u1 = f4zero(), v0 = f4zero(), v1 = f4zero();
+            float den = 1.f;
+            auto newest = [&](int crow, float4& x0, float4& x1) {       // h of a newest-level cell (un-normalised) and its norm
+                if (sc.HPn) {
+                    for (int sp = 0; sp < sc.SPn; ++sp) {
+                        const float* src = sc.HPn + (size_t)sp * sc.hp_stride + (size_t)crow * Dp;
+                        if (a0) x0 = f4add(x0, ld4(src + c0));
+                        if (a1) x1 = f4add(x1, ld4(src + c1));
+                    }
+                    const float nr = sqrtf(wave_sum(f4dot(x0, x0) + f4dot(x1, x1)));
+                    den = sc.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+                } else {
+                    const float* src = (a_new ? sc.HA : sc.HB) + (size_t)crow * Dp;
+                    if (a0) x0 = ld4(src + c0);
+                    if (a1) x1 = ld4(src + c1);
+                }
+            };
+            if (a_new) {                               // partner is a leaf: QR(leaf) = M h_b
+                newest(ar, u0, u1);
+                const float* qr = sc.QRleaf + ((size_t)b * sc.L + cb) * Dp;
+                if (a0) v0 = ld4(qr + c0);
+                if (a1) v1 = ld4(qr + c1);
+            } else {
+                const float* qa = sc.QA + (size_t)ar * sc.ldA;
+                if (a0) u0 = ld4(qa + c0);
+                if (a1) u1 = ld4(qa + c1);
+                if (b_new) newest(br, v0, v1);
+                else {
+                    const float* hb = sc.HB + (size_t)br * Dp;
+                    if (a0) v0 = ld4(hb + c0);
+                    if (a1) v1 = ld4(hb + c1);
+                }
+            }
+            const float s = wave_sum(f4dot(u0, v0) + f4dot(u1, v1)) / den + sc.SA[ar] + sc.SB[br];
+            if (lane == 0) sh_s[n] = s;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float my_s = lane < g.N ? sh_s[lane] : -INFINITY;
+    const float m = wave_max(my_s);
+    const float e = lane < g.N ? expf(my_s - m) : 0.f;
+    const float pn = e / wave_sum(e);
+    if (lane < g.N) { sc.Sp[row0 + lane] = my_s; sc.Pp[row0 + lane] = pn; }
+    const float st = wave_sum(lane < g.N ? pn * my_s : 0.f);
+    if (lane == 0) sc.Sout[(size_t)bC + g.off + p] = st;
+}
+
+// the scoring alone (first level of a pass: every operand is already final)
+static __global__ __launch_bounds__(256) void level_scores(ScoreArgs sc) {
+    __shared__ float sh_s[64];
+    score_cell(sc, blockIdx.x, sh_s);
+}
+
 template <int CT, int SP>
 __global__ __launch_bounds__(256) void level_project(const float* __restrict__ Wfrag, int K, int nrg, int nrgp, int ncolblocks,
                                                      int ncell, int Lc, int C, int off, const float* __restrict__ HP, size_t hp_stride,
                                                      int normalize, const float* __restrict__ bias, float* __restrict__ P, int ldp,
-                                                     float* __restrict__ H, float* __restrict__ nrm) {
+                                                     float* __restrict__ H, float* __restrict__ nrm, ScoreArgs sc) {
     __shared__ float4 part[4][CT][64];
     __shared__ float sh_ss[4][16];
+    if ((int)blockIdx.x < sc.nscore) {               // the next level's scores: first in the grid, so they start at once
+        score_cell(sc, blockIdx.x, &sh_ss[0][0]);
+        return;
+    }
+    const int bid = blockIdx.x - sc.nscore;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
     const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
-    const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;
+    const int cb = bid / nrgp, rg = bid - cb * nrgp;
     if (rg >= nrg) return;
     const int col0 = cb * (CT * 16);
     const int nchunks = K >> 4;

@@ -150,6 +150,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.wcat3 = img(nb * Dp, Dp); f.wcatT3 = img(Dp, nb * Dp);
         f.w1ro3 = img(npo * Dp, Dp); f.w1roT3 = img(Dp, npo * Dp);
         f.rootp = take(Dp);
+        f.matp = take(arch == 0 ? Dp * Dp : 0); f.matq3 = take(arch == 0 ? Dp * Dp : 0); f.qrleaf = take(arch == 0 ? BL * Dp : 0);
         f.xp = take(padded ? BL * Dp : 0);
         f.ihp = take(padded ? BC * Dp : 0);
         f.ohp = take(padded ? BC * Dp : 0);

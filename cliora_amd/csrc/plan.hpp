@@ -39,6 +39,7 @@ struct FwdLayout {
     int Kp3, S3;                        // image geometry for K = Dp: k rounded up to 32, row stride in dwords
     size_t wl3, wlT3, wcat3, wcatT3, w1ro3, w1roT3;   // images of the leaf / projection weights and their transposes
     size_t rootp;                       // root vector, padded
+    size_t matp, matq3, qrleaf;         // inside score matrix padded (Dp x Dp), its fragment image, and QR = M h of the leaves (B*L x Dp)
     size_t xp, ihp, ohp;                // padded copies (only when D != Dp; else unused)
     size_t objp;                        // padded obj (CLIORA, D != Dp)
     size_t t;                           // leaf tanh output (B*L x Dp)
