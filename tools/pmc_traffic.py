@@ -14,8 +14,8 @@ import sys
 from collections import defaultdict
 
 CLASSES = {
-    'compose_fwd': ('ComposeXA', 'rows_gemm'),
-    'compose_bwd': ('ComposeDzA', 'rows_gemm'),
+    'compose_fwd': ('level_compose_fwd',),
+    'compose_bwd': ('level_compose_bwd',),
     'wgrad': ('tn_gemm_dma',),
 }
 
