@@ -25,7 +25,7 @@ struct cliora_plan {
     bool uploaded = false;
     int device = -1;            // HIP device the index tables live on (set at upload; every later call must run there)
     hipStream_t side = nullptr; // side stream of the backward: weight-gradient GEMMs run beside the level chain (fork / join by events)
-    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 
 extern thread_local std::string g_cliora_err;
@@ -212,7 +212,7 @@ static int launch_rows(hipStream_t st, const float* W, int Kseg, int nseg, int n
 
 template <int T, class AP, class BP>
 static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats,
-                       float* out, float* colsum_out) {
+                       float* out, float* colsum_out, int accumulate) {
     const int blocks = (Mi / (T * 16)) * (Nj / (T * 16));
     size_t per_slice = (size_t)Mi * Nj + (colsum_out ? Mi : 0);
     int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 2048 / blocks));
@@ -228,29 +228,30 @@ static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, 
         hipLaunchKernelGGL((tn_gemm<T, T, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
     LAUNCHOK("tn_gemm");
     const size_t n = (size_t)Mi * Nj;
-    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, accumulate);
     LAUNCHOK("slab_reduce");
     if (colsum_out) {
-        hipLaunchKernelGGL(slab_reduce, dim3((Mi + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Mi, colsum_out);
+        hipLaunchKernelGGL(slab_reduce, dim3((Mi + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Mi, colsum_out, accumulate);
         LAUNCHOK("slab_reduce(colsum)");
     }
     return CLIORA_OK;
 }
 
-// out[i][j] = sum_r A(r,i) B(r,j); colsum_out[i] = sum_r A(r,i) (optional)
+// out[i][j] (+)= sum_r A(r,i) B(r,j); colsum_out[i] (+)= sum_r A(r,i) (optional)
 template <class AP, class BP>
 static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, BP bp, float* slab, size_t slab_floats,
-                     float* out, float* colsum_out) {
+                     float* out, float* colsum_out, int accumulate = 0) {
     if (nrows <= 0) {
+        if (accumulate) return CLIORA_OK;
         HIPOK(hipMemsetAsync(out, 0, (size_t)Mi * Nj * sizeof(float), st));
         if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Mi * sizeof(float), st));
         return CLIORA_OK;
     }
     switch (pick_tiles(Dp / 16)) {
-        case 5: return launch_tn_t<5>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
-        case 4: return launch_tn_t<4>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
-        case 2: return launch_tn_t<2>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
-        default: return launch_tn_t<1>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out);
+        case 5: return launch_tn_t<5>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out, accumulate);
+        case 4: return launch_tn_t<4>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out, accumulate);
+        case 2: return launch_tn_t<2>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out, accumulate);
+        default: return launch_tn_t<1>(st, nrows, Mi, Nj, ap, bp, slab, slab_floats, out, colsum_out, accumulate);
     }
 }
 

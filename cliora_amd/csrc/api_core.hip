@@ -71,7 +71,7 @@ extern "C" int cliora_plan_create_ex(int B, int L, int D, int share, int normali
 extern "C" void cliora_plan_destroy(cliora_plan* plan) {
     if (!plan) return;
     if (plan->p.d_tables) (void)hipFree(plan->p.d_tables);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (plan->ev_fork[k]) (void)hipEventDestroy(plan->ev_fork[k]);
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
     }
@@ -116,7 +116,7 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     HIPOK(hipStreamSynchronize(st));   // `flat` dies at scope exit
     plan->p.d_tables_count = flat.size();
     HIPOK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         HIPOK(hipEventCreateWithFlags(&plan->ev_fork[k], hipEventDisableTiming));
         HIPOK(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
     }

@@ -464,6 +464,12 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
     }
 
+    // The projections' weight gradient dWcat = sum over cells dP^T h is split in two: the rows of the levels >= ksplit are final once that
+    // level's gather has run, and their share runs on the side stream beside the remaining (latency-bound, small) levels; only the low
+    // levels' rows are left for the tail, where the pair weight gradient owns the chip.
+    static const int ksplit_env = [] { const char* e = getenv("CLIORA_WGRAD_SPLIT_LEVEL"); return e ? atoi(e) : -1; }();
+    const int ksplit = ksplit_env >= 0 ? ksplit_env : std::min(2, L - 1);   // measured at L = 20: 2 best (4.52 -> 4.42 ms), higher levels leave more for the tail
+    int tail_cells = C;                                         // chart rows per sentence still to be covered by the tail launch
     for (int level = L - 1; level >= 0; --level) {
         const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
         const int ncell = B * g.Lc;
@@ -478,6 +484,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
                                drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
             LAUNCHOK("cell_attend_bwd");
+        }
+        if (level == ksplit && level >= 1) {
+            const int hi = C - g.off;                           // cells per sentence at levels >= ksplit (a level's cells are contiguous)
+            HIPOK(hipEventRecord(plan->ev_fork[2], st));
+            HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[2], 0));
+            OKR(launch_tn(plan->side, B * hi, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, g.off, hi}, LevelRowsA{IH, Dp, C, g.off, hi}, wb + bw.slab2,
+                          bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
+            tail_cells = g.off;
         }
         if (level == 0) break;
         hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, dG);
@@ -498,8 +512,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // weight gradients of the cell projections and of the leaf layer on the side stream, the inside pair rows' dW2 here
     HIPOK(hipEventRecord(plan->ev_fork[1], st));
     HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[1], 0));
-    OKR(launch_tn(plan->side, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwcat,
-                  wb + bw.gbcat));
+    OKR(launch_tn(plan->side, B * tail_cells, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, 0, tail_cells}, LevelRowsA{IH, Dp, C, 0, tail_cells},
+                  wb + bw.slab2, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat, tail_cells < C));
     OKR(launch_tn(plan->side, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
     HIPOK(hipEventRecord(plan->ev_join[1], plan->side));
     {

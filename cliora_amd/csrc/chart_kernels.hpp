@@ -615,6 +615,7 @@ struct LevelRowsA {
     __device__ float4 finish(const Ctx&, const Raw& v) const { return v; }
     static constexpr bool kSide = false;
     __device__ void side(const Ctx&, int, float4) const {}
+    __device__ float val(const Ctx& c, int col) const { return c.r[col]; }
 };
 // compose layer 1, factored: x = relu(PL(a) + PR(b))           (diora.py:65-68 first Linear + ReLU)
 struct ComposeXA {

@@ -1085,13 +1085,13 @@ static __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restri
     }
 }
 
-// out[e] = sum_s slab[s][e], fixed order.
-static __global__ void slab_reduce(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out) {
+// out[e] (+)= sum_s slab[s][e], fixed order.
+static __global__ void slab_reduce(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out, int accumulate = 0) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     float v = 0.f;
     for (int s = 0; s < nslices; ++s) v += slab[(size_t)s * n + e];
-    out[e] = v;
+    out[e] = accumulate ? out[e] + v : v;
 }
 
 }  // namespace cliora
