@@ -24,8 +24,11 @@ struct cliora_plan {
     Plan p;
     bool uploaded = false;
     int device = -1;            // HIP device the index tables live on (set at upload; every later call must run there)
-    hipStream_t side = nullptr; // side stream of the backward: weight-gradient GEMMs run beside the level chain (fork / join by events)
+    // side: the second chain of the inside / outside wavefront (forward: the outside pass, backward: the outside pass's backward);
+    // side2: weight-gradient GEMMs beside the level chains.  Fork / join with the caller's stream by events.
+    hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_level;   // one per chart level: "this chain has finished level k" for the other chain
 };
 
 extern thread_local std::string g_cliora_err;

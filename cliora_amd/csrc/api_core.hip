@@ -75,7 +75,9 @@ extern "C" void cliora_plan_destroy(cliora_plan* plan) {
         if (plan->ev_fork[k]) (void)hipEventDestroy(plan->ev_fork[k]);
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
     }
+    for (hipEvent_t e : plan->ev_level) (void)hipEventDestroy(e);
     if (plan->side) (void)hipStreamDestroy(plan->side);
+    if (plan->side2) (void)hipStreamDestroy(plan->side2);
     delete plan;
 }
 
@@ -116,6 +118,12 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     HIPOK(hipStreamSynchronize(st));   // `flat` dies at scope exit
     plan->p.d_tables_count = flat.size();
     HIPOK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithFlags(&plan->side2, hipStreamNonBlocking));
+    for (int k = 0; k <= plan->p.L; ++k) {
+        hipEvent_t e;
+        HIPOK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        plan->ev_level.push_back(e);
+    }
     for (int k = 0; k < 3; ++k) {
         HIPOK(hipEventCreateWithFlags(&plan->ev_fork[k], hipEventDisableTiming));
         HIPOK(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));

@@ -7,9 +7,9 @@
 // ------------------------------------------------------------------ fused level kernels (level_kernels.hpp)
 struct ComposeGeom { int TG, SP, ntask, gx; };
 // Tasks of level_compose_fwd: TG cell tiles per workgroup (8 / TG waves each), the split range cut in SP parts.
-static ComposeGeom compose_geom(int ncell, int N, int ncb) {
+static ComposeGeom compose_geom(int ncell, int N, int ncb, int cus) {
     const int G = (ncell + 15) / 16;
-    const int cap = std::max(1, 256 / ncb);                       // one workgroup per CU (the weight block fills LDS)
+    const int cap = std::max(1, cus / ncb);                       // one workgroup per CU (the weight block fills LDS)
     // Measured on MI355X (round 2, rocprof per-level traces): a round of tasks costs a ~5.8 us latency chain (index loads, ring
     // fill, epilogue, reduction) plus ~2.8 us of MFMA / VALU / LDS issue per tile on the busiest SIMD (waves w and w+4 share
     // one); rounds do not overlap.  Pick the cheapest geometry, fewer parts on a tie.
@@ -45,9 +45,9 @@ static size_t compose_lds_bytes(int ct, int S, bool with_slots) {
 template <int CT, int K16, bool F32>
 static int launch_level_compose_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* PA, int lda,
                                      const float* PB, int ldb, const float* bias, const float* Pp, float* HP, size_t hp_stride, int Dp,
-                                     uint32_t* ymask, float* Y, int* SP_out) {
+                                     uint32_t* ymask, float* Y, int* SP_out, int cus) {
     OKR(cliora_ensure_max_lds((const void*)level_compose_fwd<CT, K16, F32>));
-    const ComposeGeom q = compose_geom(lv.ncell, lv.N, ncb);
+    const ComposeGeom q = compose_geom(lv.ncell, lv.N, ncb, cus);
     hipLaunchKernelGGL((level_compose_fwd<CT, K16, F32>), dim3(q.gx, ncb), dim3(512), compose_lds_bytes(CT, S, true), st, Wimg, S, K, lv, PA, lda,
                        PB, ldb, bias, Pp, q.TG, q.SP, q.ntask, HP, hp_stride, Dp, ymask, Y);
     LAUNCHOK("level_compose_fwd");
@@ -59,11 +59,11 @@ static int launch_level_compose_inst(hipStream_t st, const uint32_t* Wimg, int S
 // W: the plain fp32 weight (exact mode), Wimg: its split-bf16 image.
 static int launch_level_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
                                 const float* PA, int lda, const float* PB, int ldb, const float* bias, const float* Pp, float* HP,
-                                size_t hp_stride, uint32_t* ymask, float* Y, int* SP_out) {
+                                size_t hp_stride, uint32_t* ymask, float* Y, int* SP_out, int cus = 256) {
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? W : Wimg);
     const int S = f32 ? Dp : S3;
-#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, SP_out
+#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, SP_out, cus
 #define LC_CASE(c, k16) return f32 ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
     if (ct == 5 && Dp == 400) LC_CASE(5, 25);
     switch (ct) {
@@ -257,7 +257,8 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         PH = ws + f.pair_h;
     }
     const size_t hp_stride = (size_t)B * C * Dp;
-    float* HP = ws + f.hp;
+    float* HPi = ws + f.hp;                            // partial aggregates of the level being composed, one buffer per pass
+    float* HPo = ws + f.hp_o;
     uint32_t* YM = keep ? reinterpret_cast<uint32_t*>(ws + f.ymask) : nullptr;
     auto pair_level = [&](int level, bool outside_pass) {
         const LevelArgs g = level_args(p, level, outside_pass);
@@ -283,82 +284,135 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         sc.Sp = ws + f.sp; sc.Pp = ws + f.pp; sc.Sout = outside_pass ? OS : IS;
         sc.a_can_be_new = outside_pass ? 0 : 1;
         sc.new_lo = sc.new_hi = 0;
-        if (newest >= 0) { sc.new_lo = p.level_offset[newest]; sc.new_hi = sc.new_lo + (L - newest); sc.HPn = HP; sc.hp_stride = hp_stride; sc.SPn = SPn; }
+        if (newest >= 0) {
+            sc.new_lo = p.level_offset[newest]; sc.new_hi = sc.new_lo + (L - newest);
+            sc.HPn = outside_pass ? HPo : HPi; sc.hp_stride = hp_stride; sc.SPn = SPn;
+        }
         sc.normalize = p.normalize;
         sc.QRleaf = ws + f.qrleaf; sc.L = L;
         return sc;
     };
-    auto launch_scores = [&](const ScoreArgs& sc) {
-        hipLaunchKernelGGL(level_scores, dim3(sc.nscore), dim3(256), 0, st, sc);
+    auto launch_scores = [&](hipStream_t s, const ScoreArgs& sc) {
+        hipLaunchKernelGGL(level_scores, dim3(sc.nscore), dim3(256), 0, s, sc);
         LAUNCHOK("level_scores");
         return CLIORA_OK;
     };
 
-    // ---- inside pass (diora.py:295-331) ----
-    if (L > 1) {
-        // QR = M h of the leaves: the partner of a newest-level LEFT child is always a leaf (see level_project)
-        OKR(launch_rows_direct(st, ws + f.matp, PROJ_IMG(f.matq3), Dp, Dp, B * L, LevelRowsA{IH, Dp, C, 0, L},
-                               StoreRowsE{ws + f.qrleaf, Dp, nullptr, 0, Dp}));
-        OKR(launch_scores(score_args(1, false, -1, 0)));
-    }
-    for (int level = 1; level < L; ++level) {
+    // ---- the two passes as a wavefront ------------------------------------------------------------------------------------
+    // Outside target level t composes (parent outside cell, sibling inside cell) pairs whose siblings sit at inside levels
+    // <= L-2-t (diora.py:358-398, outside_index.py:39-127): the outside pass does not have to wait for the inside pass to finish,
+    // only to stay behind it.  Step k runs inside level k on the caller's stream and outside level L-k on the plan's side stream
+    // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
+    // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
+    // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
+    static const int wavefront_env = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? atoi(e) : 1; }();
+    const bool two_streams = wavefront_env != 0 && run_outside && L > 2;
+    hipStream_t sa = st, sb = two_streams ? plan->side : st;
+
+    // CUs each of the two concurrent compose launches of a step plans for (one workgroup fills a CU's LDS): in proportion to their tiles
+    static const int wf_budget_env = [] { const char* e = getenv("CLIORA_WF_BUDGET"); return e ? atoi(e) : 0; }();
+    auto level_tiles = [&](int level, bool outside_pass) {
+        if (level < 0 || level > L - 1) return 0;
+        const LevelArgs g = level_args(p, level, outside_pass);
+        return (B * g.Lc + 15) / 16 * g.N;
+    };
+    auto cu_budget = [&](int level, bool outside_pass) {
+        if (!two_streams) return 256;
+        const int other = L - (outside_pass ? level : level);           // inside level k runs beside outside level L-k and vice versa
+        const int mine = level_tiles(level, outside_pass), theirs = level_tiles(other, !outside_pass);
+        if (theirs == 0 || mine == 0) return 256;
+        if (wf_budget_env > 0) return wf_budget_env;
+        const int c = (int)(256.0 * mine / (mine + theirs));
+        return std::min(216, std::max(40, (c + 20) / 40 * 40));         // multiples of 40: 8 column groups of 5 blocks
+    };
+    auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
         int SP = 1;
         {
-            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-            OKR(launch_level_compose(st, ws + f.w2i, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi,
-                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HP, hp_stride, YM, PH, &SP));
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sa);
+            OKR(launch_level_compose(sa, ws + f.w2i, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi,
+                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, &SP, cu_budget(level, false)));
         }
         if (vl) {   // cliora.py:140-157: attention residual between the aggregate and the second unit norm, then the projections
-            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, st, g, L, PairScoreArgs{}, (const float*)nullptr,
-                               (const float*)nullptr, HP, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, sa, g, L, PairScoreArgs{}, (const float*)nullptr,
+                               (const float*)nullptr, HPi, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
                                ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
             if (level < L - 1) {
-                OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+                OKR(launch_rows_direct(sa, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                                 StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
-                OKR(launch_scores(score_args(level + 1, false, -1, 0)));
+                OKR(launch_scores(sa, score_args(level + 1, false, -1, 0)));
             }
         } else if (level < L - 1) {      // norm + projection of this level, and the next level's scores in the same launch
-            OKR(launch_level_project(st, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, ws + f.bcat,
+            OKR(launch_level_project(sa, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HPi, hp_stride, p.normalize, ws + f.bcat,
                                      ws + f.pi, ldpi, IH, ws + f.nrmi, score_args(level + 1, false, level, SP)));
         } else {
-            hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
+            hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, sa, ncell, g.Lc, C, g.off, Dp, HPi, hp_stride, SP,
                                p.normalize, IH, ws + f.nrmi);
             LAUNCHOK("level_finish");
         }
-    }
+        return CLIORA_OK;
+    };
+    auto outside_step = [&](int level) -> int {         // diora.py:358-398 for one level
+        const LevelArgs g = level_args(p, level, true);
+        const int ncell = B * g.Lc;
+        int SP = 1;
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sb);
+            OKR(launch_level_compose(sb, ws + f.w2o, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true),
+                                     ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HPo, hp_stride, YM, PH, &SP,
+                                     cu_budget(level, true)));
+        }
+        if (level >= 1)      // the level below is scored in the same launch: its newest parents are this level's cells
+            OKR(launch_level_project(sb, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HPo, hp_stride, p.normalize, nullptr,
+                                     ws + f.po, Dp, OH, ws + f.nrmo, score_args(level - 1, true, level, SP)));
+        else {
+            hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, sb, ncell, g.Lc, C, g.off, Dp, HPo, hp_stride, SP,
+                               p.normalize, OH, ws + f.nrmo);
+            LAUNCHOK("level_finish(out)");
+        }
+        return CLIORA_OK;
+    };
 
-    // ---- outside pass (diora.py:337-398) ----
-    if (run_outside) {
-        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH,
+    if (L > 1) {
+        // QR = M h of the leaves: the partner of a newest-level LEFT child is always a leaf (see level_project)
+        OKR(launch_rows_direct(st, ws + f.matp, PROJ_IMG(f.matq3), Dp, Dp, B * L, LevelRowsA{IH, Dp, C, 0, L},
+                               StoreRowsE{ws + f.qrleaf, Dp, nullptr, 0, Dp}));
+        OKR(launch_scores(st, score_args(1, false, -1, 0)));
+    }
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_fork[0], st));
+        HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+    }
+    if (run_outside) {       // root of the outside chart (diora.py:337-356) and the scores of the level below it: parents = the root only
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH,
                            ws + f.nrmo, OS);
         LAUNCHOK("unit_norm_rows(root)");
-        if (L > 1)
-            OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
-        if (L > 1) OKR(launch_scores(score_args(L - 2, true, -1, 0)));        // parents: the root only
-        for (int level = L - 2; level >= 0; --level) {
-            const LevelArgs g = level_args(p, level, true);
-            const int ncell = B * g.Lc;
-            int SP = 1;
-            {
-                ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-                OKR(launch_level_compose(st, ws + f.w2o, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true),
-                                         ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HP, hp_stride, YM, PH, &SP));
-            }
-            if (level >= 1)      // the level below is scored in the same launch: its newest parents are this level's cells
-                OKR(launch_level_project(st, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HP, hp_stride, p.normalize, nullptr,
-                                         ws + f.po, Dp, OH, ws + f.nrmo, score_args(level - 1, true, level, SP)));
-            else {
-                hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, st, ncell, g.Lc, C, g.off, Dp, HP, hp_stride, SP,
-                                   p.normalize, OH, ws + f.nrmo);
-                LAUNCHOK("level_finish(out)");
-            }
+        if (L > 1) {
+            OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+            OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
         }
     } else {
         HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
+    }
+    for (int k = 1; k <= L; ++k) {
+        if (k <= L - 1) {
+            OKR(inside_step(k));
+            if (two_streams) HIPOK(hipEventRecord(plan->ev_level[k], sa));
+        }
+        if (run_outside && k >= 2) {
+            const int level = L - k;
+            // compose reads the siblings' projections of inside levels <= k-2, the riding scores (level >= 1) those of level k-1
+            const int need = level >= 1 ? k - 1 : k - 2;
+            if (two_streams && need >= 1) HIPOK(hipStreamWaitEvent(sb, plan->ev_level[need], 0));
+            OKR(outside_step(level));
+        }
+    }
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_join[0], sb));
+        HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
     }
     if (padded) {
         CopyTable t; t.n = 0;
@@ -420,105 +474,133 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const float* IHn = vl ? ws + f.att_u : IH;
     const float* nrmIn = vl ? ws + f.att_nrmu : ws + f.nrmi;
 
-    if (ran_outside) {
-        for (int level = 0; level <= L - 1; ++level) {
-            const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
-            const int ncell = B * g.Lc;
-            hipLaunchKernelGGL(cell_gather_bwd_out, dim3(ncell), dim3(256), 0, st, g, D, d_outside_h,
-                               level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VH, dStot);
-            LAUNCHOK("cell_gather_bwd_out");
-            if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
-                                StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
-            if (level == L - 1) {
-                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
-                LAUNCHOK("root_bwd");
-                break;
-            }
-            hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, OH, ws + f.nrmo, p.normalize, dG);
-            LAUNCHOK("cell_dnorm(out)");
-            {
-                ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-                OKR(launch_level_compose_bwd(st, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dG, YM, Pp,
-                                             PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB));
-            }
-            hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStot, DS);
-            LAUNCHOK("cell_dsoftmax(out)");
+    // ---- the two backward chains as a wavefront ---------------------------------------------------------------------------
+    // The backward of outside level t only feeds inside cells of levels <= L-2-t (its siblings), so the backward of the inside
+    // pass does not have to wait for the whole outside backward: step j runs outside level j on the plan's side stream and
+    // inside level L-1-j on the caller's stream, which waits for the event of outside step j-1 (see cliora_chart_forward).
+    static const int wavefront_env = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? atoi(e) : 1; }();
+    const bool two_streams = wavefront_env != 0 && ran_outside && L > 2;
+    hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
+    float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
+
+    auto outside_bwd_step = [&](int level) -> int {
+        const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
+        const int ncell = B * g.Lc;
+        hipLaunchKernelGGL(cell_gather_bwd_out, dim3(ncell), dim3(256), 0, sb, g, D, d_outside_h,
+                           level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VHo, dStoto);
+        LAUNCHOK("cell_gather_bwd_out");
+        if (level >= 1)
+            OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                            StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (level == L - 1) {
+            hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, sb, B, C, Dp, VHo, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+            LAUNCHOK("root_bwd");
+            return CLIORA_OK;
         }
-        if (!p.share) {
-            ProfScope ps(CLIORA_KCLASS_WGRAD, st);
-            OKR(launch_tn_pairs(st, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
-                                wb + bw.gw2o, wb + bw.gb2o));
+        hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, VHo, OH, ws + f.nrmo, p.normalize, dGo);
+        LAUNCHOK("cell_dnorm(out)");
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sb);
+            OKR(launch_level_compose_bwd(sb, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dGo, YM, Pp,
+                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB));
         }
-        // dW of the outside-cell projection does not feed the inside chain and needs no LDS: it runs on the side stream beside
-        // the (LDS-bound) level kernels.  The pair weight gradient (tn_gemm_dma3) fills every CU's LDS, so it stays in line.
-        HIPOK(hipEventRecord(plan->ev_fork[0], st));
-        HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[0], 0));
-        OKR(launch_tn(plan->side, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gw1ro,
-                      (float*)nullptr));
-        HIPOK(hipEventRecord(plan->ev_join[0], plan->side));
-    } else {
-        HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
-        HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
-        HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, (size_t)Dp * Dp * sizeof(float), st));
-        HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
-    }
+        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
+        LAUNCHOK("cell_dsoftmax(out)");
+        return CLIORA_OK;
+    };
 
     // The projections' weight gradient dWcat = sum over cells dP^T h is split in two: the rows of the levels >= ksplit are final once that
-    // level's gather has run, and their share runs on the side stream beside the remaining (latency-bound, small) levels; only the low
+    // level's gather has run, and their share runs on the GEMM stream beside the remaining (latency-bound, small) levels; only the low
     // levels' rows are left for the tail, where the pair weight gradient owns the chip.
     static const int ksplit_env = [] { const char* e = getenv("CLIORA_WGRAD_SPLIT_LEVEL"); return e ? atoi(e) : -1; }();
     const int ksplit = ksplit_env >= 0 ? ksplit_env : std::min(2, L - 1);   // measured at L = 20: 2 best (4.52 -> 4.42 ms), higher levels leave more for the tail
     int tail_cells = C;                                         // chart rows per sentence still to be covered by the tail launch
-    for (int level = L - 1; level >= 0; --level) {
+    auto inside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
         const int ncell = B * g.Lc;
-        hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, st, g, D, d_inside_h,
+        hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, sa, g, D, d_inside_h,
                            level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside,
                            DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
         if (level <= L - 2)
-            OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+            OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
-            hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, st, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
+            hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, sa, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
                                drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
             LAUNCHOK("cell_attend_bwd");
         }
         if (level == ksplit && level >= 1) {
             const int hi = C - g.off;                           // cells per sentence at levels >= ksplit (a level's cells are contiguous)
-            HIPOK(hipEventRecord(plan->ev_fork[2], st));
-            HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[2], 0));
-            OKR(launch_tn(plan->side, B * hi, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, g.off, hi}, LevelRowsA{IH, Dp, C, g.off, hi}, wb + bw.slab2,
+            HIPOK(hipEventRecord(plan->ev_fork[2], sa));
+            HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
+            OKR(launch_tn(sw, B * hi, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, g.off, hi}, LevelRowsA{IH, Dp, C, g.off, hi}, wb + bw.slab2,
                           bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
             tail_cells = g.off;
         }
-        if (level == 0) break;
-        hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, st, g, VH, IHn, nrmIn, p.normalize, dG);
+        if (level == 0) return CLIORA_OK;
+        hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, VH, IHn, nrmIn, p.normalize, dG);
         LAUNCHOK("cell_dnorm(in)");
         {
-            ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
-            OKR(launch_level_compose_bwd(st, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sa);
+            OKR(launch_level_compose_bwd(sa, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
                                          PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB));
         }
-        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, st, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
+        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
         LAUNCHOK("cell_dsoftmax(in)");
+        return CLIORA_OK;
+    };
+
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_fork[0], st));
+        HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+    }
+    if (!ran_outside) {
+        HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, (size_t)Dp * Dp * sizeof(float), st));
+        HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
+    }
+    for (int j = 0; j <= L - 1; ++j) {
+        if (ran_outside) {
+            OKR(outside_bwd_step(j));
+            if (two_streams) HIPOK(hipEventRecord(plan->ev_level[j], sb));
+        }
+        // the gather of inside level L-1-j reads the outside pairs whose sibling it is: outside levels <= j-1
+        if (two_streams && j >= 1) HIPOK(hipStreamWaitEvent(sa, plan->ev_level[j - 1], 0));
+        OKR(inside_bwd_step(L - 1 - j));
     }
     // leaves
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
     LAUNCHOK("leaf_bwd_pre");
     if (d_x_span)
         OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
-    // weight gradients of the cell projections and of the leaf layer on the side stream, the inside pair rows' dW2 here
+
+    // ---- weight gradients: the cell projections' and the leaf layer's on the GEMM stream, the pair rows' dW2 (tn_gemm_dma3 fills
+    //      every CU's LDS) on the caller's stream once both chains are done ----
     HIPOK(hipEventRecord(plan->ev_fork[1], st));
-    HIPOK(hipStreamWaitEvent(plan->side, plan->ev_fork[1], 0));
-    OKR(launch_tn(plan->side, B * tail_cells, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, 0, tail_cells}, LevelRowsA{IH, Dp, C, 0, tail_cells},
+    if (ran_outside) {
+        if (two_streams) {
+            HIPOK(hipEventRecord(plan->ev_join[0], sb));
+            HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
+            HIPOK(hipStreamWaitEvent(sw, plan->ev_join[0], 0));
+        } else {
+            HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[1], 0));
+        }
+        OKR(launch_tn(sw, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gw1ro,
+                      (float*)nullptr));
+    }
+    HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[1], 0));
+    OKR(launch_tn(sw, B * tail_cells, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, 0, tail_cells}, LevelRowsA{IH, Dp, C, 0, tail_cells},
                   wb + bw.slab2, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat, tail_cells < C));
-    OKR(launch_tn(plan->side, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
-    HIPOK(hipEventRecord(plan->ev_join[1], plan->side));
+    OKR(launch_tn(sw, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
+    HIPOK(hipEventRecord(plan->ev_join[1], sw));
     {
-        // shared weights: inside and outside pair rows are one contiguous range -> one launch
         ProfScope ps(CLIORA_KCLASS_WGRAD, st);
+        if (ran_outside && !p.share)
+            OKR(launch_tn_pairs(st, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
+                                wb + bw.gw2o, wb + bw.gb2o));
+        // shared weights: inside and outside pair rows are one contiguous range -> one launch
         const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
         OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
         if (p.share) {
@@ -526,7 +608,6 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
         }
     }
-    if (ran_outside) HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
     HIPOK(hipStreamWaitEvent(st, plan->ev_join[1], 0));
 
     if (vl && d_obj_span) {

@@ -171,6 +171,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
             f.ncb3 = nt / f.ct3;
         }
         f.hp = take(arch == 0 ? (size_t)HP_PARTS * BC * Dp : 0);
+        f.hp_o = take(arch == 0 ? (size_t)HP_PARTS * BC * Dp : 0);
         f.ymask = take(arch == 0 ? Rt * f.ncb3 * 4 : 0);
         f.nrmi = take(BC);
         f.nrmo = take(BC);
@@ -188,6 +189,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         size_t o = 0;
         auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
         b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
+        b.vh_o = take(arch == 0 ? BC * Dp : 0); b.dg_o = take(arch == 0 ? BC * Dp : 0); b.dstot_o = take(arch == 0 ? BC : 0);
         b.da = take(Rt * (lstm ? 5 : 1) * Dp); b.ds = take(Rt);
         b.dz = take(Rt * Dp);
         b.x = take(arch == 0 ? Rt * Dp : 0);

@@ -48,7 +48,8 @@ struct FwdLayout {
     size_t pair_h;                      // DioraMLP hooks: per-pair compose outputs (R x Dp) in the OPTIONAL tail of the workspace (beyond `total`)
     size_t pair_h_floats;               // size of that tail
     size_t sp, pp;                      // per-pair score / softmax weight (R)
-    size_t hp;                          // partial aggregates of level_compose_fwd: HP_PARTS x (B*C x Dp), summed by level_project
+    size_t hp, hp_o;                    // partial aggregates of level_compose_fwd: HP_PARTS x (B*C x Dp), summed by level_project;
+                                        // one per pass (the two passes run as a wavefront on two streams)
     size_t ymask;                       // ReLU bits of the compose output y: R x ncb3 x 4 words (word g of a column block: 4 bits per 16-column tile)
     int ct3, ncb3;                      // column tiles per weight-stationary column block / number of such blocks (Dp = 16 * ct3 * ncb3)
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
@@ -58,7 +59,8 @@ struct FwdLayout {
 };
 
 struct BwdLayout {
-    size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C)
+    size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C): inside chart
+    size_t vh_o, dg_o, dstot_o;         // the same for the outside chart (the two backward chains run as a wavefront on two streams)
     size_t da, ds;                      // per-pair grads (R x Dp), (R)
     size_t dz;                          // per-pair grad at the second pre-activation (R x Dp); TreeLSTM: d c_a per pair
     size_t x;                           // DioraMLP: per-pair first-layer activation relu(PL+PR) (R x Dp), re-formed by level_compose_bwd for the weight gradient
