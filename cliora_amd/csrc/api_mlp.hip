@@ -79,10 +79,10 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
 template <int CT, int K16, bool F32>
 static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* dG,
                                          const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB, int ldb, const float* b2,
-                                         float* DA, float* DZ, float* X, float* DPP, float* DPB) {
+                                         float* DA, float* DZ, float* X, float* DPP, float* DPB, int cus) {
     OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32>));
     const int ntiles = (lv.ncell + 15) / 16 * lv.N;
-    const int cap = std::max(1, 256 / ncb);
+    const int cap = std::max(1, cus / ncb);
     const int passes = (ntiles + 8 * cap - 1) / (8 * cap);
     int gx = (ntiles + 8 * passes - 1) / (8 * passes);
     if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;      // column blocks of the same tiles on one XCD
@@ -95,12 +95,12 @@ static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, i
 // backward of the level's compose layer: DA, DZ, X rows and the partial dG.y_n (see level_compose_bwd).  WT: plain fp32 W2^T.
 static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float* WTimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
                                     const float* dG, const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB,
-                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB) {
+                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB, int cus = 256) {
     if (lv.N <= 0 || lv.ncell <= 0) return CLIORA_OK;
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? WT : WTimg);
     const int S = f32 ? Dp : S3;
-#define LB_ARGS st, I, S, Dp, ncb, lv, dG, ymask, Pp, PA, lda, PB, ldb, b2, DA, DZ, X, DPP, DPB
+#define LB_ARGS st, I, S, Dp, ncb, lv, dG, ymask, Pp, PA, lda, PB, ldb, b2, DA, DZ, X, DPP, DPB, cus
 #define LB_CASE(c, k16) return f32 ? launch_level_compose_bwd_inst<c, k16, true>(LB_ARGS) : launch_level_compose_bwd_inst<c, k16, false>(LB_ARGS)
     if (ct == 5 && Dp == 400) LB_CASE(5, 25);
     switch (ct) {
@@ -309,22 +309,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     const bool two_streams = wavefront_env != 0 && run_outside && L > 2;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
-    // CUs each of the two concurrent compose launches of a step plans for (one workgroup fills a CU's LDS): in proportion to their tiles
-    static const int wf_budget_env = [] { const char* e = getenv("CLIORA_WF_BUDGET"); return e ? atoi(e) : 0; }();
-    auto level_tiles = [&](int level, bool outside_pass) {
-        if (level < 0 || level > L - 1) return 0;
-        const LevelArgs g = level_args(p, level, outside_pass);
-        return (B * g.Lc + 15) / 16 * g.N;
-    };
-    auto cu_budget = [&](int level, bool outside_pass) {
-        if (!two_streams) return 256;
-        const int other = L - (outside_pass ? level : level);           // inside level k runs beside outside level L-k and vice versa
-        const int mine = level_tiles(level, outside_pass), theirs = level_tiles(other, !outside_pass);
-        if (theirs == 0 || mine == 0) return 256;
-        if (wf_budget_env > 0) return wf_budget_env;
-        const int c = (int)(256.0 * mine / (mine + theirs));
-        return std::min(216, std::max(40, (c + 20) / 40 * 40));         // multiples of 40: 8 column groups of 5 blocks
-    };
     auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
@@ -332,7 +316,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sa);
             OKR(launch_level_compose(sa, ws + f.w2i, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi,
-                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, &SP, cu_budget(level, false)));
+                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, &SP));
         }
         if (vl) {   // cliora.py:140-157: attention residual between the aggregate and the second unit norm, then the projections
             hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, sa, g, L, PairScoreArgs{}, (const float*)nullptr,
@@ -361,8 +345,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sb);
             OKR(launch_level_compose(sb, ws + f.w2o, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true),
-                                     ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HPo, hp_stride, YM, PH, &SP,
-                                     cu_budget(level, true)));
+                                     ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HPo, hp_stride, YM, PH, &SP));
         }
         if (level >= 1)      // the level below is scored in the same launch: its newest parents are this level's cells
             OKR(launch_level_project(sb, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HPo, hp_stride, p.normalize, nullptr,

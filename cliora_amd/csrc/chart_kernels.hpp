@@ -330,15 +330,22 @@ __device__ __forceinline__ void gather_uses(const UseTab& ut, int c, int b, int 
     }
 }
 
-// fixed-order sum of the four waves' partial float4 pairs through LDS; every wave gets the total
+// fixed-order sum of the four waves' partial float4 pairs through LDS, as a two-level tree ((w0 + w2) + (w1 + w3)) over a
+// two-wave buffer: 20 KB instead of 40, so that a gather workgroup fits on a CU beside a level_compose_bwd workgroup (the two
+// chains of the backward wavefront overlap there).  Wave 0 gets the total.
 constexpr int GATHER_SLOTS = 10;
 __device__ __forceinline__ void wg_sum_pairs(float4 (*sh)[GATHER_SLOTS][64], int wave, int lane, int nslots, float4* v) {
-    for (int k = 0; k < nslots; ++k) sh[wave][k][lane] = v[k];
+    if (wave >= 2)
+        for (int k = 0; k < nslots; ++k) sh[wave - 2][k][lane] = v[k];
     __syncthreads();
-    for (int k = 0; k < nslots; ++k) {
-        const float4 a = sh[0][k][lane], b = sh[1][k][lane], c = sh[2][k][lane], d = sh[3][k][lane];
-        v[k] = f4add(f4add(f4add(a, b), c), d);
-    }
+    if (wave < 2)
+        for (int k = 0; k < nslots; ++k) v[k] = f4add(v[k], sh[wave][k][lane]);
+    __syncthreads();
+    if (wave == 1)
+        for (int k = 0; k < nslots; ++k) sh[0][k][lane] = v[k];
+    __syncthreads();
+    if (wave == 0)
+        for (int k = 0; k < nslots; ++k) v[k] = f4add(v[k], sh[0][k][lane]);
 }
 
 static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
@@ -347,7 +354,7 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
                                                           const float* __restrict__ PI, int ldpi, int share,
                                                           const float* __restrict__ IH, const float* __restrict__ OH,
                                                           float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ dStot) {
-    __shared__ float4 sh[4][GATHER_SLOTS][64];
+    __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x;
@@ -411,7 +418,7 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, i
                                                            UseTab outb, const float* __restrict__ DA, const float* __restrict__ DS,
                                                            const float* __restrict__ PI, int ldpi, int blk_qlo,
                                                            float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ dStot) {
-    __shared__ float4 sh[4][GATHER_SLOTS][64];
+    __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x;
