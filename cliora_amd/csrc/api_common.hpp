@@ -25,10 +25,14 @@ struct cliora_plan {
     bool uploaded = false;
     int device = -1;            // HIP device the index tables live on (set at upload; every later call must run there)
     // side: the second chain of the inside / outside wavefront (forward: the outside pass, backward: the outside pass's backward);
-    // side2: weight-gradient GEMMs beside the level chains.  Fork / join with the caller's stream by events.
+    // side2: weight-gradient GEMMs beside the level chains.  Fork / join with the caller's stream by events.  The streams and events
+    // belong to the DEVICE (api_core.hip: device_lanes), not to the plan: HIP deals streams round-robin onto a few hardware queues,
+    // and a per-plan side stream that lands on the caller's queue serialises the two chains (measured: 6.45 -> 6.97 ms at L = 24
+    // with five plans alive).  `lanes_mu` is held while a call enqueues (the events are shared by every plan of the device).
     hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> ev_level;   // one per chart level: "this chain has finished level k" for the other chain
+    const hipEvent_t* ev_level = nullptr;   // one per chart level: "this chain has finished level k" for the other chain
+    std::mutex* lanes_mu = nullptr;
 };
 
 extern thread_local std::string g_cliora_err;

@@ -71,14 +71,7 @@ extern "C" int cliora_plan_create_ex(int B, int L, int D, int share, int normali
 extern "C" void cliora_plan_destroy(cliora_plan* plan) {
     if (!plan) return;
     if (plan->p.d_tables) (void)hipFree(plan->p.d_tables);
-    for (int k = 0; k < 3; ++k) {
-        if (plan->ev_fork[k]) (void)hipEventDestroy(plan->ev_fork[k]);
-        if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
-    }
-    for (hipEvent_t e : plan->ev_level) (void)hipEventDestroy(e);
-    if (plan->side) (void)hipStreamDestroy(plan->side);
-    if (plan->side2) (void)hipStreamDestroy(plan->side2);
-    delete plan;
+    delete plan;                       // streams and events belong to the device (device_lanes)
 }
 
 extern "C" size_t cliora_plan_fwd_workspace_bytes(const cliora_plan* plan) { return plan ? plan->p.fwd.total * sizeof(float) : 0; }
@@ -103,6 +96,33 @@ extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
     return n * sizeof(int32_t);
 }
 
+// Side streams and fork / join / level events of one device, created at the first call there and kept for the life of the process.
+struct DeviceLanes {
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t fork[3], join[3], level[CLIORA_MAX_L + 1];
+    std::mutex mu;
+};
+static int device_lanes(int dev, DeviceLanes** out) {
+    static std::mutex g_mu;
+    static DeviceLanes* g_lanes[64] = {};
+    if (dev < 0 || dev >= 64) return fail(CLIORA_EINVAL, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_lanes[dev]) {
+        DeviceLanes* ln = new (std::nothrow) DeviceLanes();
+        if (!ln) return fail(CLIORA_ENOMEM, "host allocation failed");
+        HIPOK(hipStreamCreateWithFlags(&ln->side, hipStreamNonBlocking));
+        HIPOK(hipStreamCreateWithFlags(&ln->side2, hipStreamNonBlocking));
+        for (int k = 0; k < 3; ++k) {
+            HIPOK(hipEventCreateWithFlags(&ln->fork[k], hipEventDisableTiming));
+            HIPOK(hipEventCreateWithFlags(&ln->join[k], hipEventDisableTiming));
+        }
+        for (int k = 0; k <= CLIORA_MAX_L; ++k) HIPOK(hipEventCreateWithFlags(&ln->level[k], hipEventDisableTiming));
+        g_lanes[dev] = ln;
+    }
+    *out = g_lanes[dev];
+    return CLIORA_OK;
+}
+
 int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     int dev = 0;
     HIPOK(hipGetDevice(&dev));
@@ -117,17 +137,12 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     HIPOK(hipMemcpyAsync(plan->p.d_tables, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPOK(hipStreamSynchronize(st));   // `flat` dies at scope exit
     plan->p.d_tables_count = flat.size();
-    HIPOK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
-    HIPOK(hipStreamCreateWithFlags(&plan->side2, hipStreamNonBlocking));
-    for (int k = 0; k <= plan->p.L; ++k) {
-        hipEvent_t e;
-        HIPOK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        plan->ev_level.push_back(e);
-    }
-    for (int k = 0; k < 3; ++k) {
-        HIPOK(hipEventCreateWithFlags(&plan->ev_fork[k], hipEventDisableTiming));
-        HIPOK(hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming));
-    }
+    DeviceLanes* ln = nullptr;
+    OKR(device_lanes(dev, &ln));
+    plan->side = ln->side; plan->side2 = ln->side2;
+    for (int k = 0; k < 3; ++k) { plan->ev_fork[k] = ln->fork[k]; plan->ev_join[k] = ln->join[k]; }
+    plan->ev_level = ln->level;
+    plan->lanes_mu = &ln->mu;
     plan->uploaded = true;
     plan->device = dev;
     return CLIORA_OK;

@@ -11,7 +11,7 @@ static size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch) {
     if (B < 1 || L < 1 || D < 1) return "B, L, D must be positive";
     if (D > 512) return "D > 512 is not supported by the weight-stationary kernels";
-    if (L > 64) return "L > 64 is not supported (one split per lane in the score kernels)";
+    if (L > CLIORA_MAX_L) return "L > 64 is not supported (one split per lane in the score kernels)";
     if (R < 0 || R > 64) return "R (image regions) must be in [0, 64]";
     if (normalize != 0 && normalize != 1) return "normalize must be 0 (none) or 1 (unit)";
     p.B = B; p.L = L; p.D = D; p.Dp = (D + 15) / 16 * 16; p.C = ncells(L);

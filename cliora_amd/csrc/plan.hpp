@@ -19,7 +19,8 @@ constexpr int ROLE_INB = 1;   // inside cell used as RIGHT child in the inside p
 constexpr int ROLE_OUTA = 2;  // inside cell used as SIBLING in the outside pass
 constexpr int ROLE_OUTB = 3;  // outside cell used as PARENT in the outside pass
 constexpr int N_ROLES = 4;
-constexpr int HP_PARTS = 4;   // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
+constexpr int HP_PARTS = 4;
+constexpr int CLIORA_MAX_L = 64;   // sentence length bound: one split per lane in the score kernels   // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
 
 struct UseList {
     std::vector<int32_t> off;      // C+1, CSR offsets per cell
