@@ -299,18 +299,36 @@ def main():
             step()
         fence()
         dt_ev = time.perf_counter() - t1
+    # Third pass, wavefront off: the same launches one after the other on one stream.  In the default schedule the compose kernels of
+    # the two chains run side by side, so a launch's event-to-event time includes the share of the chip its neighbour holds; this
+    # pass gives the kernel's duration with the chip to itself (reported beside the as-run figure, never instead of it).
+    kern, kern_seq, dt_seq, n_seq = {}, {}, None, min(args.steps, 20)
+    if not args.no_kernel_events:
+        if events:
+            stream = torch.cuda.current_stream().cuda_stream
+            for k in kclasses:
+                ms, n = _lib.prof_read(k, stream)            # reads and resets; recording stays on for the third pass
+                kern[k] = dict(total_ms=ms, launches=n)
+        prev_wf = _lib.set_wavefront('off')
+        try:
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n_seq):
+                step()
+            fence()
+            dt_seq = time.perf_counter() - t1
+        finally:
+            _lib.set_wavefront(prev_wf)
+        if events:
+            for k in kclasses:
+                ms, n = _lib.prof_read(k, stream)
+                _lib.prof_enable(k, False)
+                kern_seq[k] = dict(total_ms=ms, launches=n)
 
     if rank == 0:
         pairs = (L - 1) * L * (L + 1) // 2          # span pairs per sentence, inside + outside
         Dp = (D + 15) // 16 * 16
         flops_class = 2.0 * Dp * Dp * pairs * B      # one D x D layer per pair (factored compose), per step
-        kern = {}
-        if events:
-            stream = torch.cuda.current_stream().cuda_stream
-            for k in kclasses:
-                ms, n = _lib.prof_read(k, stream)
-                _lib.prof_enable(k, False)
-                kern[k] = dict(total_ms=ms, launches=n)
         roof = None
         if kern and all(v['launches'] for v in kern.values()):
             plan = _lib.get_plan(B, L, D, True, 'unit', 0, local)
@@ -352,8 +370,14 @@ def main():
                                        peak_TFLOPs=round(peak_mfma, 1), frac=round(t_mfma / t_meas, 4),
                                        frac_of_f32_mfma_peak=round(ach_tf / PEAK_FP32_MFMA_TFLOPS, 4)),
                         avg_launch_ms=round(avg_ms, 5), launches_per_step=nlaunch,
-                        measured='second pass of the same %d steps with per-launch HIP events' % args.steps,
+                        measured='second pass of the same %d steps with per-launch HIP events on the stream each launch goes to; in the default '
+                                 'schedule the two chains\' compose kernels share the chip, so a launch\'s duration includes its neighbour\'s share' % args.steps,
                         ms_per_step_with_events=round(dt_ev / args.steps * 1e3, 4),
+                        sequential=(dict(note='same kernel with the chip to itself: %d steps with cliora_set_wavefront(OFF), one stream' % n_seq,
+                                         avg_launch_ms=round(kern_seq[dom]['total_ms'] / kern_seq[dom]['launches'], 5),
+                                         frac=round(max(t_hbm, t_mfma) / (kern_seq[dom]['total_ms'] / n_seq * 1e-3), 4),
+                                         ms_per_step_with_events=round(dt_seq / n_seq * 1e3, 4))
+                                    if kern_seq.get(dom) and kern_seq[dom]['launches'] else None),
                         implementation_bytes=impl_bytes,
                         whole_step=dict(algorithmic_bytes=round(step_bytes), achieved_GBs=round(step_bytes / (dt / args.steps) / 1e9, 1),
                                         frac_of_hbm=round(step_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4)),

@@ -89,6 +89,8 @@ def lib():
     L.cliora_version.restype = C.c_char_p
     L.cliora_set_mfma_mode.argtypes = [i32]
     L.cliora_set_mfma_mode.restype = i32
+    L.cliora_set_wavefront.argtypes = [i32]
+    L.cliora_set_wavefront.restype = i32
     _lib = L
     return L
 
@@ -181,6 +183,16 @@ def prof_read(kclass, stream=0):
 
 
 MFMA_MODES = {'f32': 0, 'bf16x3': 1}
+
+
+WAVEFRONT_MODES = {'auto': -1, 'off': 0, 'on': 1}
+
+
+def set_wavefront(mode):
+    """Scheduling of the inside / outside passes (include/cliora_chart.h: cliora_set_wavefront): 'auto' (default), 'off' (the
+    reference's order on the caller's stream alone) or 'on'.  Results are bitwise identical.  Returns the previous mode."""
+    prev = lib().cliora_set_wavefront(WAVEFRONT_MODES[mode])
+    return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
 
 
 def set_mfma_mode(mode):

@@ -86,6 +86,7 @@ struct ProfScope {
 
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
+extern int g_cliora_wavefront;      // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_wavefront)
 extern int g_cliora_split_bf16;
 static inline bool split_bf16() {
     if (g_cliora_split_bf16 < 0) {

@@ -232,4 +232,11 @@ extern "C" int cliora_set_mfma_mode(int mode) {
     return prev;
 }
 
+int g_cliora_wavefront = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+extern "C" int cliora_set_wavefront(int mode) {
+    const int prev = g_cliora_wavefront;
+    g_cliora_wavefront = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
+    return prev;
+}
+
 extern "C" const char* cliora_version(void) { return "cliora_amd 0.2 (gfx950)"; }

@@ -149,7 +149,7 @@ static int launch_level_project(hipStream_t st, int SP, const float* Wfrag, int 
 
 // Two streams pay when a level's launches carry enough work to outweigh the event per step (3 us): measured on MI355X from
 // B 64 / L 8 / d 400 (1.17 -> 0.90 ms) to B 64 / L 40 / d 400 (23.1 -> 20.9 ms); B 8 / L 10 / d 50 loses (0.76 -> 0.95 ms).
-// CLIORA_WAVEFRONT=0 / 1 forces it off / on.
+// cliora_set_wavefront / CLIORA_WAVEFRONT=0|1 force it off / on.
 static bool wavefront_pays(const Plan& p, int env) {
     if (p.L <= 2 || env == 0) return false;
     if (env == 1) return true;
@@ -316,8 +316,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
-    static const int wavefront_env = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? atoi(e) : -1; }();
-    const bool two_streams = wavefront_pays(p, wavefront_env) && run_outside;
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
     auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
@@ -473,8 +472,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // The backward of outside level t only feeds inside cells of levels <= L-2-t (its siblings), so the backward of the inside
     // pass does not have to wait for the whole outside backward: step j runs outside level j on the plan's side stream and
     // inside level L-1-j on the caller's stream, which waits for the event of outside step j-1 (see cliora_chart_forward).
-    static const int wavefront_env = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? atoi(e) : -1; }();
-    const bool two_streams = wavefront_pays(p, wavefront_env) && ran_outside;
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside;
     hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
     float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
 

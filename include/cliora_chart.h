@@ -211,6 +211,18 @@ const char* cliora_last_error(void);
 #define CLIORA_MFMA_SPLIT_BF16 1
 int cliora_set_mfma_mode(int mode);
 
+/* Scheduling of the two passes.  Outside level t only reads inside levels <= L-2-t (cliora/net/outside_index.py:39-127), so the
+ * outside pass (and, in the backward, the inside pass's backward) can run one step behind the other pass instead of after it:
+ * two dependent chains on two HIP streams (the caller's and one owned by the library, forked and joined by events inside every
+ * call, so the caller's stream semantics are unchanged).  CLIORA_WAVEFRONT_AUTO (default; the environment variable
+ * CLIORA_WAVEFRONT=0|1 sets the initial value) uses two streams when a level carries enough work to pay for the events;
+ * OFF runs the reference's order on the caller's stream alone.  Results are bitwise identical either way.  Process-wide;
+ * returns the previous mode. */
+#define CLIORA_WAVEFRONT_AUTO (-1)
+#define CLIORA_WAVEFRONT_OFF 0
+#define CLIORA_WAVEFRONT_ON 1
+int cliora_set_wavefront(int mode);
+
 const char* cliora_version(void);
 
 #ifdef __cplusplus
