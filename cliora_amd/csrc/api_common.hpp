@@ -176,25 +176,12 @@ static int launch_ksplit_f32(hipStream_t st, const float* W, int K, int nt, int 
 }
 
 // image kinds a split-K launch can take beside the plain weight
-enum { IMG_NONE = 0, IMG_SPLIT_BF16 = 1, IMG_FRAG_F32 = 2 };
+enum { IMG_NONE = 0, IMG_FRAG_F32 = 2 };
 
 template <class AP, class EP>
 static int launch_rows_direct(hipStream_t st, const float* W, const float* img, int kind, int K, int ncols, int nrows, AP ap, EP ep) {
     if (nrows <= 0) return CLIORA_OK;
     const int nt = ncols / 16;
-    const int nrg = ((nrows + 15) / 16 + 1) / 2;
-    // linear id = rg + cb * nrgp with nrgp a multiple of 8: the column blocks of one row group share an XCD (L2 reuse of A)
-    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
-    if (kind == IMG_SPLIT_BF16) {      // split-bf16 arithmetic on the weight's image
-        const uint32_t* I = reinterpret_cast<const uint32_t*>(img);
-        const int S = image_stride(K);
-        if (nt % 5 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 5, AP, EP>), dim3(nrgp * (nt / 5)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 5, nrows, ap, ep);
-        else if (nt % 4 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 4, AP, EP>), dim3(nrgp * (nt / 4)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 4, nrows, ap, ep);
-        else if (nt % 2 == 0) hipLaunchKernelGGL((rows_gemm_ksplit3<2, 2, AP, EP>), dim3(nrgp * (nt / 2)), dim3(256), 0, st, I, S, K, nrg, nrgp, nt / 2, nrows, ap, ep);
-        else hipLaunchKernelGGL((rows_gemm_ksplit3<2, 1, AP, EP>), dim3(nrgp * nt), dim3(256), 0, st, I, S, K, nrg, nrgp, nt, nrows, ap, ep);
-        LAUNCHOK("rows_gemm_ksplit3");
-        return CLIORA_OK;
-    }
     if (kind == IMG_FRAG_F32) return launch_ksplit_f32<true>(st, img, K, nt, nrows, ap, ep);
     return launch_ksplit_f32<false>(st, W, K, nt, nrows, ap, ep);
 }
@@ -318,64 +305,6 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
     if (NT <= 27) TN_CASE(7, 9, 3);     // 63 accumulator tiles = 252 registers: the most that stays spill-free
     TN_CASE(8, 8, 4);
 #undef TN_CASE
-}
-
-template <int CT, int WAVES, int K16, class AP, class EP>
-static int launch_rows3_k(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
-    constexpr int PD = 4;     // four k-steps of row operands in flight per wave; deeper rings (6, 7) measured the same on MI355X
-    const size_t lds = (size_t)CT * 16 * S * sizeof(uint32_t);
-    OKR(cliora_ensure_max_lds((const void*)rows_gemm_ws3<CT, WAVES, PD, K16, AP, EP>));
-    const int ntiles = (nrows + 15) / 16;
-    const int gy = ncols / (16 * CT);
-    // same grid rule as the fp32 kernel: fewest passes over the row tiles, then the smallest grid that does it
-    const int cap = std::max(1, 256 / gy);
-    const int passes = (ntiles + WAVES * cap - 1) / (WAVES * cap);
-    int gx = (ntiles + WAVES * passes - 1) / (WAVES * passes);
-    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;
-    hipLaunchKernelGGL((rows_gemm_ws3<CT, WAVES, PD, K16, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, Wimg, S, K, nrows, ap, ep);
-    LAUNCHOK("rows_gemm_ws3");
-    return CLIORA_OK;
-}
-
-template <int CT, int WAVES, class AP, class EP>
-static int launch_rows3_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
-    // the hidden size of the reference's configurations (d = 400, K = 25 * 16) runs the fully unrolled instance
-    if (CT == 5 && K == 400) return launch_rows3_k<CT, WAVES, 25>(st, Wimg, S, K, ncols, nrows, ap, ep);
-    return launch_rows3_k<CT, WAVES, 0>(st, Wimg, S, K, ncols, nrows, ap, ep);
-}
-
-// out[r][j] = sum_k A(r,k) W[j][k] in split-bf16 arithmetic; Wimg = split_weight_image of W ([ncols][K], S dwords per row)
-template <class AP, class EP>
-static int launch_rows3(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
-    if (nrows <= 0) return CLIORA_OK;
-    const size_t budget = 150 * 1024;
-    const int nt = ncols / 16;
-    const long long ntiles = (nrows + 15) / 16;
-    for (int ct : {5, 4, 2, 1}) {
-        if (nt % ct) continue;
-        if ((size_t)ct * 16 * S * sizeof(uint32_t) > budget) continue;
-        const bool two = ntiles * (nt / ct) > 1536;      // two waves per SIMD once the launch fills the chip
-        switch (ct) {
-#define WS3_CASE(c) case c: return two ? launch_rows3_inst<c, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<c, 4>(st, Wimg, S, K, ncols, nrows, ap, ep)
-            WS3_CASE(5); WS3_CASE(4); WS3_CASE(2);
-            default: return two ? launch_rows3_inst<1, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<1, 4>(st, Wimg, S, K, ncols, nrows, ap, ep);
-#undef WS3_CASE
-        }
-    }
-    return fail(CLIORA_EINVAL, "weight block does not fit LDS");
-}
-
-// compose layer: weight-stationary kernel for the big levels, split-K kernel for the small ones
-static int g_compose_ksplit_rows = -1;  // per translation unit
-template <class AP, class EP>
-static int launch_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int nrows, AP ap, EP ep) {
-    if (g_compose_ksplit_rows < 0) {
-        const char* e = getenv("CLIORA_COMPOSE_KSPLIT_ROWS");
-        g_compose_ksplit_rows = e ? atoi(e) : 1500;   // measured crossover on MI355X (r01 sweeps: 5000 for the fp32 kernels, 1500 with the split-bf16 ones)
-    }
-    if (nrows <= g_compose_ksplit_rows) return launch_rows_direct(st, W, Wimg, split_bf16() ? IMG_SPLIT_BF16 : IMG_NONE, Dp, Dp, nrows, ap, ep);
-    if (split_bf16()) return launch_rows3(st, reinterpret_cast<const uint32_t*>(Wimg), S3, Dp, Dp, nrows, ap, ep);
-    return launch_rows(st, W, Dp, 1, Dp, nrows, ap, ep);
 }
 
 // split-bf16 images (see split_weight_image) of weight matrices already in the workspace

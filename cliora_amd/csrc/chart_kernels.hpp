@@ -140,135 +140,7 @@ static __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const
     if (lane == 0) Sout[(size_t)b * g.C + g.off + p] = st;
 }
 
-// ---------------------------------------------------------------------------------
-// Softmax-weighted sum of the per-split compose outputs + unit norm (diora.py:137-149):
-//   g = sum_n p_n y_n;  H(target) = g / max(||g||, eps)
-// ---------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void cell_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ Pp,
-                                                          int normalize, float* __restrict__ H, float* __restrict__ nrm) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.B * g.Lc) return;
-    const int b = t / g.Lc, p = t - b * g.Lc;
-    const int row0 = g.rowbase + t * g.N;
-    const int nv = g.Dp >> 2;
-    const bool a0 = lane < nv, a1 = lane + 64 < nv;
-    float4 v0 = f4zero(), v1 = f4zero();
-    for (int n0 = 0; n0 < g.N; n0 += 4) {        // four rows in flight; accumulation stays in split order
-        float pn[4];
-        float4 y0[4], y1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + j, g.N - 1);
-            pn[j] = (n0 + j < g.N) ? Pp[row0 + n] : 0.f;
-            const float* y = Y + (size_t)(row0 + n) * g.Dp;
-            y0[j] = a0 ? ld4(y + 4 * lane) : f4zero();
-            y1[j] = a1 ? ld4(y + 4 * (lane + 64)) : f4zero();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v0 = f4fma(pn[j], y0[j], v0); v1 = f4fma(pn[j], y1[j], v1); }
-    }
-    const float nr = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
-    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
-    const size_t crow = (size_t)b * g.C + g.off + p;
-    float* h = H + crow * g.Dp;
-    if (a0) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
-    if (a1) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
-    if (lane == 0) nrm[crow] = nr;
-}
 
-// ---------------------------------------------------------------------------------
-// pair_scores_fwd + cell_aggregate_fwd in one launch (text-only path): one workgroup per target cell.
-//   phase 1  wave w scores the splits n = w, w+4, ...                       (bilinear score, diora.py:25-52)
-//   phase 2  every wave takes the softmax over the N scores                 (diora.py:137-143)
-//   phase 3  wave w sums p_n y_n over its splits, the four partial vectors meet in LDS and are added in wave
-//            order (fixed summation order), then the unit norm              (diora.py:145-149)
-// The wave's first y rows are fetched before phase 1: they do not depend on the scores.
-// ---------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void cell_scores_aggregate_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
-                                                                 const float* __restrict__ QA, int ldA, const float* __restrict__ HB,
-                                                                 const float* SA, const float* SB,
-                                                                 float* __restrict__ Sp, float* __restrict__ Pp, float* Sout,
-                                                                 const float* __restrict__ Y, int normalize, float* __restrict__ H,
-                                                                 float* __restrict__ nrm) {
-    __shared__ float sh_s[64];
-    __shared__ float4 sh_v[4][128];
-    __shared__ float sh_r[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
-    const int b = t / g.Lc, p = t - b * g.Lc;
-    const int row0 = g.rowbase + t * g.N;
-    const int nv = g.Dp >> 2;
-    const bool a0 = lane < nv, a1 = lane + 64 < nv;
-    float4 y0[4], y1[4];
-    auto load_y = [&](int n0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + 4 * j, g.N - 1);
-            const float* y = Y + (size_t)(row0 + n) * g.Dp;
-            y0[j] = a0 ? ld4(y + 4 * lane) : f4zero();
-            y1[j] = a1 ? ld4(y + 4 * (lane + 64)) : f4zero();
-        }
-    };
-    load_y(wave);
-    for (int n0 = wave; n0 < g.N; n0 += 16) {
-        int ar[4], br[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + 4 * j, g.N - 1);
-            ar[j] = arow[row0 + n];
-            br[j] = brow[row0 + n];
-        }
-        float d[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* qa = QA + (size_t)ar[j] * ldA;
-            const float* hb = HB + (size_t)br[j] * g.Dp;
-            float v = 0.f;
-            if (a0) v = f4dot(ld4(qa + 4 * lane), ld4(hb + 4 * lane));
-            if (a1) v += f4dot(ld4(qa + 4 * (lane + 64)), ld4(hb + 4 * (lane + 64)));
-            d[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s = wave_sum(d[j]) + SA[ar[j]] + SB[br[j]];
-            if (lane == 0 && n0 + 4 * j < g.N) sh_s[n0 + 4 * j] = s;
-        }
-    }
-    __syncthreads();
-    const float my_s = lane < g.N ? sh_s[lane] : -INFINITY;
-    const float m = wave_max(my_s);
-    const float e = lane < g.N ? expf(my_s - m) : 0.f;
-    const float pn = e / wave_sum(e);
-    if (wave == 0) {
-        if (lane < g.N) { Sp[row0 + lane] = my_s; Pp[row0 + lane] = pn; }
-        const float st = wave_sum(lane < g.N ? pn * my_s : 0.f);
-        if (lane == 0) Sout[(size_t)b * g.C + g.off + p] = st;
-    }
-    float4 v0 = f4zero(), v1 = f4zero();
-    for (int n0 = wave; n0 < g.N; n0 += 16) {
-        if (n0 != wave) load_y(n0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 4 * j;
-            const float w = __shfl(pn, min(n, 63));
-            if (n < g.N) { v0 = f4fma(w, y0[j], v0); v1 = f4fma(w, y1[j], v1); }
-        }
-    }
-    if (a0) sh_v[wave][lane] = v0;
-    if (a1) sh_v[wave][lane + 64] = v1;
-    __syncthreads();
-    float4 sum = f4zero();
-    if (tid < nv) sum = f4add(f4add(f4add(sh_v[0][tid], sh_v[1][tid]), sh_v[2][tid]), sh_v[3][tid]);
-    const float ss = wave_sum(f4dot(sum, sum));
-    if (lane == 0) sh_r[wave] = ss;
-    __syncthreads();
-    const float nr = sqrtf((sh_r[0] + sh_r[1]) + (sh_r[2] + sh_r[3]));
-    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
-    const size_t crow = (size_t)b * g.C + g.off + p;
-    if (tid < nv) st4(H + crow * g.Dp + 4 * tid, make_float4(sum.x / den, sum.y / den, sum.z / den, sum.w / den));
-    if (tid == 0) nrm[crow] = nr;
-}
 
 // ---------------------------------------------------------------------------------
 // Backward, step 1 for the cells of one level: gather every use of the cell.
@@ -465,61 +337,6 @@ __device__ __forceinline__ void unit_norm_bwd(float4& v0, float4& v1, float4 h0,
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Backward, step 2 for the target cells of one level: unit-norm backward, then the
-// softmax / score backward:   dp_n = dG . y_n
-//   ds_n = p_n [ (dp_n - sum_m p_m dp_m) + dS_tot (1 + s_n - S) ]
-// ---------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void cell_scores_bwd(LevelArgs g, const float* __restrict__ VH, const float* __restrict__ H,
-                                                       const float* __restrict__ nrm, int normalize,
-                                                       const float* __restrict__ Y, const float* __restrict__ Sp, const float* __restrict__ Pp,
-                                                       const float* __restrict__ Schart, const float* __restrict__ dStot,
-                                                       float* __restrict__ dG, float* __restrict__ DS) {
-    // one workgroup (4 waves) per target cell; every wave does the (cheap) unit-norm backward of the
-    // row, wave w then takes the dot products with the split outputs n = w, w+4, ...
-    __shared__ float sh_dp[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
-    const int b = t / g.Lc, p = t - b * g.Lc;
-    const size_t crow = (size_t)b * g.C + g.off + p;
-    const int Dp = g.Dp, nv = Dp >> 2;
-    const bool a0 = lane < nv, a1 = lane + 64 < nv;
-    float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
-    if (a0) { v0 = ld4(VH + crow * Dp + 4 * lane); h0 = ld4(H + crow * Dp + 4 * lane); }
-    if (a1) { v1 = ld4(VH + crow * Dp + 4 * (lane + 64)); h1 = ld4(H + crow * Dp + 4 * (lane + 64)); }
-    unit_norm_bwd(v0, v1, h0, h1, nrm[crow], normalize);
-    if (wave == 0) {
-        if (a0) st4(dG + crow * Dp + 4 * lane, v0);
-        if (a1) st4(dG + crow * Dp + 4 * (lane + 64), v1);
-    }
-    if (g.N == 0) return;
-    const int row0 = g.rowbase + t * g.N;
-    for (int n0 = wave; n0 < g.N; n0 += 16) {
-        float d[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* y = Y + (size_t)(row0 + min(n0 + 4 * j, g.N - 1)) * Dp;
-            float v = 0.f;
-            if (a0) v = f4dot(v0, ld4(y + 4 * lane));
-            if (a1) v += f4dot(v1, ld4(y + 4 * (lane + 64)));
-            d[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float r = wave_sum(d[j]);
-            if (lane == 0 && n0 + 4 * j < g.N) sh_dp[n0 + 4 * j] = r;
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const bool an = lane < g.N;
-    const float dp = an ? sh_dp[lane] : 0.f;
-    const float pn = an ? Pp[row0 + lane] : 0.f;
-    const float sn = an ? Sp[row0 + lane] : 0.f;
-    const float mean = wave_sum(pn * dp);
-    const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + sn - Schart[crow]));
-    if (an) DS[row0 + lane] = ds;
-}
 
 // leaves: H = unit(T), T = tanh(U)  (diora.py:58-63, 283-292):  dU = normbwd(vH) * (1 - T^2)
 static __global__ __launch_bounds__(256) void leaf_bwd_pre(int B, int L, int C, int Dp, const float* __restrict__ VH, const float* __restrict__ H,
@@ -624,42 +441,6 @@ struct LevelRowsA {
     __device__ void side(const Ctx&, int, float4) const {}
     __device__ float val(const Ctx& c, int col) const { return c.r[col]; }
 };
-// compose layer 1, factored: x = relu(PL(a) + PR(b))           (diora.py:65-68 first Linear + ReLU)
-struct ComposeXA {
-    const int32_t *arow, *brow; int rowbase;
-    const float* A; int ldA; const float* Bm; int ldB;
-    float* X; int Dp;                       // side output: x rows (global pair row order, row stride Dp)
-    struct Ctx { const float *pa, *pb; float* xo; };
-    __device__ Ctx row(int r) const {
-        const size_t gr = (size_t)rowbase + r;
-        return Ctx{A + (size_t)arow[gr] * ldA, Bm + (size_t)brow[gr] * ldB, X + gr * Dp};
-    }
-    using Raw = Raw2;
-    __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.pa + k), ld4(c.pb + k)}; }
-    __device__ float4 finish(const Ctx&, const Raw& r) const {
-        return make_float4(fmaxf(r.u.x + r.v.x, 0.f), fmaxf(r.u.y + r.v.y, 0.f), fmaxf(r.u.z + r.v.z, 0.f), fmaxf(r.u.w + r.v.w, 0.f));
-    }
-    static constexpr bool kSide = true;
-    __device__ void side(const Ctx& c, int k, float4 v) const { st4(c.xo + k, v); }
-};
-// dz = p_n * dG(target) masked by the second ReLU (y > 0)
-struct ComposeDzA {
-    const int32_t* trow; int rowbase;
-    const float *dG, *Y, *Pp; int Dp;
-    float* DZ;                              // side output: dz rows (global pair row order, row stride Dp)
-    struct Ctx { const float *g, *y; float pn; float* zo; };
-    __device__ Ctx row(int r) const {
-        const size_t gr = (size_t)rowbase + r;
-        return Ctx{dG + (size_t)trow[gr] * Dp, Y + gr * Dp, Pp[gr], DZ + gr * Dp};
-    }
-    using Raw = Raw2;   // u = dG chunk, v = Y chunk
-    __device__ Raw fetch(const Ctx& c, int k) const { return Raw{ld4(c.g + k), ld4(c.y + k)}; }
-    __device__ float4 finish(const Ctx& c, const Raw& r) const {
-        return make_float4(r.v.x > 0.f ? c.pn * r.u.x : 0.f, r.v.y > 0.f ? c.pn * r.u.y : 0.f, r.v.z > 0.f ? c.pn * r.u.z : 0.f, r.v.w > 0.f ? c.pn * r.u.w : 0.f);
-    }
-    static constexpr bool kSide = true;
-    __device__ void side(const Ctx& c, int k, float4 v) const { st4(c.zo + k, v); }
-};
 
 // epilogues
 struct StoreRowsE {            // out[r*ld + col] = act(v + bias[col]); ACT 0 none, 1 tanh, 2 relu; cols >= ncols skipped
@@ -686,18 +467,6 @@ struct StoreLevelE {           // level row r -> chart row; out[crow*ld + col] =
         if (bias) v = f4add(v, ld4(bias + col));
         if (accumulate) v = f4add(v, ld4(rc.o + col));
         st4(rc.o + col, v);
-    }
-};
-struct ComposeBwdE {           // DA[row][col] = (x > 0) ? v : 0, x = relu(PL(a) + PR(b)) as stored by the forward
-    const float* X; float* DA; int rowbase, Dp;
-    struct RCtx { const float* x; float* o; };
-    __device__ RCtx row(int r) const {
-        const size_t gr = (size_t)rowbase + r;
-        return RCtx{X + gr * Dp, DA + gr * Dp};
-    }
-    __device__ void store4(const RCtx& rc, int col, float4 v) const {
-        const float4 x = ld4(rc.x + col);
-        st4(rc.o + col, make_float4(x.x > 0.f ? v.x : 0.f, x.y > 0.f ? v.y : 0.f, x.z > 0.f ? v.z : 0.f, x.w > 0.f ? v.w : 0.f));
     }
 };
 
