@@ -66,9 +66,14 @@ typedef struct cliora_params {
  * regions R; R = 0 selects text-only DIORA) and owns the small device index
  * tables for that chart shape: per-level (left,right) / (sibling,parent) cell
  * tables (cliora/net/inside_index.py:182-197, outside_index.py:93-127) and the
- * per-cell use lists the backward gathers over.  Creating a plan allocates
- * device memory; do it outside the step loop (the reference caches the same
- * tables in Index, cliora/net/utils.py:67-134). */
+ * per-cell use lists the backward gathers over.  Creating a plan builds the
+ * tables on the host (no GPU needed); they are uploaded by the FIRST forward
+ * call that uses the plan, on the device that is current then (one hipMalloc
+ * + copy + stream synchronise; cliora_plan_device_bytes tells how much), and
+ * every later call must run on that device.  Create and warm plans outside the
+ * step loop, or cache them (the reference caches the same tables in Index,
+ * cliora/net/utils.py:67-134; cliora_amd/_lib.py keeps an LRU of plans under
+ * a byte budget). */
 int cliora_plan_create(int B, int L, int D, int share, int normalize, int R, cliora_plan** out);
 /* arch: 0 = DioraMLP (as above), 1 = DioraTreeLSTM (needs share = 1, R = 0) */
 int cliora_plan_create_ex(int B, int L, int D, int share, int normalize, int R, int arch, cliora_plan** out);
