@@ -102,7 +102,52 @@ struct DeviceLanes {
     hipEvent_t fork[3], join[3], level[CLIORA_MAX_L + 1];
     std::mutex mu;
 };
-static int device_lanes(int dev, DeviceLanes** out) {
+// Holds one workgroup for `ticks` of the 100 MHz wall clock: the probe of pick_concurrent_stream.
+static __global__ void lane_probe(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+// HIP deals streams round-robin onto a few hardware queues; two streams on one queue run one after the other.  Create streams until
+// one runs a probe kernel CONCURRENTLY with every stream of `busy` (the caller's stream, lanes picked before), measured once:
+// 40 us probes on all of them take ~40 us together when they overlap and n x 40 us when any two share a queue.
+static int pick_concurrent_stream(hipStream_t* busy, int nbusy, hipStream_t* out) {
+    hipEvent_t e0 = nullptr, e1 = nullptr, ej = nullptr;
+    HIPOK(hipEventCreate(&e0)); HIPOK(hipEventCreate(&e1)); HIPOK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    int clk_khz = 100000;
+    (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, 0);
+    const long long ticks = 40LL * clk_khz / 1000;
+    std::vector<hipStream_t> rejected;
+    hipStream_t pick = nullptr;
+    for (int attempt = 0; attempt < 8 && !pick; ++attempt) {
+        hipStream_t c = nullptr;
+        HIPOK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {      // first rep warms the kernel up
+            HIPOK(hipEventRecord(e0, busy[0]));
+            for (int k = 1; k < nbusy; ++k) HIPOK(hipStreamWaitEvent(busy[k], e0, 0));
+            HIPOK(hipStreamWaitEvent(c, e0, 0));
+            for (int k = 0; k < nbusy; ++k) hipLaunchKernelGGL(lane_probe, dim3(1), dim3(64), 0, busy[k], ticks);
+            hipLaunchKernelGGL(lane_probe, dim3(1), dim3(64), 0, c, ticks);
+            for (int k = 1; k < nbusy; ++k) { HIPOK(hipEventRecord(ej, busy[k])); HIPOK(hipStreamWaitEvent(busy[0], ej, 0)); }
+            HIPOK(hipEventRecord(ej, c)); HIPOK(hipStreamWaitEvent(busy[0], ej, 0));
+            HIPOK(hipEventRecord(e1, busy[0]));
+            HIPOK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPOK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0) best = std::min(best, ms);
+        }
+        if (best < 0.070f) pick = c;             // 40 us when everything overlaps, >= 80 when two probes shared a queue
+        else rejected.push_back(c);
+    }
+    if (!pick && !rejected.empty()) { pick = rejected.back(); rejected.pop_back(); }     // no concurrent queue found: still correct, only slower
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ej);
+    if (!pick) return fail(CLIORA_EHIP, "could not create a side stream");
+    *out = pick;
+    return CLIORA_OK;
+}
+
+static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
     static std::mutex g_mu;
     static DeviceLanes* g_lanes[64] = {};
     if (dev < 0 || dev >= 64) return fail(CLIORA_EINVAL, "device index out of range");
@@ -110,8 +155,10 @@ static int device_lanes(int dev, DeviceLanes** out) {
     if (!g_lanes[dev]) {
         DeviceLanes* ln = new (std::nothrow) DeviceLanes();
         if (!ln) return fail(CLIORA_ENOMEM, "host allocation failed");
-        HIPOK(hipStreamCreateWithFlags(&ln->side, hipStreamNonBlocking));
-        HIPOK(hipStreamCreateWithFlags(&ln->side2, hipStreamNonBlocking));
+        hipStream_t busy[3] = {st, nullptr, nullptr};
+        OKR(pick_concurrent_stream(busy, 1, &ln->side));
+        busy[1] = ln->side;
+        OKR(pick_concurrent_stream(busy, 2, &ln->side2));
         for (int k = 0; k < 3; ++k) {
             HIPOK(hipEventCreateWithFlags(&ln->fork[k], hipEventDisableTiming));
             HIPOK(hipEventCreateWithFlags(&ln->join[k], hipEventDisableTiming));
@@ -138,7 +185,7 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     HIPOK(hipStreamSynchronize(st));   // `flat` dies at scope exit
     plan->p.d_tables_count = flat.size();
     DeviceLanes* ln = nullptr;
-    OKR(device_lanes(dev, &ln));
+    OKR(device_lanes(dev, st, &ln));
     plan->side = ln->side; plan->side2 = ln->side2;
     for (int k = 0; k < 3; ++k) { plan->ev_fork[k] = ln->fork[k]; plan->ev_join[k] = ln->join[k]; }
     plan->ev_level = ln->level;
