@@ -79,6 +79,10 @@ def lib():
     L.cliora_vl_scores_forward.restype = i32
     L.cliora_vl_scores_backward.argtypes = [vp] + [vp] * 5 + [i32] + [vp] * 6 + [vp, sz, vp]
     L.cliora_vl_scores_backward.restype = i32
+    L.cliora_vl_scores_max_forward.argtypes = [vp] + [vp] * 3 + [vp, vp, vp, sz, vp]
+    L.cliora_vl_scores_max_forward.restype = i32
+    L.cliora_vl_scores_max_backward.argtypes = [vp] + [vp] * 3 + [vp, vp, vp, vp, vp, sz, vp]
+    L.cliora_vl_scores_max_backward.restype = i32
     L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
     L.cliora_cky_decode.restype = i32
     L.cliora_prof_enable.argtypes = [i32, i32]

@@ -82,19 +82,21 @@ class VLScoreFunction(torch.autograd.Function):
 
     @staticmethod
     @_lib.on_device(lambda ctx, plan, training, inside_h, *a: inside_h)
-    def forward(ctx, plan, training, inside_h, outside_h, obj_span, x_word, obj_word):
+    def forward(ctx, plan, training, inside_h, outside_h, obj_span, x_word, obj_word, want_all):
+        """x_word / obj_word None: all_atten only; want_all False (training mode only): vg_atten only."""
         B, L, Cc, R = plan.B, plan.L, plan.C, plan.R
-        tens = [t.contiguous().float() for t in (inside_h, outside_h, obj_span, x_word, obj_word)]
+        tens = [t.contiguous().float() if t is not None else None for t in (inside_h, outside_h, obj_span, x_word, obj_word)]
         dev = tens[0].device
-        all_att = torch.empty((B, B, Cc, R), device=dev, dtype=torch.float32)
-        vg = torch.empty((B, B, L, R), device=dev, dtype=torch.float32)
+        all_att = torch.empty((B, B, Cc, R), device=dev, dtype=torch.float32) if want_all else None
+        vg = torch.empty((B, B, L, R), device=dev, dtype=torch.float32) if x_word is not None else None
         nbytes = _lib.lib().cliora_plan_vl_workspace_bytes(plan.handle)
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         rc = _lib.lib().cliora_vl_scores_forward(plan.handle, *[_ptr(t) for t in tens], int(training), _ptr(all_att), _ptr(vg),
                                                 _ptr(ws), nbytes, _stream())
         _lib.check(rc, 'cliora_vl_scores_forward')
         ctx.plan, ctx.training, ctx.nbytes = plan, int(training), nbytes
-        ctx.save_for_backward(*tens)
+        ctx.have_words = x_word is not None
+        ctx.save_for_backward(*[t for t in tens if t is not None])
         ctx.set_materialize_grads(False)
         return all_att, vg
 
@@ -102,20 +104,128 @@ class VLScoreFunction(torch.autograd.Function):
     @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
     def backward(ctx, d_all, d_vg):
         plan = ctx.plan
-        inside_h, outside_h, obj_span, x_word, obj_word = ctx.saved_tensors
+        if ctx.have_words:
+            inside_h, outside_h, obj_span, x_word, obj_word = ctx.saved_tensors
+        else:
+            (inside_h, outside_h, obj_span), x_word, obj_word = ctx.saved_tensors, None, None
         dev = inside_h.device
         cont = lambda g: g.contiguous().float() if g is not None else None
         d_all, d_vg = cont(d_all), cont(d_vg)
         d_sum = torch.empty_like(inside_h)
         d_obj_span = torch.empty_like(obj_span)
-        d_x_word = torch.empty_like(x_word)
-        d_obj_word = torch.empty_like(obj_word)
+        d_x_word = torch.empty_like(x_word) if x_word is not None else None
+        d_obj_word = torch.empty_like(obj_word) if obj_word is not None else None
         ws = torch.empty(ctx.nbytes, device=dev, dtype=torch.uint8)
         rc = _lib.lib().cliora_vl_scores_backward(plan.handle, _ptr(inside_h), _ptr(outside_h), _ptr(obj_span), _ptr(x_word),
                                                  _ptr(obj_word), ctx.training, _ptr(d_all), _ptr(d_vg), _ptr(d_sum),
                                                  _ptr(d_obj_span), _ptr(d_x_word), _ptr(d_obj_word), _ptr(ws), ctx.nbytes, _stream())
         _lib.check(rc, 'cliora_vl_scores_backward')
-        return None, None, d_sum, d_sum, d_obj_span, d_x_word, d_obj_word
+        return None, None, d_sum, d_sum, d_obj_span, d_x_word, d_obj_word, None
+
+
+class VLMaxFunction(torch.autograd.Function):
+    """cliora_vl_scores_max_forward / _backward: max over the R regions of einsum('abx,cdx->acbd', inside_h + outside_h, obj)
+    (cliora.py:457 followed by trainer.py:101) without the (B, B, C, R) tensor."""
+
+    @staticmethod
+    @_lib.on_device(lambda ctx, plan, inside_h, *a: inside_h)
+    def forward(ctx, plan, inside_h, outside_h, obj_span):
+        B, Cc = plan.B, plan.C
+        tens = [t.contiguous().float() for t in (inside_h, outside_h, obj_span)]
+        dev = tens[0].device
+        vmax = torch.empty((B, B, Cc), device=dev, dtype=torch.float32)
+        arg = torch.empty((B, B, Cc), device=dev, dtype=torch.int32)
+        nbytes = _lib.lib().cliora_plan_vl_workspace_bytes(plan.handle)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_max_forward(plan.handle, *[_ptr(t) for t in tens], _ptr(vmax), _ptr(arg), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_max_forward')
+        ctx.plan, ctx.nbytes = plan, nbytes
+        ctx.save_for_backward(*tens, arg)
+        ctx.mark_non_differentiable(arg)
+        return vmax, arg
+
+    @staticmethod
+    @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
+    def backward(ctx, d_max, _d_arg):
+        plan = ctx.plan
+        inside_h, outside_h, obj_span, arg = ctx.saved_tensors
+        if d_max is None:
+            return None, None, None, None
+        d_max = d_max.contiguous().float()
+        d_sum = torch.empty_like(inside_h)
+        d_obj = torch.empty_like(obj_span)
+        ws = torch.empty(ctx.nbytes, device=inside_h.device, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_max_backward(plan.handle, _ptr(inside_h), _ptr(outside_h), _ptr(obj_span), _ptr(d_max), _ptr(arg),
+                                                     _ptr(d_sum), _ptr(d_obj), _ptr(ws), ctx.nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_max_backward')
+        return None, d_sum, d_sum, d_obj
+
+
+class RegionMax(tuple):
+    """What `all_atten_score.max(-1)` returns: (values, indices) with the field names of torch.return_types.max."""
+    values = property(lambda self: self[0])
+    indices = property(lambda self: self[1])
+
+
+class LazyRegionScores:
+    """`all_atten_score` of cliora.py:457 -- einsum('abx,cdx->acbd', inside_h + outside_h, obj_span), (B, B, C, R) -- in training
+    mode, before anyone has asked for it.  Its one consumer there, ContrastiveLoss (trainer.py:101), takes `.max(-1).values`:
+    that runs the fused scorer (the GEMM's epilogue keeps the maximum and its region per (sentence, image, span); the 124 MB
+    tensor at B 64 / L 20 / R 36 is never written or differentiated through).  Anything else -- indexing, torch functions,
+    tensor attributes -- materialises the dense tensor once through the ordinary scorer and behaves like it."""
+
+    def __init__(self, plan, inside_h, outside_h, obj_span):
+        self._plan, self._args = plan, (inside_h, outside_h, obj_span)
+        self._dense, self._max = None, None
+        self.shape = torch.Size((plan.B, plan.B, plan.C, plan.R))
+        self.device, self.dtype = inside_h.device, torch.float32
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 4
+
+    def max(self, dim=None, keepdim=False):
+        if dim in (-1, 3) and not keepdim and self._dense is None:
+            if self._max is None:
+                vmax, arg = VLMaxFunction.apply(self._plan, *self._args)
+                self._max = RegionMax((vmax, arg.long()))
+            return self._max
+        return self.materialize().max() if dim is None else self.materialize().max(dim, keepdim)
+
+    def materialize(self):
+        if self._dense is None:
+            ih, oh, obj = self._args
+            self._dense = VLScoreFunction.apply(self._plan, True, ih, oh, obj, None, None, True)[0]
+        return self._dense
+
+    def __getattr__(self, name):                    # only reached for names not defined above
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a.materialize() if isinstance(a, LazyRegionScores) else a
+        return func(*[un(a) for a in args], **{k: un(v) for k, v in (kwargs or {}).items()})
+
+
+def _delegate(name):
+    def op(self, *a, **k):
+        return getattr(self.materialize(), name)(*a, **k)
+    op.__name__ = name
+    return op
+
+
+for _n in ('__add__', '__radd__', '__sub__', '__rsub__', '__mul__', '__rmul__', '__truediv__', '__rtruediv__', '__neg__', '__pow__',
+           '__matmul__', '__lt__', '__le__', '__gt__', '__ge__', '__eq__', '__ne__', '__iter__', '__repr__', '__array__'):
+    setattr(LazyRegionScores, _n, _delegate(_n))
+LazyRegionScores.__hash__ = object.__hash__
 
 
 class AttentionHead(nn.Module):
@@ -147,6 +257,7 @@ class DioraMLP(DioraBase):
         self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
         self.root_vector_out_c = None
         self.dropout_mask = None      # tests inject a (B, C, R) pre-scaled mask here; None = draw one per forward
+        self.lazy_region_scores = True   # training mode: all_atten_score is a LazyRegionScores (False: always the dense tensor)
 
     def get_chart_wrapper(self):
         return self
@@ -181,7 +292,12 @@ class DioraMLP(DioraBase):
         self.init_with_batch(ih[:, :L], ic[:, :L])
         self._serve_hooks(L)
         # cliora.py:453-468
-        all_att, vg = VLScoreFunction.apply(plan, self.training, ih, oh, obj_embed_span, x_word, obj_embed_word)
+        if self.training and self.lazy_region_scores:
+            # training: vg_atten does not read all_atten (cliora.py:459-461) and the contrastive loss only wants its region max
+            _, vg = VLScoreFunction.apply(plan, True, ih, oh, obj_embed_span, x_word, obj_embed_word, False)
+            all_att = LazyRegionScores(plan, ih, oh, obj_embed_span)
+        else:
+            all_att, vg = VLScoreFunction.apply(plan, self.training, ih, oh, obj_embed_span, x_word, obj_embed_word, True)
         self.all_atten_score = all_att
         self.vg_atten_score_word = vg
         self.vg_atten_score = vg

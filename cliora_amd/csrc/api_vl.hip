@@ -55,7 +55,8 @@ static VlViews vl_views(const Plan& p, void* ws) {
 extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
                                         const float* x_word, const float* obj_word, int training, float* all_atten,
                                         float* vg_atten, void* vl_ws, size_t vl_ws_bytes, void* stream) {
-    if (!plan || !inside_h || !outside_h || !obj_span || !all_atten || !vl_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan || !inside_h || !outside_h || !obj_span || !vl_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!all_atten && !(training && vg_atten)) return fail(CLIORA_EINVAL, "all_atten may only be NULL in training mode with vg_atten given");
     const Plan& p = plan->p;
     if (p.R <= 0) return fail(CLIORA_EINVAL, "the scorers need a CLIORA plan (R > 0)");
     if (vl_ws_bytes < p.vl.total * sizeof(float)) return fail(CLIORA_ENOMEM, "VL workspace too small");
@@ -66,14 +67,14 @@ extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h
     const VlViews v = vl_views(p, vl_ws);
     {
         CopyTable t; t.n = 0;
-        add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
+        if (all_atten) add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
         if (vg_atten) add_copy(t, v.wall, Dp, NRp, Dp, obj_word, D, B * R, D, 0, 0, 0);
-        if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
+        if (padded && all_atten) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
         if (vg_atten && (padded || !training)) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }
     const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
-    OKR(launch_rows(st, v.oall, Dp, 1, NRp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
+    if (all_atten) OKR(launch_rows(st, v.oall, Dp, 1, NRp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
     if (vg_atten) {
         if (training) {
             const SumRowsA xw = SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
@@ -84,6 +85,68 @@ extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h
             LAUNCHOK("unit_norm_rows(x_word)");
             OKR(launch_rows(st, v.wall, Dp, 1, NRp, B * L, SumRowsA{v.xwn, nullptr, Dp}, ScoreStoreE{vg_atten, B, L, R, all_atten, C}));
         }
+    }
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_vl_scores_max_forward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
+                                            float* all_max, int32_t* all_arg, void* vl_ws, size_t vl_ws_bytes, void* stream) {
+    if (!plan || !inside_h || !outside_h || !obj_span || !all_max || !vl_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.R <= 0) return fail(CLIORA_EINVAL, "the scorers need a CLIORA plan (R > 0)");
+    if (vl_ws_bytes < p.vl.total * sizeof(float)) return fail(CLIORA_ENOMEM, "VL workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p.B, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
+    const bool padded = D != Dp;
+    const VlViews v = vl_views(p, vl_ws);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>((float*)vl_ws + p.vl.keys);
+    const size_t nkeys = (size_t)B * B * C;
+    HIPOK(hipMemsetAsync(keys, 0, nkeys * sizeof(unsigned long long), st));
+    {
+        CopyTable t; t.n = 0;
+        add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
+        if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
+    OKR(launch_rows(st, v.oall, Dp, 1, NRp, B * C, sumA, ScoreMaxE{keys, B, C, R}));
+    hipLaunchKernelGGL(region_keys_decode, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, keys, nkeys, all_max, all_arg);
+    LAUNCHOK("region_keys_decode");
+    return CLIORA_OK;
+}
+
+extern "C" int cliora_vl_scores_max_backward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
+                                             const float* d_all_max, const int32_t* all_arg, float* d_sum_h, float* d_obj_span,
+                                             void* vl_ws, size_t vl_ws_bytes, void* stream) {
+    if (!plan || !inside_h || !outside_h || !obj_span || !d_all_max || !all_arg || !vl_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    const Plan& p = plan->p;
+    if (p.R <= 0) return fail(CLIORA_EINVAL, "the scorers need a CLIORA plan (R > 0)");
+    if (vl_ws_bytes < p.vl.total * sizeof(float)) return fail(CLIORA_ENOMEM, "VL workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p.B, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
+    const VlViews v = vl_views(p, vl_ws);
+    if (Dp > 512) return fail(CLIORA_EINVAL, "region-max backward: D > 512 is not supported");
+    {   // padded, 16-byte aligned operand rows: the region matrix and S = inside_h + outside_h
+        CopyTable t; t.n = 0;
+        if (d_sum_h) add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
+        if (d_obj_span) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
+        OKR(run_copies(st, t));
+    }
+    if (d_sum_h) {
+        hipLaunchKernelGGL(region_max_bwd_rows, dim3(B * C), dim3(256), 0, st, B, C, R, D, Dp, d_all_max, all_arg, v.oall, d_sum_h);
+        LAUNCHOK("region_max_bwd_rows");
+    }
+    if (d_obj_span) {
+        // partial sums over chunks of sentences (at most 8: the slab holds 8 region matrices), then the fixed-order sum and the unpad copy
+        const int a_per_chunk = std::max(4, (B + 7) / 8), nchunk = (B + a_per_chunk - 1) / a_per_chunk;
+        const size_t n = (size_t)B * R * Dp;
+        hipLaunchKernelGGL(region_max_bwd_obj, dim3(B * R, nchunk), dim3(256), 0, st, B, C, R, Dp, a_per_chunk, d_all_max, all_arg, v.sump, v.slab);
+        LAUNCHOK("region_max_bwd_obj");
+        hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v.slab, nchunk, n, v.gobj, 0);
+        LAUNCHOK("slab_reduce");
+        CopyTable t; t.n = 0;
+        add_copy(t, d_obj_span, D, B * R, D, v.gobj, Dp, B * R, D, 0, 0, 0);
+        OKR(run_copies(st, t));
     }
     return CLIORA_OK;
 }

@@ -349,6 +349,140 @@ struct ScoreStoreE {
         put(rc, col, v.x); put(rc, col + 1, v.y); put(rc, col + 2, v.z); put(rc, col + 3, v.w);
     }
 };
+// Region-max scorer (ContrastiveLoss, trainer.py:101): key = (order-preserving bits of the score) << 32 | ~region, merged by a
+// 64-bit atomic max -- exact and order-independent: the largest score wins, the smallest region index among equal scores
+// (torch.max).  keys[(a*B + c)*Cq + b], zeroed before the launch.
+__device__ __forceinline__ unsigned long long region_key(float v, int d) {
+    const uint32_t u = __float_as_uint(v);
+    const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)o << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)d);
+}
+struct ScoreMaxE {
+    unsigned long long* keys; int B, Cq, R;
+    struct RCtx { int a, b; };
+    __device__ RCtx row(int r) const { const int a = r / Cq; return RCtx{a, r - a * Cq}; }
+    __device__ void put(const RCtx& rc, int col, float v) const {
+        if (col >= B * R) return;
+        const int c = col / R, d = col - c * R;
+        atomicMax(keys + ((size_t)rc.a * B + c) * Cq + rc.b, region_key(v, d));
+    }
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
+        if ((R & 3) == 0 && col + 3 < B * R) {       // the four columns are four regions of one image: one atomic
+            const int c = col / R, d = col - c * R;
+            unsigned long long k = region_key(v.x, d);
+            const unsigned long long k1 = region_key(v.y, d + 1), k2 = region_key(v.z, d + 2), k3 = region_key(v.w, d + 3);
+            k = k1 > k ? k1 : k; k = k2 > k ? k2 : k; k = k3 > k ? k3 : k;
+            atomicMax(keys + ((size_t)rc.a * B + c) * Cq + rc.b, k);
+            return;
+        }
+        put(rc, col, v.x); put(rc, col + 1, v.y); put(rc, col + 2, v.z); put(rc, col + 3, v.w);
+    }
+};
+static __global__ void region_keys_decode(const unsigned long long* __restrict__ keys, size_t n, float* __restrict__ vmax, int32_t* __restrict__ arg) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const unsigned long long k = keys[e];
+    const uint32_t o = (uint32_t)(k >> 32);
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    vmax[e] = __uint_as_float(u);
+    if (arg) arg[e] = (int32_t)(0xFFFFFFFFu - (uint32_t)k);
+}
+// Backward of the region max, sparse: one region per (sentence a, image c, span b) carries the cotangent.
+//   d_sum_h[a][b][:] = sum_c g[a][c][b] * O[c][arg[a][c][b]][:]            one workgroup per (a, b), waves over c, fixed order
+// O = the padded region matrix (B*R rows of stride Dp, 16-byte aligned rows), out rows have stride D.
+static __global__ __launch_bounds__(256) void region_max_bwd_rows(int B, int Cq, int R, int D, int Dp, const float* __restrict__ G,
+                                                                  const int32_t* __restrict__ arg, const float* __restrict__ O,
+                                                                  float* __restrict__ out) {
+    __shared__ float4 sh[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x, a = r / Cq, b = r - a * Cq;
+    const int nv = Dp >> 2;
+    const bool act0 = lane < nv, act1 = lane + 64 < nv;
+    const int col0 = 4 * lane, col1 = 4 * (lane + 64);
+    float4 acc0 = f4zero(), acc1 = f4zero();
+    const size_t base = (size_t)a * B * Cq + b;
+    for (int c0 = wave; c0 < B; c0 += 16) {
+        float gv[4]; const float* row[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + 4 * j;
+            const bool ok = c < B;
+            const size_t o = base + (size_t)(ok ? c : 0) * Cq;
+            gv[j] = ok ? G[o] : 0.f;
+            row[j] = O + ((size_t)(ok ? c : 0) * R + arg[o]) * Dp;
+        }
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = act0 ? ld4(row[j] + col0) : f4zero(); v1[j] = act1 ? ld4(row[j] + col1) : f4zero(); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc0 = f4fma(gv[j], v0[j], acc0); acc1 = f4fma(gv[j], v1[j], acc1); }
+    }
+    if (wave > 0) { sh[wave - 1][0][lane] = acc0; sh[wave - 1][1][lane] = acc1; }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { acc0 = f4add(acc0, sh[w][0][lane]); acc1 = f4add(acc1, sh[w][1][lane]); }
+    float* o = out + (size_t)r * D;
+    const float a0[4] = {acc0.x, acc0.y, acc0.z, acc0.w}, a1[4] = {acc1.x, acc1.y, acc1.z, acc1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (col0 + j < D) o[col0 + j] = a0[j];
+        if (col1 + j < D) o[col1 + j] = a1[j];
+    }
+}
+//   d_obj[c][d][:] = sum over (a, b) with arg[a][c][b] == d of g[a][c][b] * S[a][b][:]     one workgroup per (c, d) and CHUNK of
+// sentences a (blockIdx.y): the arg max of an image is heavily skewed towards a few regions, so a region's matches are cut
+// into nchunk independent partial sums (part[chunk][c*R + d][:], rows of stride Dp, added in chunk order by slab_reduce).  The waves
+// scan the chunk's (sentence, span) entries in a fixed order and add the matching rows of S = inside_h + outside_h (stride Dp).
+static __global__ __launch_bounds__(256) void region_max_bwd_obj(int B, int Cq, int R, int Dp, int a_per_chunk, const float* __restrict__ G,
+                                                                 const int32_t* __restrict__ arg, const float* __restrict__ S,
+                                                                 float* __restrict__ part) {
+    __shared__ float4 sh[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x / R, d = blockIdx.x - c * R;
+    const int nv = Dp >> 2;
+    const bool act0 = lane < nv, act1 = lane + 64 < nv;
+    const int col0 = 4 * lane, col1 = 4 * (lane + 64);
+    float4 acc0 = f4zero(), acc1 = f4zero();
+    const int a_lo = blockIdx.y * a_per_chunk, a_hi = min(B, a_lo + a_per_chunk);
+    for (int a = a_lo + wave; a < a_hi; a += 4) {
+        const size_t base = ((size_t)a * B + c) * Cq;
+        for (int b0 = 0; b0 < Cq; b0 += 64) {
+            const int b = b0 + lane;
+            const bool hit = b < Cq && arg[base + b] == d;
+            const float gl = hit ? G[base + b] : 0.f;
+            unsigned long long m = __ballot(hit);
+            while (m) {                              // up to four matches in flight, in span order
+                int bb[4]; float gv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int l = m ? __ffsll((long long)m) - 1 : 0;
+                    gv[j] = m ? __shfl(gl, l) : 0.f;
+                    bb[j] = b0 + l;
+                    if (m) m &= m - 1;
+                }
+                float4 v0[4], v1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* row = S + ((size_t)a * Cq + bb[j]) * Dp;
+                    v0[j] = act0 ? ld4(row + col0) : f4zero();
+                    v1[j] = act1 ? ld4(row + col1) : f4zero();
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc0 = f4fma(gv[j], v0[j], acc0); acc1 = f4fma(gv[j], v1[j], acc1); }
+            }
+        }
+    }
+    if (wave > 0) { sh[wave - 1][0][lane] = acc0; sh[wave - 1][1][lane] = acc1; }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { acc0 = f4add(acc0, sh[w][0][lane]); acc1 = f4add(acc1, sh[w][1][lane]); }
+    float* o = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Dp;
+    if (act0) st4(o + col0, acc0);
+    if (act1) st4(o + col1, acc1);
+}
+
 // A(r, k) = dScore[a][c][b][d] with r = (a, b), k = (c, d); k >= B*R reads as zero
 struct ScoreGradA {
     const float* G; int B, Cq, R;

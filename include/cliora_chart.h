@@ -160,6 +160,7 @@ int cliora_lstm_backward(cliora_plan* plan, const cliora_params* params, const f
  * charts; d_obj_span, d_obj_word (B,R,D), d_x_word (B,L,D; training mode only).  NULL cotangents
  * are zero; NULL outputs are skipped. */
 size_t cliora_plan_vl_workspace_bytes(const cliora_plan* plan);
+/* all_atten may be NULL in training mode (only vg_atten is wanted: the contrastive loss takes cliora_vl_scores_max_forward). */
 int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h, const float* outside_h,
                              const float* obj_span, const float* x_word, const float* obj_word,
                              int training, float* all_atten, float* vg_atten,
@@ -169,6 +170,19 @@ int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_h, const fl
                               int training, const float* d_all_atten, const float* d_vg_atten,
                               float* d_sum_h, float* d_obj_span, float* d_x_word, float* d_obj_word,
                               void* vl_workspace, size_t vl_workspace_bytes, void* stream);
+
+/* The same span-region scores reduced over the R regions of each image, as ContrastiveLoss consumes them
+ * (cliora/net/trainer.py:101 `all_atten_score.max(-1).values`): the (B,B,C,R) tensor (124 MB at B 64, L 20, R 36) is never
+ * written -- the GEMM's epilogue keeps, per (sentence a, image c, span b), the largest score and the smallest region index
+ * that attains it (what torch.max returns):
+ *   all_max (B,B,C) float, all_arg (B,B,C) int32
+ * Backward: the cotangent of all_max flows to the arg-max region only (torch's max backward); d_sum_h (B,C,D) as above,
+ * d_obj_span (B,R,D).  NULL outputs are skipped.  Uses the same workspace as cliora_vl_scores_forward. */
+int cliora_vl_scores_max_forward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
+                                 float* all_max, int32_t* all_arg, void* vl_workspace, size_t vl_workspace_bytes, void* stream);
+int cliora_vl_scores_max_backward(cliora_plan* plan, const float* inside_h, const float* outside_h, const float* obj_span,
+                                  const float* d_all_max, const int32_t* all_arg, float* d_sum_h, float* d_obj_span,
+                                  void* vl_workspace, size_t vl_workspace_bytes, void* stream);
 
 /* Un-aggregated per-split tensors the reference hands to inside_hook (diora.py:295-334)
  * for `level`: scores = (B, L-level, level) laid out exactly like the reference's

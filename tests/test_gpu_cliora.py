@@ -103,6 +103,7 @@ def test_cliora_against_oracle(D, B, L, R, share, mfma_mode):
         sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].clone()
     m.load_state_dict(sd)
     m = m.cuda().train()
+    m.lazy_region_scores = False      # this test differentiates all_atten_score itself (a cotangent on the dense tensor)
     m.dropout_mask = mask.cuda()
     tg = {k: v.clone().cuda().requires_grad_(True) for k, v in dict(x_span=x_span, x_word=x_word, obj_span=obj_span, obj_word=obj_word).items()}
     m(tg['x_span'], tg['x_word'], tg['obj_span'], tg['obj_word'])
@@ -137,3 +138,45 @@ def test_cliora_against_oracle(D, B, L, R, share, mfma_mode):
         grad_check(named[k].grad, p.grad, mfma_mode, GRAD_TOL, k)
     for k in tg:
         grad_check(tg[k].grad, tc[k].grad, mfma_mode, GRAD_TOL, k)
+
+
+@pytest.mark.parametrize('B,L,D,R', [(5, 7, 48, 6), (8, 9, 400, 36), (3, 5, 33, 5), (64, 20, 400, 36)])
+def test_region_max_scorer_is_the_dense_scorer_then_max(B, L, D, R, mfma_mode):
+    """all_atten_score.max(-1) in training mode (ContrastiveLoss, trainer.py:101) runs cliora_vl_scores_max_forward / _backward:
+    values, region indices and every gradient must be exactly those of the dense (B, B, C, R) tensor followed by torch.max."""
+    from cliora_amd.cliora import DioraMLP, LazyRegionScores
+    torch.manual_seed(7)
+    m = DioraMLP(D, outside=True, normalize='unit', compress=False, share=True).cuda().train()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    C = L * (L + 1) // 2
+    mask = torch.ones(B, C, R, device='cuda')
+    w = torch.randn(B, B, C, device='cuda')
+    res = {}
+    for lazy in (True, False):
+        m.lazy_region_scores, m.dropout_mask = lazy, mask
+        g = torch.Generator().manual_seed(11)
+        t = [torch.randn(sh, generator=g).cuda().requires_grad_(True) for sh in ((B, L, D), (B, L, D), (B, R, D), (B, R, D))]
+        for p in m.parameters():
+            p.grad = None
+        m(*t)
+        a = m.all_atten_score
+        assert isinstance(a, LazyRegionScores) == lazy
+        assert tuple(a.shape) == (B, B, C, R)
+        r = a.max(-1)
+        ((r.values * w).sum() + m.vg_atten_score.sum() * 0.1).backward()
+        res[lazy] = (r.values.detach(), r.indices, [x.grad.clone() for x in t], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0])          # same accumulators, max taken in the epilogue: bit for bit
+    assert torch.equal(res[True][1], res[False][1])
+    # the backward sums the arg-max rows directly (sparse) instead of a dense GEMM over 35/36 zeros: same terms, another order
+    close = lambda x, y: float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max()))
+    for ga, gb in zip(res[True][2], res[False][2]):
+        assert close(ga, gb)
+    for n in res[True][3]:
+        assert close(res[True][3][n], res[False][3][n]), n
+    # the lazy object still serves everything else the dense tensor does
+    m.lazy_region_scores = True
+    m(*[x.detach() for x in t])
+    a = m.all_atten_score
+    dense = a[:, :, :L]
+    assert tuple(dense.shape) == (B, B, L, R) and torch.equal((a * 2.0).max(-1).values, res[False][0] * 2.0)
