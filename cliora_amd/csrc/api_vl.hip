@@ -65,25 +65,26 @@ extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h
     const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
     const bool padded = D != Dp;
     const VlViews v = vl_views(p, vl_ws);
+    const bool inplace = !padded && B * R == NRp;        // the region matrices are already (NRp x Dp) weights: no packed copies
     {
         CopyTable t; t.n = 0;
-        if (all_atten) add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
-        if (vg_atten) add_copy(t, v.wall, Dp, NRp, Dp, obj_word, D, B * R, D, 0, 0, 0);
+        if (all_atten && !inplace) add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
+        if (vg_atten && !inplace) add_copy(t, v.wall, Dp, NRp, Dp, obj_word, D, B * R, D, 0, 0, 0);
         if (padded && all_atten) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
         if (vg_atten && (padded || !training)) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }
     const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
-    if (all_atten) OKR(launch_rows(st, v.oall, Dp, 1, NRp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
+    if (all_atten) OKR(launch_rows(st, inplace ? obj_span : v.oall, Dp, 1, NRp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
     if (vg_atten) {
         if (training) {
             const SumRowsA xw = SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
-            OKR(launch_rows(st, v.wall, Dp, 1, NRp, B * L, xw, ScoreStoreE{vg_atten, B, L, R, nullptr, 0}));
+            OKR(launch_rows(st, inplace ? obj_word : v.wall, Dp, 1, NRp, B * L, xw, ScoreStoreE{vg_atten, B, L, R, nullptr, 0}));
         } else {   // eval: all_atten[:, :, :L] + unit(x_word) . obj_word   (cliora.py:462-464)
             hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B * L)), dim3(256), 0, st, v.xwp, Dp, B * L, B * L, 0, 0, Dp, p.normalize,
                                v.xwn, v.nrm, v.nrm + B * L);
             LAUNCHOK("unit_norm_rows(x_word)");
-            OKR(launch_rows(st, v.wall, Dp, 1, NRp, B * L, SumRowsA{v.xwn, nullptr, Dp}, ScoreStoreE{vg_atten, B, L, R, all_atten, C}));
+            OKR(launch_rows(st, inplace ? obj_word : v.wall, Dp, 1, NRp, B * L, SumRowsA{v.xwn, nullptr, Dp}, ScoreStoreE{vg_atten, B, L, R, all_atten, C}));
         }
     }
     return CLIORA_OK;
@@ -102,14 +103,15 @@ extern "C" int cliora_vl_scores_max_forward(cliora_plan* plan, const float* insi
     unsigned long long* keys = reinterpret_cast<unsigned long long*>((float*)vl_ws + p.vl.keys);
     const size_t nkeys = (size_t)B * B * C;
     HIPOK(hipMemsetAsync(keys, 0, nkeys * sizeof(unsigned long long), st));
-    {
+    const bool inplace = !padded && B * R == NRp;        // the region matrix is already a (NRp x Dp) weight: no packed copy
+    if (!inplace) {
         CopyTable t; t.n = 0;
         add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
         if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }
     const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
-    OKR(launch_rows(st, v.oall, Dp, 1, NRp, B * C, sumA, ScoreMaxE{keys, B, C, R}));
+    OKR(launch_rows(st, inplace ? obj_span : v.oall, Dp, 1, NRp, B * C, sumA, ScoreMaxE{keys, B, C, R}));
     hipLaunchKernelGGL(region_keys_decode, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, keys, nkeys, all_max, all_arg);
     LAUNCHOK("region_keys_decode");
     return CLIORA_OK;
@@ -126,20 +128,27 @@ extern "C" int cliora_vl_scores_max_backward(cliora_plan* plan, const float* ins
     const int B = p.B, D = p.D, Dp = p.Dp, C = p.C, R = p.R, NRp = p.vl.NRp;
     const VlViews v = vl_views(p, vl_ws);
     if (Dp > 512) return fail(CLIORA_EINVAL, "region-max backward: D > 512 is not supported");
-    {   // padded, 16-byte aligned operand rows: the region matrix and S = inside_h + outside_h
+    const bool padded = D != Dp;
+    if (padded) {   // 16-byte aligned operand rows: the region matrix and S = inside_h + outside_h (D % 16 == 0: read in place)
         CopyTable t; t.n = 0;
         if (d_sum_h) add_copy(t, v.oall, Dp, NRp, Dp, obj_span, D, B * R, D, 0, 0, 0);
         if (d_obj_span) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }
     if (d_sum_h) {
-        hipLaunchKernelGGL(region_max_bwd_rows, dim3(B * C), dim3(256), 0, st, B, C, R, D, Dp, d_all_max, all_arg, v.oall, d_sum_h);
+        hipLaunchKernelGGL(region_max_bwd_rows, dim3(B * C), dim3(256), 0, st, B, C, R, D, Dp, d_all_max, all_arg, padded ? v.oall : obj_span, Dp, d_sum_h);
         LAUNCHOK("region_max_bwd_rows");
     }
     if (d_obj_span) {
         // partial sums over chunks of sentences (at most 8: the slab holds 8 region matrices), then the fixed-order sum and the unpad copy
         const int a_per_chunk = std::max(4, (B + 7) / 8), nchunk = (B + a_per_chunk - 1) / a_per_chunk;
         const size_t n = (size_t)B * R * Dp;
+        if (!padded) {
+            const size_t n4 = (size_t)B * C * Dp / 4;
+            hipLaunchKernelGGL(add_rows4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(inside_h),
+                               reinterpret_cast<const float4*>(outside_h), n4, reinterpret_cast<float4*>(v.sump));
+            LAUNCHOK("add_rows4");
+        }
         hipLaunchKernelGGL(region_max_bwd_obj, dim3(B * R, nchunk), dim3(256), 0, st, B, C, R, Dp, a_per_chunk, d_all_max, all_arg, v.sump, v.slab);
         LAUNCHOK("region_max_bwd_obj");
         hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v.slab, nchunk, n, v.gobj, 0);
@@ -166,9 +175,10 @@ extern "C" int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_
     const bool eval_vg = !training && d_vg;      // eval: vg = all_atten[:, :, :L] + unit(x_word) . obj_word  (cliora.py:462-464)
     {   // transposed region matrices: W[j][k] = O[k][j], k padded with zero rows
         CopyTable t; t.n = 0;
-        add_copy(t, v.oallT, NRp, Dp, NRp, obj_span, D, B * R, D, 0, 0, 1);
+        const bool all_live = d_all || eval_vg;              // no cotangent reaches all_atten (training with the region-max scorer): skip its operands
+        if (all_live && d_sum_h) add_copy(t, v.oallT, NRp, Dp, NRp, obj_span, D, B * R, D, 0, 0, 1);
         if (d_vg) add_copy(t, v.wallT, NRp, Dp, NRp, obj_word, D, B * R, D, 0, 0, 1);
-        if (padded) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
+        if (padded && all_live) add_copy(t, v.sump, Dp, B * C, Dp, inside_h, D, B * C, D, 0, 0, 0, outside_h, D, B * C, D, 0, 0, 0);
         if (d_vg && (padded || eval_vg)) add_copy(t, v.xwp, Dp, B * L, Dp, x_word, D, B * L, D, 0, 0, 0);
         OKR(run_copies(st, t));
     }

@@ -391,7 +391,7 @@ static __global__ void region_keys_decode(const unsigned long long* __restrict__
 //   d_sum_h[a][b][:] = sum_c g[a][c][b] * O[c][arg[a][c][b]][:]            one workgroup per (a, b), waves over c, fixed order
 // O = the padded region matrix (B*R rows of stride Dp, 16-byte aligned rows), out rows have stride D.
 static __global__ __launch_bounds__(256) void region_max_bwd_rows(int B, int Cq, int R, int D, int Dp, const float* __restrict__ G,
-                                                                  const int32_t* __restrict__ arg, const float* __restrict__ O,
+                                                                  const int32_t* __restrict__ arg, const float* __restrict__ O, int ldo,
                                                                   float* __restrict__ out) {
     __shared__ float4 sh[3][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -409,7 +409,7 @@ static __global__ __launch_bounds__(256) void region_max_bwd_rows(int B, int Cq,
             const bool ok = c < B;
             const size_t o = base + (size_t)(ok ? c : 0) * Cq;
             gv[j] = ok ? G[o] : 0.f;
-            row[j] = O + ((size_t)(ok ? c : 0) * R + arg[o]) * Dp;
+            row[j] = O + ((size_t)(ok ? c : 0) * R + arg[o]) * ldo;
         }
         float4 v0[4], v1[4];
 #pragma unroll
@@ -429,6 +429,11 @@ static __global__ __launch_bounds__(256) void region_max_bwd_rows(int B, int Cq,
         if (col0 + j < D) o[col0 + j] = a0[j];
         if (col1 + j < D) o[col1 + j] = a1[j];
     }
+}
+// S = P + Q for two aligned (n4 float4) arrays: the summed chart rows of the region-max backward when no padding is needed
+static __global__ void add_rows4(const float4* __restrict__ P, const float4* __restrict__ Q, size_t n4, float4* __restrict__ S) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n4) { const float4 a = P[e], b = Q[e]; S[e] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 }
 //   d_obj[c][d][:] = sum over (a, b) with arg[a][c][b] == d of g[a][c][b] * S[a][b][:]     one workgroup per (c, d) and CHUNK of
 // sentences a (blockIdx.y): the arg max of an image is heavily skewed towards a few regions, so a region's matches are cut

@@ -1,5 +1,7 @@
+#!/bin/bash
+# kernel stats of the whole training step (tools/step_bench.py [diora|cliora|both]); summary of the top kernels
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o stepc -- python3 $GRAFT_REPO_ROOT/tools/step_bench.py > $GRAFT_REPO_ROOT/gpurun_out/prof_stepc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o stepc -- python3 $GRAFT_REPO_ROOT/tools/step_bench.py ${1:-both} > $GRAFT_REPO_ROOT/gpurun_out/prof_stepc.log 2>&1
 python3 - $GRAFT_REPO_ROOT/gpurun_out/prof/stepc_kernel_stats.csv <<'PY'
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -38,5 +38,8 @@ def run(name, vl, B=64, L=20, D=400, V=10000, E=1024, K=100, steps=20, warmup=5)
 
 
 if __name__ == '__main__':
-    run('DIORA whole step (c2 shape)', False)
-    run('CLIORA whole step (c3 shape)', True)
+    which = sys.argv[1] if len(sys.argv) > 1 else 'both'
+    if which in ('both', 'diora'):
+        run('DIORA whole step (c2 shape)', False)
+    if which in ('both', 'cliora'):
+        run('CLIORA whole step (c3 shape)', True)
