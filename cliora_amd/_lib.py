@@ -83,6 +83,10 @@ def lib():
     L.cliora_vl_scores_max_forward.restype = i32
     L.cliora_vl_scores_max_backward.argtypes = [vp] + [vp] * 3 + [vp, vp, vp, vp, vp, sz, vp]
     L.cliora_vl_scores_max_backward.restype = i32
+    L.cliora_contrastive_workspace_bytes.argtypes = [i32, i32]
+    L.cliora_contrastive_workspace_bytes.restype = sz
+    L.cliora_contrastive_loss.argtypes = [i32, i32, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, sz, vp]
+    L.cliora_contrastive_loss.restype = i32
     L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
     L.cliora_cky_decode.restype = i32
     L.cliora_prof_enable.argtypes = [i32, i32]

@@ -224,3 +224,32 @@ extern "C" int cliora_vl_scores_backward(cliora_plan* plan, const float* inside_
     }
     return CLIORA_OK;
 }
+
+// ------------------------------------------------------------------ ContrastiveLoss on the region maxima
+extern "C" size_t cliora_contrastive_workspace_bytes(int B, int C) { return ((size_t)(C / 2) * (B + 1) + 64) * sizeof(float); }
+
+extern "C" int cliora_contrastive_loss(int B, int C, const float* all_max, const float* inside_s, const float* outside_s, float margin,
+                                       float alpha, float* loss, float* d_all_max, float* d_inside_s, float* d_outside_s, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    if (!all_max || !inside_s || !outside_s || !loss || !d_all_max || !d_inside_s || !d_outside_s || !ws) return fail(CLIORA_EINVAL, "NULL argument");
+    if (B < 1 || B > 128 || C < 1) return fail(CLIORA_EINVAL, "contrastive loss kernel: 1 <= B <= 128");
+    if (ws_bytes < cliora_contrastive_workspace_bytes(B, C)) return fail(CLIORA_ENOMEM, "contrastive workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = C / 2;                              // trainer.py:126: only the first span_length // 2 spans enter the loss
+    float* part = (float*)ws;
+    float* last = part + ((nb + 63) / 64) * 64;
+    HIPOK(hipMemsetAsync(d_all_max, 0, (size_t)B * B * C * sizeof(float), st));
+    HIPOK(hipMemsetAsync(d_inside_s, 0, (size_t)B * C * sizeof(float), st));
+    HIPOK(hipMemsetAsync(d_outside_s, 0, (size_t)B * C * sizeof(float), st));
+    const float k = alpha / (float)B;
+    if (nb > 0) {
+        const size_t lds = ((size_t)B * (B + 1) + 4 * B + 256) * sizeof(float);
+        OKR(cliora_ensure_max_lds((const void*)contrastive_spans));
+        hipLaunchKernelGGL(contrastive_spans, dim3(nb), dim3(256), lds, st, B, C, all_max, inside_s, outside_s, margin, k, part, last,
+                           d_all_max, d_inside_s, d_outside_s);
+        LAUNCHOK("contrastive_spans");
+    }
+    hipLaunchKernelGGL(contrastive_finish, dim3(1), dim3(128), 0, st, B, C, nb, part, last, k, loss, d_inside_s);
+    LAUNCHOK("contrastive_finish");
+    return CLIORA_OK;
+}

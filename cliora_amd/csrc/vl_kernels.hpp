@@ -488,6 +488,97 @@ static __global__ __launch_bounds__(256) void region_max_bwd_obj(int B, int Cq, 
     if (act1) st4(o + col1, acc1);
 }
 
+// ContrastiveLoss on the region maxima (trainer.py:103-128) with its gradient, one workgroup per span b < C/2.
+//   part[b] = sum_x marg[x][b] vl[x][b];  last[b][x] = marg[x][b] vl[x][b] (the in_s[x][C-1] term of the marginal's gradient)
+constexpr float CONTRASTIVE_FLOOR = 1e-8f;   // trainer.py:86 min_val
+static __global__ __launch_bounds__(256) void contrastive_spans(int B, int Cq, const float* __restrict__ M, const float* __restrict__ IS,
+                                                                const float* __restrict__ OS, float margin, float k,
+                                                                float* __restrict__ part, float* __restrict__ last,
+                                                                float* __restrict__ dM, float* __restrict__ dIS, float* __restrict__ dOS) {
+    extern __shared__ float sm[];
+    float* S = sm;                       // [B][B+1]: s[a][c] of this span (padded rows: column walks stay conflict-free)
+    float* diag = S + B * (B + 1);       // [B]
+    float* marg = diag + B;              // [B]
+    float* vl = marg + B;                // [B]
+    float* dd = vl + B;                  // [B] gradient reaching the diagonal through the subtracted positives
+    float* red = dd + B;                 // [256]
+    const int b = blockIdx.x, tid = threadIdx.x, ld = B + 1;
+    for (int e = tid; e < B * B; e += 256) {
+        const int a = e / B, c = e - a * B;
+        S[a * ld + c] = M[((size_t)a * B + c) * Cq + b];
+    }
+    __syncthreads();
+    if (tid < B) {
+        diag[tid] = S[tid * ld + tid];
+        marg[tid] = expf(IS[(size_t)tid * Cq + b] + OS[(size_t)tid * Cq + b] - IS[(size_t)tid * Cq + Cq - 1]);
+    }
+    __syncthreads();
+    const float invB = 1.f / (float)B;
+    if (tid < B) {                       // row x = tid: text hinge over the images; column x: image hinge over the texts
+        const int x = tid;
+        float lt = 0.f, li = 0.f;
+        for (int j = 0; j < B; ++j) {
+            if (j == x) continue;
+            lt += fmaxf(margin + S[x * ld + j] - diag[x], CONTRASTIVE_FLOOR);
+            li += fmaxf(margin + S[j * ld + x] - diag[x], CONTRASTIVE_FLOOR);
+        }
+        vl[x] = (lt + li) * invB;
+    }
+    __syncthreads();
+    // gradient: d txt[a][c] = k marg[a] / B, d img[a][c] = k marg[c] / B, through the clamp where its argument >= the floor
+    if (tid < B) {
+        const int x = tid;
+        float g = 0.f;
+        for (int j = 0; j < B; ++j) {
+            if (j == x) continue;
+            if (margin + S[x * ld + j] - diag[x] >= CONTRASTIVE_FLOOR) g -= k * marg[x] * invB;      // txt row x subtracts diag[x]
+            if (margin + S[j * ld + x] - diag[x] >= CONTRASTIVE_FLOOR) g -= k * marg[x] * invB;      // img column x (-> vl[x]) subtracts diag[x]
+        }
+        dd[x] = g;
+    }
+    __syncthreads();
+    for (int e = tid; e < B * B; e += 256) {
+        const int a = e / B, c = e - a * B;
+        float g;
+        if (a == c) g = dd[a];
+        else {
+            const float s = S[a * ld + c];
+            g = (margin + s - diag[a] >= CONTRASTIVE_FLOOR ? k * marg[a] * invB : 0.f) + (margin + s - diag[c] >= CONTRASTIVE_FLOOR ? k * marg[c] * invB : 0.f);
+        }
+        dM[((size_t)a * B + c) * Cq + b] = g;
+    }
+    float p = 0.f;
+    if (tid < B) {
+        const float mv = marg[tid] * vl[tid];
+        p = mv;
+        dIS[(size_t)tid * Cq + b] = k * mv;          // d marg = k vl, d (in_s + out_s) = d marg * marg
+        dOS[(size_t)tid * Cq + b] = k * mv;
+        last[(size_t)b * B + tid] = mv;
+    }
+    red[tid] = p;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0) part[b] = red[0];
+}
+// loss = k sum_b part[b];  d in_s[x][C-1] = -k sum_b last[b][x]   (fixed order)
+static __global__ void contrastive_finish(int B, int Cq, int nb, const float* __restrict__ part, const float* __restrict__ last, float k,
+                                          float* __restrict__ loss, float* __restrict__ dIS) {
+    const int x = threadIdx.x;
+    if (x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += part[b];
+        loss[0] = k * s;
+    }
+    if (x < B) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += last[(size_t)b * B + x];
+        dIS[(size_t)x * Cq + Cq - 1] -= k * s;
+    }
+}
+
 // A(r, k) = dScore[a][c][b][d] with r = (a, b), k = (c, d); k >= B*R reads as zero
 struct ScoreGradA {
     const float* G; int B, Cq, R;

@@ -70,8 +70,38 @@ class ReconstructionSoftmaxLoss(nn.Module):
         return F.cross_entropy(logits, torch.zeros(B * L, dtype=torch.long, device=logits.device))
 
 
+class FusedContrastive(torch.autograd.Function):
+    """cliora_contrastive_loss: the hinge + span-marginal weighting of trainer.py:103-128 on the region maxima (B, B, C), value and
+    gradient in one launch (the backward scales the stored gradients by the incoming cotangent)."""
+
+    @staticmethod
+    def forward(ctx, smax, ins, outs, margin, alpha):
+        from . import _lib
+        import ctypes as C
+        B, _, Cc = smax.shape
+        smax, ins, outs = smax.contiguous().float(), ins.contiguous().float(), outs.contiguous().float()
+        dev = smax.device
+        loss = torch.empty(1, device=dev)
+        d_smax, d_ins, d_outs = torch.empty_like(smax), torch.empty_like(ins), torch.empty_like(outs)
+        nbytes = _lib.lib().cliora_contrastive_workspace_bytes(B, Cc)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            rc = _lib.lib().cliora_contrastive_loss(B, Cc, p(smax), p(ins), p(outs), float(margin), float(alpha), p(loss), p(d_smax), p(d_ins),
+                                                   p(d_outs), p(ws), nbytes, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, 'cliora_contrastive_loss')
+        ctx.save_for_backward(d_smax, d_ins, d_outs)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d_smax, d_ins, d_outs = ctx.saved_tensors
+        return d_smax * g, d_ins * g, d_outs * g, None, None
+
+
 class ContrastiveLoss(nn.Module):
     name = 'contrastive_loss'
+    fused = True            # native kernel when the scores are on the GPU and B <= 128 (False: the torch ops below)
 
     def __init__(self, margin=1.0, alpha_contr=0.01):
         super().__init__()
@@ -80,7 +110,10 @@ class ContrastiveLoss(nn.Module):
     def forward(self, diora):
         ins, outs = diora.inside_s.squeeze(-1), diora.outside_s.squeeze(-1)
         B, C = ins.shape
-        sc = diora.all_atten_score.max(-1).values.permute(2, 0, 1)       # C,B(text),B(image)
+        smax = diora.all_atten_score.max(-1).values                      # B(text),B(image),C
+        if self.fused and smax.is_cuda and B <= 128:
+            return FusedContrastive.apply(smax, ins, outs, self.margin, self.alpha)
+        sc = smax.permute(2, 0, 1)                                       # C,B(text),B(image)
         pos = torch.diagonal(sc, 0, 1, 2).unsqueeze(-1)                  # C,B,1
         off_diag = ~torch.eye(B, dtype=torch.bool, device=sc.device)
         txt = (self.margin + sc - pos).clamp(min=self.floor) * off_diag

@@ -184,6 +184,18 @@ int cliora_vl_scores_max_backward(cliora_plan* plan, const float* inside_h, cons
                                   const float* d_all_max, const int32_t* all_arg, float* d_sum_h, float* d_obj_span,
                                   void* vl_workspace, size_t vl_workspace_bytes, void* stream);
 
+/* ContrastiveLoss after the region max (cliora/net/trainer.py:103-128), one launch per direction:
+ *   s[b][a][c] = all_max[a][c][b];  txt = clamp(margin + s - s[b][a][a], min=1e-8), img = clamp(margin + s - s[b][c][c], min=1e-8),
+ *   both zero on a == c;  vl[a][b] = mean_c txt[b][a][c] + mean_a' img[b][a'][a];  marg[a][b] = exp(in_s + out_s - in_s[a][C-1]);
+ *   loss = alpha * mean_a sum_{b < C/2} marg[a][b] * vl[a][b]
+ * all_max (B,B,C), inside_s / outside_s (B,C).  The forward also leaves the gradient of the loss w.r.t. its three inputs (for an
+ * upstream cotangent of 1) in d_all_max (B,B,C), d_inside_s, d_outside_s (B,C): the caller scales them by the cotangent it
+ * receives.  B <= 128.  workspace: cliora_contrastive_workspace_bytes(B, C). */
+size_t cliora_contrastive_workspace_bytes(int B, int C);
+int cliora_contrastive_loss(int B, int C, const float* all_max, const float* inside_s, const float* outside_s, float margin,
+                            float alpha, float* loss, float* d_all_max, float* d_inside_s, float* d_outside_s, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Un-aggregated per-split tensors the reference hands to inside_hook (diora.py:295-334)
  * for `level`: scores = (B, L-level, level) laid out exactly like the reference's
  * s.view(B, Lc, N, 1); h = the compose outputs, `rows` = B*(L-level)*level rows of D

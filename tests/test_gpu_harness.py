@@ -57,3 +57,32 @@ def test_net_losses_grads_and_three_adam_steps(name, vl, mfma_mode):
         # are held to one lr (1e-3) and the exact-fp32 mode to half of it
         tol = 5e-4 if mfma_mode == 'f32' else 1e-3
         assert float((p.detach().cpu() - torch.from_numpy(want)).abs().max()) <= tol * max(1.0, float(np.abs(want).max())), k
+
+
+@pytest.mark.parametrize('B,L,margin', [(64, 20, 1.0), (7, 5, 0.2), (128, 6, 0.5), (2, 3, 1.0)])
+def test_fused_contrastive_loss_matches_the_torch_formula(B, L, margin):
+    """cliora_contrastive_loss (hinge + span-marginal weighting, trainer.py:103-128, one launch) against the same formula written
+    with torch ops (ContrastiveLoss.fused = False), value and the gradient of every input, under a non-unit upstream cotangent."""
+    from cliora_amd import harness as H
+
+    class Chart:
+        pass
+    C = L * (L + 1) // 2
+    g = torch.Generator().manual_seed(B * 100 + L)
+    smax0 = torch.randn(B, B, C, generator=g)
+    ins0, outs0 = 0.3 * torch.randn(B, C, 1, generator=g), 0.3 * torch.randn(B, C, 1, generator=g)
+    res = {}
+    for fused in (True, False):
+        t = [x.clone().cuda().requires_grad_(True) for x in (smax0, ins0, outs0)]
+        d = Chart()
+        d.inside_s, d.outside_s = t[1], t[2]
+        # what the module serves: an object whose .max(-1).values is the (B, B, C) region maximum
+        d.all_atten_score = torch.stack([t[0], t[0] - 1.0], -1)
+        loss_mod = H.ContrastiveLoss(margin=margin, alpha_contr=0.7)
+        loss_mod.fused = fused
+        loss = loss_mod(d)
+        (loss * 1.7).backward()
+        res[fused] = (float(loss), [x.grad.clone() for x in t])
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * max(1.0, abs(res[False][0]))
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())) + 1e-9
