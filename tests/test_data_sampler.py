@@ -43,3 +43,32 @@ def test_synthetic_batches_shapes():
         assert len(set(bm['neg_samples'].tolist())) == 10
         n += 1
     assert n == 4
+
+
+def test_device_feed_prefetches_in_order_and_shards():
+    """DeviceFeed (the staged version of batch_iterator.py:97-184's .cuda() calls): same batches, same order, this rank's share;
+    errors of the producer surface in the consumer.  On a CPU device it is a prefetching pass-through."""
+    import torch
+    from cliora_amd.data import DeviceFeed, partition, synthetic_batches
+    lengths = [5] * 9 + [7] * 6 + [3] * 4
+    want = list(synthetic_batches(50, lengths, 3, seed=5, k_neg=7))
+    got = list(DeviceFeed(synthetic_batches(50, lengths, 3, seed=5, k_neg=7), 'cpu', depth=2))
+    assert len(got) == len(want) and len(want) > 3
+    for a, b in zip(got, want):
+        assert a['example_ids'] == b['example_ids'] and torch.equal(a['sentences'], b['sentences']) and torch.equal(a['neg_samples'], b['neg_samples'])
+    for rank in range(2):
+        got = list(DeviceFeed(synthetic_batches(50, lengths, 4, seed=5, k_neg=7), 'cpu', depth=3, rank=rank, world=2))
+        for a, b in zip(got, synthetic_batches(50, lengths, 4, seed=5, k_neg=7)):
+            assert torch.equal(a['sentences'], partition(b['sentences'], rank, 2))
+            assert a['example_ids'] == partition(b['example_ids'], rank, 2)
+
+    def broken():
+        yield want[0]
+        raise RuntimeError('reader failed')
+    feed = DeviceFeed(broken(), 'cpu')
+    next(feed)
+    try:
+        next(feed)
+        assert False, 'the producer error must surface'
+    except RuntimeError as e:
+        assert 'reader failed' in str(e)

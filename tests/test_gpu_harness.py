@@ -86,3 +86,18 @@ def test_fused_contrastive_loss_matches_the_torch_formula(B, L, margin):
     assert abs(res[True][0] - res[False][0]) <= 1e-5 * max(1.0, abs(res[False][0]))
     for a, b in zip(res[True][1], res[False][1]):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())) + 1e-9
+
+
+def test_device_feed_on_the_gpu():
+    """DeviceFeed with pinned buffers, a copy stream and per-batch events: the staged batches are the source's, in order."""
+    from cliora_amd.data import DeviceFeed, synthetic_batches
+    lengths = [6] * 12 + [9] * 8
+    want = list(synthetic_batches(80, lengths, 4, seed=3, k_neg=5))
+    feed = DeviceFeed(({**b, 'obj_feats': torch.full((b['batch_size'], 36, 64), float(i))} for i, b in enumerate(synthetic_batches(80, lengths, 4, seed=3, k_neg=5))),
+                      'cuda:0', depth=2)
+    n = 0
+    for i, (a, b) in enumerate(zip(feed, want)):
+        assert a['sentences'].is_cuda and torch.equal(a['sentences'].cpu(), b['sentences'])
+        assert float(a['obj_feats'].sum()) == float(i) * b['batch_size'] * 36 * 64
+        n += 1
+    assert n == len(want)
