@@ -156,7 +156,7 @@ def other_measurements(torch, dev, budget_steps=12):
             x.grad = None
             m(x, x, obj, obj) if R else m(x, x)
             outs = [getattr(m, k) for k in keys]
-            extra = [m.all_atten_score.sum() * 1e-3] if R else []
+            extra = [m.all_atten_score.max(-1).values.sum() * 1e-3] if R else []
             torch.autograd.backward(outs + extra, cot + [None] * len(extra))
         for _ in range(warmup):
             step()
@@ -191,7 +191,7 @@ def other_measurements(torch, dev, budget_steps=12):
         return dict(B=B, L=L, D=D, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1))
 
     cases = (('c1 DioraMLP d50 B8 L10', lambda: chart(lambda: DioraMLP(50), 8, 10, 50)),
-             ('c3 CLIORA d400 B64 L20 R36 (chart + scorers)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36)),
+             ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36)),
              ('DioraMLP d400 B64 L40', lambda: chart(lambda: DioraMLP(400), 64, 40, 400, steps=6, warmup=2)),
              ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2)),
              ('whole step DIORA c2 (Embed, chart, reconstruction loss, clip, Adam)', lambda: whole(False)),

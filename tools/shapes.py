@@ -35,7 +35,7 @@ def run(name, make, B, L, D, R=0, steps=20, warmup=5):
         outs = [getattr(m, k) for k in keys]
         extra = []
         if R:
-            extra = [m.all_atten_score.sum() * 1e-3]
+            extra = [m.all_atten_score.max(-1).values.sum() * 1e-3]
         torch.autograd.backward(outs + extra, [cot[k] for k in keys] + [None] * len(extra))
 
     for _ in range(warmup):
