@@ -334,9 +334,12 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
             if (level < L - 1) {
-                OKR(launch_rows_direct(sa, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
-                                StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
-                OKR(launch_scores(sa, score_args(level + 1, false, -1, 0)));
+                // projections of the finished rows (the attention kernel wrote H and its norms: nothing to normalise, no chart output)
+                // and the next level's scores in the same launch, the newest operands read from H as one "part"
+                ScoreArgs sc = score_args(level + 1, false, level, 1);
+                sc.HPn = nullptr;                  // the newest cells are final rows of H already
+                OKR(launch_level_project(sa, 1, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, IH, 0, 0, ws + f.bcat, ws + f.pi, ldpi,
+                                         (float*)nullptr, (float*)nullptr, sc));
             }
         } else if (level < L - 1) {      // norm + projection of this level, and the next level's scores in the same launch
             OKR(launch_level_project(sa, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HPi, hp_stride, p.normalize, ws + f.bcat,
