@@ -242,8 +242,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
-        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, PairScoreArgs{}, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, (size_t)0, 0,
+        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, (const float*)nullptr, (size_t)0, 0,
                            ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                            inside_c, D, IS);
         LAUNCHOK("cell_attend_fwd(leaves)");
@@ -329,8 +328,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                      ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, &SP));
         }
         if (vl) {   // cliora.py:140-157: attention residual between the aggregate and the second unit norm, then the projections
-            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, sa, g, L, PairScoreArgs{}, (const float*)nullptr,
-                               (const float*)nullptr, HPi, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
+            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, sa, g, L, HPi, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
                                ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
             if (level < L - 1) {

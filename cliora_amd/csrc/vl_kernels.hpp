@@ -21,22 +21,12 @@ namespace cliora {
 constexpr int VL_MAXR = 64;     // regions per image (one per lane in the softmax)
 
 // ---------------------------------------------------------------------------------
-// Forward for the inside cells of one level (N > 0: aggregate the N splits first; N == 0: leaves,
+// Forward for the inside cells of one level (N > 0: sum the partial aggregates first; N == 0: leaves,
 // source = tanh output T).  Writes H = unit(u + ctx), U = u, P = prob (before dropout), the two
 // norms, and for the leaves inside_c = unit(ctx).
 // ---------------------------------------------------------------------------------
-// split-score inputs / outputs when the scoring of pair_scores_fwd is done inside cell_attend_fwd (arow == nullptr: not fused)
-struct PairScoreArgs {
-    const int32_t *arow, *brow;
-    const float* QA; int ldA;
-    const float *HB, *SA, *SB;
-    float *Sp, *Pp, *Sout;
-};
-
-// HP != nullptr: the aggregate g = sum_n p_n y_n of the level's cells comes from level_compose_fwd as SP partial rows (HP), the
-// scores from pair_scores_fwd (Y, Pp and the fused scoring are then unused).
-static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, PairScoreArgs sc, const float* __restrict__ Y, const float* __restrict__ Pp,
-                                                       const float* __restrict__ HP, size_t hp_stride, int SP,
+// The aggregate g = sum_n p_n y_n of the level's cells comes from level_compose_fwd as SP partial rows (HP).
+static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const float* __restrict__ HP, size_t hp_stride, int SP,
                                                        const float* __restrict__ T, const float* __restrict__ OBJ, int R,
                                                        const float* __restrict__ mask, int normalize,
                                                        float* __restrict__ H, float* __restrict__ nrmV, float* __restrict__ U,
@@ -67,68 +57,12 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
         if (a0) v0 = ld4(s + c0);
         if (a1) v1 = ld4(s + c1);
         if (tid == 0) S[crow] = 0.f;
-    } else if (HP) {                                  // every wave reads the whole (pre-aggregated) row: parts added in order
+    } else {                                          // every wave reads the whole (pre-aggregated) row: parts added in order
         for (int sp = 0; sp < SP; ++sp) {
             const float* src = HP + (size_t)sp * hp_stride + crow * Dp;
             if (a0) v0 = f4add(v0, ld4(src + c0));
             if (a1) v1 = f4add(v1, ld4(src + c1));
         }
-    } else {
-        const int row0 = g.rowbase + t * g.N;
-        const bool fused = sc.arow != nullptr;        // uniform
-        float pn_lane = 0.f;                          // softmax weight of split `lane` (fused scoring)
-        if (fused) {                                  // bilinear split scores + softmax, as pair_scores_fwd
-            for (int n0 = wave; n0 < g.N; n0 += 16) {
-                int ar[4], br[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = min(n0 + 4 * j, g.N - 1);
-                    ar[j] = sc.arow[row0 + n];
-                    br[j] = sc.brow[row0 + n];
-                }
-                float d[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float* qa = sc.QA + (size_t)ar[j] * sc.ldA;
-                    const float* hb = sc.HB + (size_t)br[j] * Dp;
-                    float v = 0.f;
-                    if (a0) v = f4dot(ld4(qa + c0), ld4(hb + c0));
-                    if (a1) v += f4dot(ld4(qa + c1), ld4(hb + c1));
-                    d[j] = v;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float s = wave_sum(d[j]) + sc.SA[ar[j]] + sc.SB[br[j]];
-                    if (lane == 0 && n0 + 4 * j < g.N) sh_sc[n0 + 4 * j] = s;
-                }
-            }
-            __syncthreads();
-            const float my_s = lane < g.N ? sh_sc[lane] : -INFINITY;
-            const float m = wave_max(my_s);
-            const float e = lane < g.N ? expf(my_s - m) : 0.f;
-            pn_lane = e / wave_sum(e);
-            if (wave == 0) {
-                if (lane < g.N) { sc.Sp[row0 + lane] = my_s; sc.Pp[row0 + lane] = pn_lane; }
-                const float st = wave_sum(lane < g.N ? pn_lane * my_s : 0.f);
-                if (lane == 0) sc.Sout[crow] = st;
-            }
-        }
-        for (int n0 = wave; n0 < g.N; n0 += 16) {
-            float pn[4];
-            float4 y0[4], y1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = min(n0 + 4 * j, g.N - 1);
-                const float pf = __shfl(pn_lane, min(n, 63));
-                pn[j] = (n0 + 4 * j < g.N) ? (fused ? pf : Pp[row0 + n]) : 0.f;
-                const float* y = Y + (size_t)(row0 + n) * Dp;
-                y0[j] = a0 ? ld4(y + c0) : f4zero();
-                y1[j] = a1 ? ld4(y + c1) : f4zero();
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0 = f4fma(pn[j], y0[j], v0); v1 = f4fma(pn[j], y1[j], v1); }
-        }
-        sum_waves(v0, v1);
     }
     // u = unit(v)   (every wave holds the whole row)
     const float nu = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
