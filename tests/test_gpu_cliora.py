@@ -180,3 +180,43 @@ def test_region_max_scorer_is_the_dense_scorer_then_max(B, L, D, R, mfma_mode):
     a = m.all_atten_score
     dense = a[:, :, :L]
     assert tuple(dense.shape) == (B, B, L, R) and torch.equal((a * 2.0).max(-1).values, res[False][0] * 2.0)
+
+
+@pytest.mark.parametrize('B,L,D,R,share', [(16, 12, 400, 36, True), (6, 3, 48, 5, False), (64, 20, 400, 36, True)])
+def test_cliora_wavefront_is_bitwise_the_sequential_order(B, L, D, R, share, mfma_mode):
+    """The CLIORA levels (attention between the aggregate and the projection) on two streams against one stream: bit for bit."""
+    from cliora_amd import _lib
+    from cliora_amd.cliora import DioraMLP
+    torch.manual_seed(3)
+    m = DioraMLP(D, outside=True, normalize='unit', compress=False, share=share).cuda().train()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    C = L * (L + 1) // 2
+    m.dropout_mask = (torch.rand(B, C, R, device='cuda') > 0.1).float() / 0.9
+    g = torch.Generator().manual_seed(5)
+    t = [torch.randn(sh, generator=g).cuda().requires_grad_(True) for sh in ((B, L, D), (B, L, D), (B, R, D), (B, R, D))]
+    keys = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
+    cot = [torch.randn(B, C, 1 if k.endswith('_s') else D, generator=g).cuda() for k in keys]
+    res = {}
+    prev = _lib.set_wavefront('off')
+    try:
+        for mode in ('off', 'on', 'on'):
+            _lib.set_wavefront(mode)
+            for p in m.parameters():
+                p.grad = None
+            for x in t:
+                x.grad = None
+            m(*t)
+            outs = [getattr(m, k) for k in keys]
+            loss = m.all_atten_score.max(-1).values.sum() * 1e-2 + m.vg_atten_score.sum() * 1e-2
+            torch.autograd.backward(outs + [loss], cot + [None])
+            cur = ([o.detach().clone() for o in outs], [x.grad.clone() for x in t], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+            if mode == 'off':
+                res = cur
+                continue
+            for a, b in zip(cur[0] + cur[1], res[0] + res[1]):
+                assert torch.equal(a, b)
+            for n in res[2]:
+                assert torch.equal(cur[2][n], res[2][n]), n
+    finally:
+        _lib.set_wavefront(prev)
