@@ -181,7 +181,9 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
         f.total = o;
-        f.pair_h = o;                               // optional tail (hooks)
+        // per-pair compose outputs for the hooks: the TreeLSTM keeps them anyway (y rows), DioraMLP writes them into an
+        // optional tail of the workspace only when a hook is overridden
+        f.pair_h = arch == 0 ? o : f.y;
         f.pair_h_floats = arch == 0 ? align64(Rt * Dp) : 0;
     }
     {

@@ -107,11 +107,7 @@ class DioraTreeLSTM(DioraBase):
         self.chart = ch
         self._wss, self._plan = holder, plan
         self.init_with_batch(ih[:, :L], ic[:, :L])
-        if self._hook_overridden('outside_hook'):
-            # the TreeLSTM pair rows keep (h, c) of the outside splits in this library's own order only
-            raise NotImplementedError('outside_hook is not served by the native TreeLSTM path (inside_hook is)')
-        if self._hook_overridden('inside_hook'):
-            for level in range(1, L):
-                h, s = self.pair_states(level)
-                self.inside_hook(level, h, torch.zeros_like(h), s)
+        # hooks: per-split h (the pair rows the backward keeps anyway) and scores, in the reference's layout and order
+        # (diora.py:331, 398); the per-split cell states are not kept: c is passed as zeros, as for DioraMLP
+        self._serve_hooks(L)
         return None

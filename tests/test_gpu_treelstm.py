@@ -73,3 +73,31 @@ def test_treelstm_against_oracle(D, B, L):
     for k, p in P.items():
         assert _err(named[k].grad, p.grad.numpy()) <= 2e-4 * _scale(p.grad.numpy()), k
     assert _err(xg.grad, xc.grad.numpy()) <= 2e-4 * _scale(xc.grad.numpy())
+
+
+def test_treelstm_hooks_receive_the_reference_states():
+    """inside_hook / outside_hook on the TreeLSTM module: (level, h, c, s) in the reference's layout and order (diora.py:331, 398),
+    checked against the oracle's per-split scores and outside compose outputs."""
+    import types
+    from oracle import diora_ref as R
+    D, B, L = 48, 3, 7
+    P = R.init_params_treelstm(D, seed=4)
+    x = torch.randn(B, L, D, generator=torch.Generator().manual_seed(8))
+    m = _module(P, D).eval()
+    seen_in, seen_out = [], []
+    m.inside_hook = types.MethodType(lambda self, level, h, c, s: seen_in.append((level, h.clone(), s.clone())), m)
+    m.outside_hook = types.MethodType(lambda self, level, h, c, s: seen_out.append((level, h.clone(), s.clone())), m)
+    with torch.no_grad():
+        m(x.cuda(), x.cuda())
+        ref = R.diora_forward(P, x, x, arch='treelstm', keep_pairs=True)
+    assert [lv for lv, _, _ in seen_in] == list(range(1, L)) and [lv for lv, _, _ in seen_out] == list(range(L - 2, -1, -1))
+    for level, h, s in seen_in:
+        want = ref['pair_s_in'][level]
+        assert tuple(s.shape) == tuple(want.shape) == (B, L - level, level, 1)
+        assert _err(s, want) <= 2e-4 * _scale(want), level
+        assert tuple(h.shape) == (B * (L - level) * level, D)
+    for level, h, s in seen_out:
+        Lc, N = L - level, L - level - 1
+        want_s, want_h = ref['pair_s_out'][level], ref['pair_h_out'][level].reshape(B * N * Lc, D)
+        assert tuple(s.shape) == (B, N, Lc, 1) and _err(s, want_s) <= 2e-4 * _scale(want_s), level
+        assert tuple(h.shape) == (B * N * Lc, D) and _err(h, want_h) <= 1e-4 * _scale(want_h), level
