@@ -2,6 +2,13 @@
 #include "api_common.hpp"
 #include "lstm_kernels.hpp"
 
+// two streams pay under the same rule as for DioraMLP (api_mlp.hip: wavefront_pays)
+static bool wavefront_pays_lstm(const Plan& p, int mode) {
+    if (p.L <= 2 || mode == 0) return false;
+    if (mode == 1) return true;
+    return (double)(p.R_in + p.R_out) / (2.0 * (p.L - 1)) * p.Dp >= 100e3;
+}
+
 // ------------------------------------------------------------------ DioraTreeLSTM (parity unpinned, see lstm_kernels.hpp)
 extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, float* inside_h, float* inside_c,
                                    float* inside_s, float* outside_h, float* outside_c, float* outside_s, void* fwd_ws,
@@ -14,6 +21,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
+    std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
     const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
@@ -66,48 +74,72 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     LAUNCHOK("lstm_leaf_fwd");
     if (L > 1)
         OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
-    for (int level = 1; level < L; ++level) {
+    // The two passes as a wavefront (see cliora_chart_forward): step k runs inside level k on the caller's stream and outside level
+    // L-k on the side stream, which needs the inside projections of the levels <= k-2 (its siblings).
+    const bool two_streams = wavefront_pays_lstm(p, g_cliora_wavefront) && run_outside;
+    hipStream_t sa = st, sb = two_streams ? plan->side : st;
+    auto inside_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, IH, IS, IS,
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, sa, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, IH, IS, IS,
                            ws + f.sp, ws + f.pp, IS);
         LAUNCHOK("pair_scores_fwd");
-        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
+        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, sa, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
                            ws + f.pi + 5 * Dp, ldpi, IC, IC, 1.0f, ws + f.y, ws + f.x);
         LAUNCHOK("lstm_pair_fwd");
-        hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, IH, IC,
+        hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, sa, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, IH, IC,
                            ws + f.nrmi, ws + f.nrmic);
         LAUNCHOK("lstm_aggregate_fwd");
         if (level < L - 1)
-            OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
+            OKR(launch_rows_direct(sa, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                                    StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
+        return CLIORA_OK;
+    };
+    auto outside_step = [&](int level) -> int {
+        const LevelArgs g = level_args(p, level, true);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, sb, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, OH, IS, OS,
+                           ws + f.sp, ws + f.pp, OS);
+        LAUNCHOK("pair_scores_fwd(out)");
+        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, sb, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
+                           ws + f.po, ldpo, IC, OC, 0.0f, ws + f.y, ws + f.x);
+        LAUNCHOK("lstm_pair_fwd(out)");
+        hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, sb, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, OH, OC,
+                           ws + f.nrmo, ws + f.nrmoc);
+        LAUNCHOK("lstm_aggregate_fwd(out)");
+        if (level >= 1)
+            OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
+                                   StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));
+        return CLIORA_OK;
+    };
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_fork[0], st));
+        HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
     }
     if (run_outside) {
-        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH, ws + f.nrmo, OS);
-        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, st, ws + f.rootc, 0, B, 1, C, C - 1, Dp, p.normalize, OC, ws + f.nrmoc, OS);
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH, ws + f.nrmo, OS);
+        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootc, 0, B, 1, C, C - 1, Dp, p.normalize, OC, ws + f.nrmoc, OS);
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1)
-            OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
-        for (int level = L - 2; level >= 0; --level) {
-            const LevelArgs g = level_args(p, level, true);
-            const int ncell = B * g.Lc, nrows = ncell * g.N;
-            hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, st, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, OH, IS, OS,
-                               ws + f.sp, ws + f.pp, OS);
-            LAUNCHOK("pair_scores_fwd(out)");
-            hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
-                               ws + f.po, ldpo, IC, OC, 0.0f, ws + f.y, ws + f.x);
-            LAUNCHOK("lstm_pair_fwd(out)");
-            hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, st, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, OH, OC,
-                               ws + f.nrmo, ws + f.nrmoc);
-            LAUNCHOK("lstm_aggregate_fwd(out)");
-            if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
-                                       StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));
-        }
+            OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
     } else {
         HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(OC, 0, (size_t)B * C * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
+    }
+    for (int k = 1; k <= L; ++k) {
+        if (k <= L - 1) {
+            OKR(inside_step(k));
+            if (two_streams) HIPOK(hipEventRecord(plan->ev_level[k], sa));
+        }
+        if (run_outside && k >= 2) {
+            if (two_streams && k >= 3) HIPOK(hipStreamWaitEvent(sb, plan->ev_level[k - 2], 0));
+            OKR(outside_step(L - k));
+        }
+    }
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_join[0], sb));
+        HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
     }
     if (padded) {
         CopyTable t; t.n = 0;
@@ -135,6 +167,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     if (!plan->uploaded) return fail(CLIORA_EINVAL, "backward called before forward");
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
+    std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
     const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     float* wb = (float*)bwd_ws;
@@ -151,53 +184,74 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     float *DA = wb + bw.da, *DCA = wb + bw.dz, *DCB = wb + bw.dcb, *DS = wb + bw.ds, *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
     const float *Y = ws + f.y, *Xc = ws + f.x, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po;
 
-    if (ran_outside) {
-        for (int level = 0; level <= L - 1; ++level) {
-            const LevelArgs g = level_args(p, level, true);
-            const int ncell = B * g.Lc, nrows = ncell * g.N;
-            hipLaunchKernelGGL(lstm_gather_bwd_out, dim3(ncell, (7 * Dp / 4 + 255) / 256), dim3(256), 0, st, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os,
-                               dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VH, VC, dStot);
-            LAUNCHOK("lstm_gather_bwd_out");
-            if (level >= 1)
-                OKR(launch_rows_direct(st, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
-                                       StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
-            if (level == L - 1) {
-                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VH, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
-                hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VC, OC, ws + f.nrmoc, p.normalize, wb + bw.grootc);
-                LAUNCHOK("root_bwd");
-                break;
-            }
-            hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, VC, OH, OC, ws + f.nrmo, ws + f.nrmoc, p.normalize, Y, Xc,
-                               Sp, Pp, OS, dStot, dG, dGc, DS);
-            LAUNCHOK("lstm_scores_bwd(out)");
-            hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
-                               PO, ldpo, IC, OC, 0.0f, Xc, Pp, dG, dGc, DA, DCA, DCB);
-            LAUNCHOK("lstm_pair_bwd(out)");
+    const bool two_streams = wavefront_pays_lstm(p, g_cliora_wavefront) && ran_outside;
+    hipStream_t sa = st, sb = two_streams ? plan->side : st;
+    float *VHo = wb + bw.vh_o, *VCo = wb + bw.vc_o, *dGo = wb + bw.dg_o, *dGco = wb + bw.dgc_o, *dStoto = wb + bw.dstot_o;
+    auto outside_bwd_step = [&](int level) -> int {
+        const LevelArgs g = level_args(p, level, true);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(lstm_gather_bwd_out, dim3(ncell, (7 * Dp / 4 + 255) / 256), dim3(256), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os,
+                           dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VHo, VCo, dStoto);
+        LAUNCHOK("lstm_gather_bwd_out");
+        if (level >= 1)
+            OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
+                                   StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (level == L - 1) {
+            hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, sb, B, C, Dp, VHo, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+            hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, sb, B, C, Dp, VCo, OC, ws + f.nrmoc, p.normalize, wb + bw.grootc);
+            LAUNCHOK("root_bwd");
+            return CLIORA_OK;
         }
-        OKR(launch_tn(st, B * C, ldpo, Dp, Dp, PlainRowsA{dPO, ldpo}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
-                      (float*)nullptr));
-    } else {
+        hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, sb, g, VHo, VCo, OH, OC, ws + f.nrmo, ws + f.nrmoc, p.normalize, Y, Xc,
+                           Sp, Pp, OS, dStoto, dGo, dGco, DS);
+        LAUNCHOK("lstm_scores_bwd(out)");
+        hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, sb, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
+                           PO, ldpo, IC, OC, 0.0f, Xc, Pp, dGo, dGco, DA, DCA, DCB);
+        LAUNCHOK("lstm_pair_bwd(out)");
+        return CLIORA_OK;
+    };
+    auto inside_bwd_step = [&](int level) -> int {
+        const LevelArgs g = level_args(p, level, false);
+        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        hipLaunchKernelGGL(lstm_gather_bwd_in, dim3(ncell, (13 * Dp / 4 + 255) / 256), dim3(256), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA],
+                           dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
+        LAUNCHOK("lstm_gather_bwd_in");
+        if (level <= L - 2)
+            OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                                   StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        if (level == 0) return CLIORA_OK;
+        hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, sa, g, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic, p.normalize, Y, Xc, Sp,
+                           Pp, IS, dStot, dG, dGc, DS);
+        LAUNCHOK("lstm_scores_bwd(in)");
+        hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, sa, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
+                           PI + 5 * Dp, ldpi, IC, IC, 1.0f, Xc, Pp, dG, dGc, DA, DCA, DCB);
+        LAUNCHOK("lstm_pair_bwd(in)");
+        return CLIORA_OK;
+    };
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_fork[0], st));
+        HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+    }
+    if (!ran_outside) {
         HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, 5 * DD * sizeof(float), st));
         HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(wb + bw.grootc, 0, (size_t)Dp * sizeof(float), st));
     }
-    for (int level = L - 1; level >= 0; --level) {
-        const LevelArgs g = level_args(p, level, false);
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(lstm_gather_bwd_in, dim3(ncell, (13 * Dp / 4 + 255) / 256), dim3(256), 0, st, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA],
-                           dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
-        LAUNCHOK("lstm_gather_bwd_in");
-        if (level <= L - 2)
-            OKR(launch_rows_direct(st, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
-                                   StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
-        if (level == 0) break;
-        hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, st, g, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic, p.normalize, Y, Xc, Sp,
-                           Pp, IS, dStot, dG, dGc, DS);
-        LAUNCHOK("lstm_scores_bwd(in)");
-        hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, st, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
-                           PI + 5 * Dp, ldpi, IC, IC, 1.0f, Xc, Pp, dG, dGc, DA, DCA, DCB);
-        LAUNCHOK("lstm_pair_bwd(in)");
+    for (int j = 0; j <= L - 1; ++j) {                   // outside level j beside inside level L-1-j (see cliora_chart_backward)
+        if (ran_outside) {
+            OKR(outside_bwd_step(j));
+            if (two_streams) HIPOK(hipEventRecord(plan->ev_level[j], sb));
+        }
+        if (two_streams && j >= 1) HIPOK(hipStreamWaitEvent(sa, plan->ev_level[j - 1], 0));
+        OKR(inside_bwd_step(L - 1 - j));
     }
+    if (two_streams) {
+        HIPOK(hipEventRecord(plan->ev_join[0], sb));
+        HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
+    }
+    if (ran_outside)
+        OKR(launch_tn(st, B * C, ldpo, Dp, Dp, PlainRowsA{dPO, ldpo}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+                      (float*)nullptr));
     hipLaunchKernelGGL(lstm_leaf_bwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic,
                        p.normalize, ws + f.t, dU);
     LAUNCHOK("lstm_leaf_bwd");

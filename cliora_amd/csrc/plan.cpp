@@ -191,7 +191,8 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         size_t o = 0;
         auto take = [&](size_t n) { size_t at = o; o = align64(o + n); return at; };
         b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
-        b.vh_o = take(arch == 0 ? BC * Dp : 0); b.dg_o = take(arch == 0 ? BC * Dp : 0); b.dstot_o = take(arch == 0 ? BC : 0);
+        b.vh_o = take(BC * Dp); b.dg_o = take(BC * Dp); b.dstot_o = take(BC);
+        b.vc_o = take(lstm * BC * Dp); b.dgc_o = take(lstm * BC * Dp);
         b.da = take(Rt * (lstm ? 5 : 1) * Dp); b.ds = take(Rt);
         b.dz = take(Rt * Dp);
         b.x = take(arch == 0 ? Rt * Dp : 0);

@@ -62,6 +62,7 @@ struct FwdLayout {
 struct BwdLayout {
     size_t vh, dg, dstot;               // per-cell backward state (B*C x Dp), (B*C): inside chart
     size_t vh_o, dg_o, dstot_o;         // the same for the outside chart (the two backward chains run as a wavefront on two streams)
+    size_t vc_o, dgc_o;                 // TreeLSTM: the cell-state halves of the outside chart's backward state
     size_t da, ds;                      // per-pair grads (R x Dp), (R)
     size_t dz;                          // per-pair grad at the second pre-activation (R x Dp); TreeLSTM: d c_a per pair
     size_t x;                           // DioraMLP: per-pair first-layer activation relu(PL+PR) (R x Dp), re-formed by level_compose_bwd for the weight gradient

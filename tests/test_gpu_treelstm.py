@@ -101,3 +101,36 @@ def test_treelstm_hooks_receive_the_reference_states():
         want_s, want_h = ref['pair_s_out'][level], ref['pair_h_out'][level].reshape(B * N * Lc, D)
         assert tuple(s.shape) == (B, N, Lc, 1) and _err(s, want_s) <= 2e-4 * _scale(want_s), level
         assert tuple(h.shape) == (B * N * Lc, D) and _err(h, want_h) <= 1e-4 * _scale(want_h), level
+
+
+@pytest.mark.parametrize('D,B,L', [(400, 8, 14), (48, 3, 6)])
+def test_treelstm_wavefront_is_bitwise_the_sequential_order(D, B, L):
+    """TreeLSTM levels on two streams (cliora_set_wavefront) against the one-stream order: every output and gradient bit."""
+    from cliora_amd import _lib
+    from oracle import diora_ref as R
+    P = R.init_params_treelstm(D, seed=2)
+    m = _module(P, D)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, L, D, generator=g).cuda().requires_grad_(True)
+    C = L * (L + 1) // 2
+    cot = [torch.randn(B, C, 1 if k.endswith('_s') else D, generator=g).cuda() for k in KEYS]
+    prev = _lib.set_wavefront('off')
+    ref = None
+    try:
+        for mode in ('off', 'on', 'on'):
+            _lib.set_wavefront(mode)
+            for p in m.parameters():
+                p.grad = None
+            x.grad = None
+            m(x, x)
+            outs = [getattr(m, k) for k in KEYS]
+            torch.autograd.backward(outs, cot)
+            cur = [o.detach().clone() for o in outs] + [x.grad.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+            if ref is None:
+                ref = cur
+                continue
+            assert len(cur) == len(ref)
+            for a, b in zip(cur, ref):
+                assert torch.equal(a, b)
+    finally:
+        _lib.set_wavefront(prev)
