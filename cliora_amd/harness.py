@@ -205,4 +205,4 @@ class Trainer(object):
                 self.reducer.all_reduce_mean()
             torch.nn.utils.clip_grad_norm_(self.params, 5.0)
             self.optimizer.step()
-        return {'total_loss': float(total)}
+        return {'total_loss': float(total.detach())}
