@@ -180,15 +180,19 @@ def other_measurements(torch, dev, budget_steps=12):
         bm = dict(sentences=torch.randint(0, V, (B, L), generator=g).to(dev), neg_samples=torch.randperm(V, generator=g)[:K].to(dev))
         if vl:
             bm['obj_feats'] = torch.randn(B, 36, 2048, generator=g).to(dev)
-        for _ in range(warmup):
-            tr.step(bm, train=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.step(bm, train=True)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        return dict(B=B, L=L, D=D, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1))
+        res = {}
+        for sync in (True, False):       # True: loss.item() every step like the reference (trainer.py:463); False: the host runs ahead
+            for _ in range(warmup):
+                tr.step(bm, train=True, sync=sync)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(bm, train=True, sync=sync)
+            torch.cuda.synchronize()
+            res[sync] = (time.perf_counter() - t0) / steps
+        dt = res[True]
+        return dict(B=B, L=L, D=D, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1),
+                    ms_per_step_without_per_step_item=round(res[False] * 1e3, 3))
 
     cases = (('c1 DioraMLP d50 B8 L10', lambda: chart(lambda: DioraMLP(50), 8, 10, 50)),
              ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36)),

@@ -193,7 +193,10 @@ class Trainer(object):
         self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8)
         self.reducer = reducer                               # cliora_amd.parallel.FlatGradAllReduce or None
 
-    def step(self, batch_map, train=True, compute_loss=True):
+    def step(self, batch_map, train=True, compute_loss=True, sync=True):
+        """One training / evaluation step (trainer.py:437-501).  sync=True returns the loss as a Python float like the reference's
+        `.item()` (trainer.py:463) -- a device synchronisation per step; sync=False returns the 0-d tensor and lets the host run
+        ahead of the device (read it when logging)."""
         self.net.train(train)
         with torch.set_grad_enabled(train):
             out = self.net(batch_map['sentences'], batch_map.get('obj_feats'), batch_map.get('neg_samples'), compute_loss)
@@ -205,4 +208,4 @@ class Trainer(object):
                 self.reducer.all_reduce_mean()
             torch.nn.utils.clip_grad_norm_(self.params, 5.0)
             self.optimizer.step()
-        return {'total_loss': float(total.detach())}
+        return {'total_loss': float(total.detach()) if sync else total.detach()}

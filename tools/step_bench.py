@@ -26,15 +26,17 @@ def run(name, vl, B=64, L=20, D=400, V=10000, E=1024, K=100, steps=20, warmup=5)
     bm = dict(sentences=torch.randint(0, V, (B, L), generator=g).cuda(), neg_samples=torch.randperm(V, generator=g)[:K].cuda())
     if vl:
         bm['obj_feats'] = torch.randn(B, 36, 2048, generator=g).cuda()
-    for _ in range(warmup):
-        tr.step(bm, train=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(bm, train=True)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    print(json.dumps(dict(config=name, B=B, L=L, D=D, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1))), flush=True)
+    for sync in (True, False):           # True: loss.item() every step like the reference (trainer.py:463); False: the host runs ahead
+        for _ in range(warmup):
+            tr.step(bm, train=True, sync=sync)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(bm, train=True, sync=sync)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(json.dumps(dict(config=name + ('' if sync else ' (no per-step .item())'), B=B, L=L, D=D, ms_per_step=round(dt * 1e3, 3),
+                              sentences_per_s=round(B / dt, 1))), flush=True)
 
 
 if __name__ == '__main__':
