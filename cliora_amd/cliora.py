@@ -201,6 +201,8 @@ class LazyRegionScores:
         return self._dense
 
     def __getattr__(self, name):                    # only reached for names not defined above
+        if name.startswith('_'):                    # private / dunder probes (copy, pickle, ...) must not materialise or recurse
+            raise AttributeError(name)
         return getattr(self.materialize(), name)
 
     def __getitem__(self, idx):
