@@ -361,3 +361,40 @@ def test_outside_hook_receives_the_reference_states():
         if 'pair_h_out' in ref:
             want_h = ref['pair_h_out'][level].reshape(B * N * Lc, D)      # un-normalised compose outputs (magnitude ~10)
             assert _err(h, want_h) <= OUT_TOL * _scale(want_h), level
+
+
+def test_two_host_threads_share_the_device_lanes():
+    """Two host threads, each with its own torch stream and model, stepping at the same time: the library's side streams and
+    events are per device and shared (api_core.hip: device_lanes, guarded by a mutex while a call enqueues), so every result
+    must still be bitwise what the same thread computes alone."""
+    import threading
+    from oracle import synth
+    D, B, L = 400, 16, 12
+    cases = [synth.diora_case(D, B, L, 40 + i) for i in range(2)]
+    mods = [_module_from_params(P, D, True, 'unit') for P, _, _ in cases]
+
+    def run(i, out, reps):
+        P, x, cot = cases[i]
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(reps):
+                for p in mods[i].parameters():
+                    p.grad = None
+                outs, xg = _run_gpu(mods[i], x, cot)
+            s.synchronize()
+            out[i] = ({k: v.detach().clone() for k, v in outs.items()}, xg.grad.clone(),
+                      {n: p.grad.clone() for n, p in mods[i].named_parameters() if p.grad is not None})
+    alone, together = {}, {}
+    for i in range(2):
+        run(i, alone, 1)
+    th = [threading.Thread(target=run, args=(i, together, 6)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        for k in CHARTS:
+            assert torch.equal(alone[i][0][k], together[i][0][k]), (i, k)
+        assert torch.equal(alone[i][1], together[i][1]), i
+        for n in alone[i][2]:
+            assert torch.equal(alone[i][2][n], together[i][2][n]), (i, n)
