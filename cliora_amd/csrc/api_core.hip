@@ -114,7 +114,9 @@ static int pick_concurrent_stream(hipStream_t* busy, int nbusy, hipStream_t* out
     hipEvent_t e0 = nullptr, e1 = nullptr, ej = nullptr;
     HIPOK(hipEventCreate(&e0)); HIPOK(hipEventCreate(&e1)); HIPOK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
     int clk_khz = 100000;
-    (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, 0);
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, cur_dev) != hipSuccess || clk_khz <= 0) clk_khz = 100000;
     const long long ticks = 40LL * clk_khz / 1000;
     std::vector<hipStream_t> rejected;
     hipStream_t pick = nullptr;
