@@ -168,6 +168,30 @@ def other_measurements(torch, dev, budget_steps=12):
         dt = (time.perf_counter() - t0) / steps
         return dict(B=B, L=L, D=D, R=R, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1))
 
+    def parse(B=64, L=20, D=400, steps=budget_steps, warmup=3):
+        """Inference as scripts/parse.py runs it: eval-mode forward (no backward state kept) + the CKY decode of every sentence."""
+        torch.manual_seed(0)
+        m = DioraMLP(D).to(dev).eval()
+        for p in m.parameters():
+            torch.nn.init.normal_(p)
+        x = torch.randn(B, L, D, device=dev)
+        res = {}
+        for with_cky in (False, True):
+            def step():
+                with torch.no_grad():
+                    m(x, x)
+                    return m.cky() if with_cky else None
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            res[with_cky] = (time.perf_counter() - t0) / steps
+        return dict(B=B, L=L, D=D, ms_forward=round(res[False] * 1e3, 3), ms_forward_and_trees=round(res[True] * 1e3, 3),
+                    sentences_per_s=round(B / res[True], 1))
+
     def whole(vl, B=64, L=20, D=400, V=10000, E=1024, K=100, steps=budget_steps, warmup=3):
         from cliora_amd import harness as H
         torch.manual_seed(1234)
@@ -198,6 +222,7 @@ def other_measurements(torch, dev, budget_steps=12):
              ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36)),
              ('DioraMLP d400 B64 L40', lambda: chart(lambda: DioraMLP(400), 64, 40, 400, steps=6, warmup=2)),
              ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2)),
+             ('parse c2 (eval forward + CKY trees on the GPU, trees copied to the host)', parse),
              ('whole step DIORA c2 (Embed, chart, reconstruction loss, clip, Adam)', lambda: whole(False)),
              ('whole step CLIORA c3 (+ ImageEncoder, VG and contrastive losses)', lambda: whole(True)))
     for name, fn in cases:
