@@ -80,7 +80,7 @@ extern "C" size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan) { ret
 
 extern "C" int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count) {
     if (!plan || !name || !data || !count) return fail(CLIORA_EINVAL, "NULL argument");
-    const std::vector<int32_t>* v = find_table(plan->p, name);
+    const std::vector<int32_t>* v = find_table(const_cast<cliora_plan*>(plan)->p, name);   // may build the row maps (host side only)
     if (!v) return fail(CLIORA_EINVAL, std::string("unknown table ") + name);
     *data = v->data();
     *count = v->size();
@@ -91,7 +91,7 @@ extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
     if (!plan) return 0;
     const Plan& p = plan->p;
     size_t n = p.pair_a_in.size() + p.pair_b_in.size() + p.pair_a_out.size() + p.pair_b_out.size() + p.lvl_base_in.size() +
-               p.arow.size() + p.brow.size() + p.trow.size();
+               (p.arch == 1 ? 3 * (size_t)(p.R_in + p.R_out) : 0);     // the batch-expanded row maps: TreeLSTM plans only
     for (int r = 0; r < N_ROLES; ++r) n += p.uses[r].off.size() + 3 * p.uses[r].row.size();
     return n * sizeof(int32_t);
 }

@@ -173,7 +173,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
-    const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
     const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, nb = p.nblk, ldpi = nb * Dp;
@@ -287,7 +286,11 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         ScoreArgs sc{};
         sc.g = level_args(p, T, outside_pass);
         sc.nscore = B * sc.g.Lc;
-        sc.arow = dv.arow; sc.brow = dv.brow;
+        {
+            const size_t base = outside_pass ? p.lvl_base_out[T] : p.lvl_base_in[T];
+            sc.pa = p.d_tables + (outside_pass ? p.dev.pair_a_out : p.dev.pair_a_in) + base;
+            sc.pb = p.d_tables + (outside_pass ? p.dev.pair_b_out : p.dev.pair_b_in) + base;
+        }
         sc.QA = ws + f.pi + (size_t)(outside_pass ? p.blk_qlo : 2) * Dp; sc.ldA = ldpi;
         sc.HB = outside_pass ? OH : IH; sc.HA = IH;
         sc.SA = IS; sc.SB = outside_pass ? OS : IS;

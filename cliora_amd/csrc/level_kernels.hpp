@@ -306,7 +306,7 @@ __device__ __forceinline__ float4 sum_parts(const float* hp, size_t hp_stride, i
 struct ScoreArgs {
     int nscore;                     // target cells of the level to score (0: no scoring in this launch)
     LevelArgs g;                    // that level
-    const int32_t *arow, *brow;     // chart rows (b*C + cell) of the two operands of every pair row
+    const int32_t *pa, *pb;         // operand cells (ids inside one sentence's chart) of the level's pairs: index p*N + n
     const float* QA; int ldA;       // QL table of the a operands (row stride ldA)
     const float* HB;                // H chart of the b operands
     const float *SA, *SB;           // chart scores of the a / b operands
@@ -334,8 +334,8 @@ __device__ __forceinline__ void score_cell(const ScoreArgs& sc, int t, float* sh
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + 4 * j;
             if (n >= g.N) break;                     // wave-uniform
-            const int ar = sc.arow[row0 + n], br = sc.brow[row0 + n];
-            const int ca = ar - bC, cb = br - bC;
+            const int ca = sc.pa[p * g.N + n], cb = sc.pb[p * g.N + n];
+            const int ar = bC + ca, br = bC + cb;
             const bool a_new = sc.a_can_be_new && ca >= sc.new_lo && ca < sc.new_hi;
             const bool b_new = cb >= sc.new_lo && cb < sc.new_hi;
             float4 u0 = f4zero(), u1 = f4zero(), v0 = f4zero(), v1 = f4zero();

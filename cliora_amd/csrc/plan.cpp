@@ -101,31 +101,6 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         }
     }
 
-    // ---- per-row maps (batch expanded) ---------------------------------------------
-    {
-        const size_t Rt = (size_t)(p.R_in + p.R_out);
-        p.arow.resize(Rt); p.brow.resize(Rt); p.trow.resize(Rt);
-        for (int pass = 0; pass < 2; ++pass) {
-            const auto& ta = pass ? p.pair_a_out : p.pair_a_in;
-            const auto& tb = pass ? p.pair_b_out : p.pair_b_in;
-            const auto& base = pass ? p.lvl_base_out : p.lvl_base_in;
-            const int lv0 = pass ? 0 : 1, lv1 = pass ? L - 1 : L;
-            for (int lv = lv0; lv < lv1; ++lv) {
-                const int Lc = L - lv, N = pass ? L - lv - 1 : lv;
-                const long long rb = pass ? p.row_base_out(lv) : p.row_base_in(lv);
-                for (int b = 0; b < B; ++b)
-                    for (int pos = 0; pos < Lc; ++pos)
-                        for (int n = 0; n < N; ++n) {
-                            const int loc = pos * N + n;
-                            const size_t r = (size_t)(rb + (long long)b * Lc * N + loc);
-                            p.arow[r] = b * C + ta[base[lv] + loc];
-                            p.brow[r] = b * C + tb[base[lv] + loc];
-                            p.trow[r] = b * C + cell(lv, pos);
-                        }
-            }
-        }
-    }
-
     // ---- workspace layouts -----------------------------------------------------
     const size_t Dp = p.Dp, nb = p.nblk, BC = (size_t)B * C, BL = (size_t)B * L;
     const size_t npo = p.npo, nlf = p.nleaf, lstm = arch == 1 ? 1 : 0;
@@ -233,6 +208,36 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
     return "";
 }
 
+// Batch-expanded operand / target chart rows of every pair row.  Only the TreeLSTM kernels read them on the device (the DioraMLP
+// kernels index the per-sentence pair tables), so they are built on demand: at the TreeLSTM upload, or when a caller asks for the
+// tables by name (tests).  3 x (R_in + R_out) ints: 25 MB at B 64 / L 40.
+void build_row_maps(Plan& p) {
+    const size_t Rt = (size_t)(p.R_in + p.R_out);
+    if (p.arow.size() == Rt) return;
+    const int B = p.B, L = p.L, C = p.C;
+    auto cell = [&](int level, int pos) { return p.level_offset[level] + pos; };
+    p.arow.resize(Rt); p.brow.resize(Rt); p.trow.resize(Rt);
+    for (int pass = 0; pass < 2; ++pass) {
+        const auto& ta = pass ? p.pair_a_out : p.pair_a_in;
+        const auto& tb = pass ? p.pair_b_out : p.pair_b_in;
+        const auto& base = pass ? p.lvl_base_out : p.lvl_base_in;
+        const int lv0 = pass ? 0 : 1, lv1 = pass ? L - 1 : L;
+        for (int lv = lv0; lv < lv1; ++lv) {
+            const int Lc = L - lv, N = pass ? L - lv - 1 : lv;
+            const long long rb = pass ? p.row_base_out(lv) : p.row_base_in(lv);
+            for (int b = 0; b < B; ++b)
+                for (int pos = 0; pos < Lc; ++pos)
+                    for (int n = 0; n < N; ++n) {
+                        const int loc = pos * N + n;
+                        const size_t r = (size_t)(rb + (long long)b * Lc * N + loc);
+                        p.arow[r] = b * C + ta[base[lv] + loc];
+                        p.brow[r] = b * C + tb[base[lv] + loc];
+                        p.trow[r] = b * C + cell(lv, pos);
+                    }
+        }
+    }
+}
+
 std::vector<int32_t> flatten_tables(Plan& p) {
     std::vector<int32_t> flat;
     auto put = [&](const std::vector<int32_t>& v) {
@@ -251,12 +256,13 @@ std::vector<int32_t> flatten_tables(Plan& p) {
     }
     p.dev.lvl_base_in = put(p.lvl_base_in);
     p.dev.lvl_base_out = put(p.lvl_base_out);
+    if (p.arch == 1) build_row_maps(p);
     p.dev.arow = put(p.arow); p.dev.brow = put(p.brow); p.dev.trow = put(p.trow);
     if (flat.empty()) flat.push_back(0);
     return flat;
 }
 
-const std::vector<int32_t>* find_table(const Plan& p, const std::string& name) {
+const std::vector<int32_t>* find_table(Plan& p, const std::string& name) {
     if (name == "level_offset") return &p.level_offset;
     if (name == "pair_a_in") return &p.pair_a_in;
     if (name == "pair_b_in") return &p.pair_b_in;
@@ -264,6 +270,7 @@ const std::vector<int32_t>* find_table(const Plan& p, const std::string& name) {
     if (name == "pair_b_out") return &p.pair_b_out;
     if (name == "pair_lvl_base_in") return &p.lvl_base_in;
     if (name == "pair_lvl_base_out") return &p.lvl_base_out;
+    if (name == "arow" || name == "brow" || name == "trow") build_row_maps(p);
     if (name == "arow") return &p.arow;
     if (name == "brow") return &p.brow;
     if (name == "trow") return &p.trow;

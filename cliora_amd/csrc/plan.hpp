@@ -117,6 +117,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
 // Flattens all int32 tables into one array (to upload once); fills p.dev offsets.
 std::vector<int32_t> flatten_tables(Plan& p);
 
-const std::vector<int32_t>* find_table(const Plan& p, const std::string& name);
+const std::vector<int32_t>* find_table(Plan& p, const std::string& name);     // builds the row maps when they are asked for
+void build_row_maps(Plan& p);
 
 }  // namespace cliora
