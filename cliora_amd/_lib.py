@@ -63,6 +63,8 @@ def lib():
     L.cliora_plan_pair_states_bytes.restype = sz
     L.cliora_plan_device_bytes.argtypes = [vp]
     L.cliora_plan_device_bytes.restype = sz
+    L.cliora_plan_fwd_offset.argtypes = [vp, C.c_char_p]
+    L.cliora_plan_fwd_offset.restype = sz
     L.cliora_plan_table.argtypes = [vp, C.c_char_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(sz)]
     L.cliora_plan_table.restype = i32
     L.cliora_chart_forward.argtypes = [vp, C.POINTER(Params)] + [vp] * 8 + [vp, sz, i32, vp]
@@ -99,6 +101,10 @@ def lib():
     L.cliora_set_mfma_mode.restype = i32
     L.cliora_set_wavefront.argtypes = [i32]
     L.cliora_set_wavefront.restype = i32
+    L.cliora_set_persistent.argtypes = [i32]
+    L.cliora_set_persistent.restype = i32
+    L.cliora_persistent_status.argtypes = [vp, C.POINTER(C.c_uint), vp]
+    L.cliora_persistent_status.restype = i32
     _lib = L
     return L
 
@@ -201,6 +207,21 @@ def set_wavefront(mode):
     reference's order on the caller's stream alone) or 'on'.  Results are bitwise identical.  Returns the previous mode."""
     prev = lib().cliora_set_wavefront(WAVEFRONT_MODES[mode])
     return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
+
+
+def set_persistent(mode):
+    """The level loop of the forward as one persistent launch (include/cliora_chart.h: cliora_set_persistent): 'auto' (default:
+    on where the kernel covers the plan), 'off' (two launches per level) or 'on'.  Results are bitwise identical.  Returns the
+    previous mode."""
+    prev = lib().cliora_set_persistent(WAVEFRONT_MODES[mode])
+    return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
+
+
+def persistent_timeouts(plan, stream=0):
+    """Barrier waits of the persistent kernels that ever gave up on this plan's device (0 in normal operation); synchronises."""
+    n = C.c_uint()
+    check(lib().cliora_persistent_status(plan.handle, C.byref(n), C.c_void_p(stream)), 'cliora_persistent_status')
+    return n.value
 
 
 def set_mfma_mode(mode):

@@ -33,6 +33,12 @@ struct cliora_plan {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     const hipEvent_t* ev_level = nullptr;   // one per chart level: "this chain has finished level k" for the other chain
     std::mutex* lanes_mu = nullptr;
+    // persistent level-loop kernels (persist_kernels.hpp): one workgroup per CU that spins on grid-wide counters, so two of them
+    // must never share the device: every such launch waits for the previous one's event (device-wide chain, under lanes_mu)
+    int ncu = 0;
+    hipEvent_t ev_persist = nullptr;
+    unsigned* persist_status = nullptr;     // device words: [0] barrier timeouts since the process started
+    std::mutex upload_mu;                   // first-use upload of the tables (plans are shared between host threads)
 };
 
 extern thread_local std::string g_cliora_err;
@@ -56,6 +62,10 @@ static inline int fail(int code, const std::string& msg) { g_cliora_err = msg; r
 int cliora_ensure_max_lds(const void* fn);
 // uploads the plan's index tables on first use (current device) and checks that later calls run on that device
 int cliora_plan_ready(cliora_plan* plan, hipStream_t st);
+
+// persistent level-loop kernels (api_persist.hip)
+namespace cliora { struct PersistFwd; }
+int cliora_launch_persist_fwd(hipStream_t st, const cliora::PersistFwd& a, int ct, int nwg);
 
 // ------------------------------------------------------------------ profiling (HIP events)
 struct ProfClass {
@@ -87,6 +97,7 @@ struct ProfScope {
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
 extern int g_cliora_wavefront;      // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_wavefront)
+extern int g_cliora_persistent;     // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_persistent)
 extern int g_cliora_split_bf16;
 static inline bool split_bf16() {
     if (g_cliora_split_bf16 < 0) {

@@ -80,17 +80,40 @@ extern "C" size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan) { ret
 
 extern "C" int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count) {
     if (!plan || !name || !data || !count) return fail(CLIORA_EINVAL, "NULL argument");
-    const std::vector<int32_t>* v = find_table(const_cast<cliora_plan*>(plan)->p, name);   // may build the row maps (host side only)
+    cliora_plan* pl = const_cast<cliora_plan*>(plan);
+    std::lock_guard<std::mutex> up(pl->upload_mu);                   // find_table may build the row maps; so may a concurrent upload
+    const std::vector<int32_t>* v = find_table(pl->p, name);
     if (!v) return fail(CLIORA_EINVAL, std::string("unknown table ") + name);
     *data = v->data();
     *count = v->size();
     return CLIORA_OK;
 }
 
+// float offset of a named region of the forward workspace (tests and tooling: compare two runs region by region); (size_t)-1 = unknown
+extern "C" size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* name) {
+    if (!plan || !name) return (size_t)-1;
+    const FwdLayout& f = plan->p.fwd;
+    const std::string n = name;
+    if (n == "t") return f.t;
+    if (n == "pi") return f.pi;
+    if (n == "po") return f.po;
+    if (n == "sp") return f.sp;
+    if (n == "pp") return f.pp;
+    if (n == "hp") return f.hp;
+    if (n == "hp_o") return f.hp_o;
+    if (n == "ymask") return f.ymask;
+    if (n == "nrmi") return f.nrmi;
+    if (n == "nrmo") return f.nrmo;
+    if (n == "qrleaf") return f.qrleaf;
+    if (n == "sync") return f.sync;
+    if (n == "total") return f.total;
+    return (size_t)-1;
+}
+
 extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
     if (!plan) return 0;
     const Plan& p = plan->p;
-    size_t n = p.pair_a_in.size() + p.pair_b_in.size() + p.pair_a_out.size() + p.pair_b_out.size() + p.lvl_base_in.size() +
+    size_t n = p.pair_a_in.size() + p.pair_b_in.size() + p.pair_a_out.size() + p.pair_b_out.size() + p.lvl_base_in.size() + p.persist_levels.size() +
                (p.arch == 1 ? 3 * (size_t)(p.R_in + p.R_out) : 0);     // the batch-expanded row maps: TreeLSTM plans only
     for (int r = 0; r < N_ROLES; ++r) n += p.uses[r].off.size() + 3 * p.uses[r].row.size();
     return n * sizeof(int32_t);
@@ -100,6 +123,9 @@ extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
 struct DeviceLanes {
     hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t fork[3], join[3], level[CLIORA_MAX_L + 1];
+    hipEvent_t persist = nullptr;       // end of the last persistent launch on this device
+    unsigned* status = nullptr;         // 16 device words, zeroed once
+    int ncu = 0;
     std::mutex mu;
 };
 // Holds one workgroup for `ticks` of the 100 MHz wall clock: the probe of pick_concurrent_stream.
@@ -174,6 +200,11 @@ static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
             HIPOK(hipEventCreateWithFlags(&ln->join[k], hipEventDisableTiming));
         }
         for (int k = 0; k <= CLIORA_MAX_L; ++k) HIPOK(hipEventCreateWithFlags(&ln->level[k], hipEventDisableTiming));
+        HIPOK(hipEventCreateWithFlags(&ln->persist, hipEventDisableTiming));
+        HIPOK(hipEventRecord(ln->persist, st));
+        HIPOK(hipMalloc((void**)&ln->status, 64));
+        HIPOK(hipMemsetAsync(ln->status, 0, 64, st));
+        HIPOK(hipDeviceGetAttribute(&ln->ncu, hipDeviceAttributeMultiprocessorCount, dev));
         g_lanes[dev] = ln;
     }
     *out = g_lanes[dev];
@@ -183,12 +214,17 @@ static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
 int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     int dev = 0;
     HIPOK(hipGetDevice(&dev));
-    if (plan->uploaded) {
+    auto check_device = [&]() -> int {
         if (dev != plan->device)
             return fail(CLIORA_EINVAL, "plan tables live on device " + std::to_string(plan->device) + " but the current device is " +
                                            std::to_string(dev) + " (call under the tensors' device)");
         return CLIORA_OK;
-    }
+    };
+    if (__atomic_load_n(&plan->uploaded, __ATOMIC_ACQUIRE)) return check_device();
+    // plans are shared process-wide (cliora_amd/_lib.py) and ctypes drops the GIL: two host threads can make their first call on
+    // one cold plan together.  One of them uploads, the other waits here and then sees `uploaded` (published last, release).
+    std::lock_guard<std::mutex> up(plan->upload_mu);
+    if (plan->uploaded) return check_device();
     std::vector<int32_t> flat = flatten_tables(plan->p);
     HIPOK(hipMalloc((void**)&plan->p.d_tables, flat.size() * sizeof(int32_t)));
     HIPOK(hipMemcpyAsync(plan->p.d_tables, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -200,8 +236,9 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     for (int k = 0; k < 3; ++k) { plan->ev_fork[k] = ln->fork[k]; plan->ev_join[k] = ln->join[k]; }
     plan->ev_level = ln->level;
     plan->lanes_mu = &ln->mu;
-    plan->uploaded = true;
+    plan->ncu = ln->ncu; plan->ev_persist = ln->persist; plan->persist_status = ln->status;
     plan->device = dev;
+    __atomic_store_n(&plan->uploaded, true, __ATOMIC_RELEASE);
     return CLIORA_OK;
 }
 
@@ -296,4 +333,18 @@ extern "C" int cliora_set_wavefront(int mode) {
     return prev;
 }
 
-extern "C" const char* cliora_version(void) { return "cliora_amd 0.2 (gfx950)"; }
+int g_cliora_persistent = [] { const char* e = getenv("CLIORA_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+extern "C" int cliora_set_persistent(int mode) {
+    const int prev = g_cliora_persistent;
+    g_cliora_persistent = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
+    return prev;
+}
+extern "C" int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream) {
+    if (!plan || !timeouts) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan->uploaded) { *timeouts = 0; return CLIORA_OK; }
+    HIPOK(hipMemcpyAsync(timeouts, plan->persist_status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPOK(hipStreamSynchronize((hipStream_t)stream));
+    return CLIORA_OK;
+}
+
+extern "C" const char* cliora_version(void) { return "cliora_amd 0.3 (gfx950)"; }

@@ -2,38 +2,19 @@
 // See include/cliora_chart.h for the contract and the reference lines it replaces.
 #include "api_common.hpp"
 #include "level_kernels.hpp"
+#include "persist_kernels.hpp"
 #include "vl_kernels.hpp"
 
 // ------------------------------------------------------------------ fused level kernels (level_kernels.hpp)
-struct ComposeGeom { int TG, SP, ntask, gx; };
-// Tasks of level_compose_fwd: TG cell tiles per workgroup (8 / TG waves each), the split range cut in SP parts.
-static ComposeGeom compose_geom(int ncell, int N, int ncb, int cus) {
-    const int G = (ncell + 15) / 16;
-    const int cap = std::max(1, cus / ncb);                       // one workgroup per CU (the weight block fills LDS)
-    // Measured on MI355X (round 2, rocprof per-level traces): a round of tasks costs a ~5.8 us latency chain (index loads, ring
-    // fill, epilogue, reduction) plus ~2.8 us of MFMA / VALU / LDS issue per tile on the busiest SIMD (waves w and w+4 share
-    // one); rounds do not overlap.  Pick the cheapest geometry, fewer parts on a tie.
-    ComposeGeom best{1, 1, G, 1};
-    double best_t = 1e30;
-    for (int TG : {1, 2, 4, 8}) {
-        const int wpg = 8 / TG;
-        const int groups = (G + TG - 1) / TG;
-        for (int SP = 1; SP <= HP_PARTS && SP <= std::max(1, N); SP *= 2) {
-            const int np = (N + SP - 1) / SP;
-            const int ntask = groups * SP;
-            const int rounds = (ntask + cap - 1) / cap;
-            const int depth = (np + wpg - 1) / wpg;
-            const int busy = TG * std::min(wpg, np);
-            int simd = depth * (busy > 4 ? 2 : 1);
-            if (busy > 4 && wpg == 8 && np % 8 != 0 && np % 8 <= 4) simd -= 1;     // the last sweep reaches one wave of each pair only
-            const double t = rounds * (5.8 + 2.8 * simd) + 0.3 * (SP - 1);
-            if (t < best_t - 1e-9) { best_t = t; best = ComposeGeom{TG, SP, ntask, std::min(ntask, cap)}; }
-        }
-    }
-    ComposeGeom q = best;
+// Geometry of a level's compose launch: the plan's tasks (plan.cpp compose_geom, shared with the persistent kernel so that both
+// paths sum in the same order) on at most `cap` workgroups per column block.
+struct ComposeLaunch { int TG, SP, ntask, gx; };
+static ComposeLaunch compose_launch(const Plan& p, int level, bool outside_pass) {
+    const int32_t* e = p.persist_levels.data() + ((size_t)(outside_pass ? p.L : 0) + level) * PLEVEL_INTS;
+    ComposeLaunch q{e[5], e[6], e[7], std::min(e[7], p.compose_cap)};
     // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8 the column blocks
     // that gather the same operand rows share one XCD's L2 (speed only, never correctness)
-    if (q.gx >= 8 && (q.gx + 7) / 8 * 8 <= cap) q.gx = (q.gx + 7) / 8 * 8;
+    if (q.gx >= 8 && (q.gx + 7) / 8 * 8 <= p.compose_cap) q.gx = (q.gx + 7) / 8 * 8;
     return q;
 }
 
@@ -45,13 +26,11 @@ static size_t compose_lds_bytes(int ct, int S, bool with_slots) {
 template <int CT, int K16, bool F32>
 static int launch_level_compose_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* PA, int lda,
                                      const float* PB, int ldb, const float* bias, const float* Pp, float* HP, size_t hp_stride, int Dp,
-                                     uint32_t* ymask, float* Y, int* SP_out, int cus) {
+                                     uint32_t* ymask, float* Y, const ComposeLaunch& q) {
     OKR(cliora_ensure_max_lds((const void*)level_compose_fwd<CT, K16, F32>));
-    const ComposeGeom q = compose_geom(lv.ncell, lv.N, ncb, cus);
     hipLaunchKernelGGL((level_compose_fwd<CT, K16, F32>), dim3(q.gx, ncb), dim3(512), compose_lds_bytes(CT, S, true), st, Wimg, S, K, lv, PA, lda,
                        PB, ldb, bias, Pp, q.TG, q.SP, q.ntask, HP, hp_stride, Dp, ymask, Y);
     LAUNCHOK("level_compose_fwd");
-    *SP_out = q.SP;
     return CLIORA_OK;
 }
 
@@ -59,11 +38,11 @@ static int launch_level_compose_inst(hipStream_t st, const uint32_t* Wimg, int S
 // W: the plain fp32 weight (exact mode), Wimg: its split-bf16 image.
 static int launch_level_compose(hipStream_t st, const float* W, const float* Wimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
                                 const float* PA, int lda, const float* PB, int ldb, const float* bias, const float* Pp, float* HP,
-                                size_t hp_stride, uint32_t* ymask, float* Y, int* SP_out, int cus = 256) {
+                                size_t hp_stride, uint32_t* ymask, float* Y, const ComposeLaunch& q) {
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? W : Wimg);
     const int S = f32 ? Dp : S3;
-#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, SP_out, cus
+#define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, q
 #define LC_CASE(c, k16) return f32 ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
     if (ct == 5 && Dp == 400) LC_CASE(5, 25);
     switch (ct) {
@@ -155,6 +134,20 @@ static bool wavefront_pays(const Plan& p, int env) {
     if (env == 1) return true;
     const double row_floats_per_level = (double)(p.R_in + p.R_out) / (2.0 * (p.L - 1)) * p.Dp;
     return row_floats_per_level >= 100e3;
+}
+
+// The level loop as ONE persistent launch (persist_kernels.hpp) when the shape allows: text-only DioraMLP, every handed-over buffer
+// within the 32-bit offsets of a buffer descriptor, at least one CU per resident weight block.  cliora_set_persistent /
+// CLIORA_PERSISTENT=0|1 force it off / on (on is still refused for shapes the kernel does not cover).
+static bool persist_pays(const cliora_plan* plan, bool vl) {
+    const Plan& p = plan->p;
+    if (g_cliora_persistent == 0 || vl || p.arch != 0 || p.L < 2) return false;
+    const size_t lim = 0xfff00000ull;
+    const size_t BC = (size_t)p.B * p.C;
+    if (BC * p.nblk * p.Dp * 4 > lim || (size_t)HP_PARTS * BC * p.Dp * 4 > lim || (size_t)(p.R_in + p.R_out) * 4 > lim) return false;
+    const int nslots = p.fwd.ncb3 * (p.share ? 1 : 2);
+    if (plan->ncu < nslots || plan->ncu < 8) return false;
+    return true;
 }
 
 // ------------------------------------------------------------------ forward
@@ -318,17 +311,19 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside;
+    const bool persist = persist_pays(plan, vl);
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
     auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
-        int SP = 1;
+        const ComposeLaunch cq = compose_launch(p, level, false);
+        const int SP = cq.SP;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sa);
             OKR(launch_level_compose(sa, ws + f.w2i, ws + f.w2i3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), ws + f.pi, ldpi,
-                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, &SP));
+                                     ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, cq));
         }
         if (vl) {   // cliora.py:140-157: attention residual between the aggregate and the second unit norm, then the projections
             hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, sa, g, L, HPi, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
@@ -355,11 +350,12 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     auto outside_step = [&](int level) -> int {         // diora.py:358-398 for one level
         const LevelArgs g = level_args(p, level, true);
         const int ncell = B * g.Lc;
-        int SP = 1;
+        const ComposeLaunch cq = compose_launch(p, level, true);
+        const int SP = cq.SP;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sb);
             OKR(launch_level_compose(sb, ws + f.w2o, ws + f.w2o3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true),
-                                     ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HPo, hp_stride, YM, PH, &SP));
+                                     ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, ws + f.pp, HPo, hp_stride, YM, PH, cq));
         }
         if (level >= 1)      // the level below is scored in the same launch: its newest parents are this level's cells
             OKR(launch_level_project(sb, SP, ws + f.w1ro3, Dp, Dp, ncell, g.Lc, C, g.off, HPo, hp_stride, p.normalize, nullptr,
@@ -376,7 +372,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         // QR = M h of the leaves: the partner of a newest-level LEFT child is always a leaf (see level_project)
         OKR(launch_rows_direct(st, ws + f.matp, PROJ_IMG(f.matq3), Dp, Dp, B * L, LevelRowsA{IH, Dp, C, 0, L},
                                StoreRowsE{ws + f.qrleaf, Dp, nullptr, 0, Dp}));
-        OKR(launch_scores(st, score_args(1, false, -1, 0)));
+        if (!persist) OKR(launch_scores(st, score_args(1, false, -1, 0)));
     }
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_fork[0], st));
@@ -388,13 +384,42 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         LAUNCHOK("unit_norm_rows(root)");
         if (L > 1) {
             OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
-            OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
+            if (!persist) OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
         }
     } else {
         HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
     }
-    for (int k = 1; k <= L; ++k) {
+    if (persist) {
+        // ---- every level of both passes in one launch (persist_kernels.hpp): the first scores of both chains included ----
+        PersistFwd a{};
+        a.tabs = p.d_tables; a.lev = reinterpret_cast<const PLevel*>(p.d_tables + p.dev.persist_levels);
+        a.pa_in = (uint32_t)p.dev.pair_a_in; a.pb_in = (uint32_t)p.dev.pair_b_in;
+        a.pa_out = (uint32_t)p.dev.pair_a_out; a.pb_out = (uint32_t)p.dev.pair_b_out;
+        a.PI = ws + f.pi; a.PO = ws + f.po; a.HPi = HPi; a.HPo = HPo; a.Pp = ws + f.pp; a.Sp = ws + f.sp;
+        a.IH = IH; a.OH = OH; a.IS = IS; a.OS = OS; a.nrmi = ws + f.nrmi; a.nrmo = ws + f.nrmo;
+        a.ymask = YM; a.Y = PH; a.QRleaf = ws + f.qrleaf;
+        const bool f32 = !split_bf16();
+        a.Wimg[0] = reinterpret_cast<const uint32_t*>(f32 ? ws + f.w2i : ws + f.w2i3);
+        a.Wimg[1] = reinterpret_cast<const uint32_t*>(f32 ? ws + f.w2o : ws + f.w2o3);
+        a.b2[0] = ws + f.b2i; a.b2[1] = ws + f.b2o;
+        a.wcat_frag = ws + f.wcat3; a.bcat = ws + f.bcat; a.w1ro_frag = ws + f.w1ro3;
+        a.sync = reinterpret_cast<unsigned*>(ws + f.sync); a.status = plan->persist_status;
+        a.B = B; a.L = L; a.C = C; a.Dp = Dp; a.ldpi = ldpi; a.blk_plo = p.blk_plo; a.blk_qlo = p.blk_qlo; a.normalize = p.normalize;
+        a.share = p.share; a.S = f.S3; a.K = Dp; a.ncb = f.ncb3; a.run_outside = run_outside;
+        const size_t BC = (size_t)B * C;
+        a.hp_stride_bytes = (uint32_t)(hp_stride * sizeof(float));
+        a.bytes_PI = (uint32_t)(BC * ldpi * 4); a.bytes_PO = (uint32_t)(BC * Dp * 4); a.bytes_HP = (uint32_t)((size_t)HP_PARTS * BC * Dp * 4);
+        a.bytes_R = (uint32_t)((size_t)(p.R_in + p.R_out) * 4); a.bytes_H = (uint32_t)(BC * Dp * 4); a.bytes_S = (uint32_t)(BC * 4);
+        HIPOK(hipMemsetAsync(a.sync, 0, 256 * sizeof(unsigned), st));
+        HIPOK(hipStreamWaitEvent(st, plan->ev_persist, 0));           // never two spinning grids on one device
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+            OKR(cliora_launch_persist_fwd(st, a, f.ct3, plan->ncu));
+        }
+        HIPOK(hipEventRecord(plan->ev_persist, st));
+    }
+    for (int k = 1; k <= L && !persist; ++k) {
         if (k <= L - 1) {
             OKR(inside_step(k));
             if (two_streams) HIPOK(hipEventRecord(plan->ev_level[k], sa));

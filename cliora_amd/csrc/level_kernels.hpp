@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void level_project(const float* __restrict__ W
 }
 
 // levels whose cells need no projection (inside root, outside leaves): sum the partial aggregates, unit norm, chart row.
-__global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, int off, int Dp, const float* __restrict__ HP,
+static __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, int off, int Dp, const float* __restrict__ HP,
                                                     size_t hp_stride, int SP, int normalize, float* __restrict__ H,
                                                     float* __restrict__ nrm) {
     const int lane = threadIdx.x & 63;

@@ -8,6 +8,31 @@ static inline int ncells(int L) { return L * (L + 1) / 2; }
 
 static size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
 
+// Measured on MI355X (round 2, rocprof per-level traces): a round of tasks costs a ~5.8 us latency chain (index loads, ring
+// fill, epilogue, reduction) plus ~2.8 us of MFMA / VALU / LDS issue per tile on the busiest SIMD (waves w and w+4 share
+// one); rounds do not overlap.  Pick the cheapest geometry, fewer parts on a tie.
+ComposeGeom compose_geom(int ncell, int N, int cap) {
+    const int G = (ncell + 15) / 16;
+    ComposeGeom best{1, 1, G};
+    double best_t = 1e30;
+    for (int TG : {1, 2, 4, 8}) {
+        const int wpg = 8 / TG;
+        const int groups = (G + TG - 1) / TG;
+        for (int SP = 1; SP <= HP_PARTS && SP <= std::max(1, N); SP *= 2) {
+            const int np = (N + SP - 1) / SP;
+            const int ntask = groups * SP;
+            const int rounds = (ntask + cap - 1) / cap;
+            const int depth = (np + wpg - 1) / wpg;
+            const int busy = TG * std::min(wpg, np);
+            int simd = depth * (busy > 4 ? 2 : 1);
+            if (busy > 4 && wpg == 8 && np % 8 != 0 && np % 8 <= 4) simd -= 1;     // the last sweep reaches one wave of each pair only
+            const double t = rounds * (5.8 + 2.8 * simd) + 0.3 * (SP - 1);
+            if (t < best_t - 1e-9) { best_t = t; best = ComposeGeom{TG, SP, ntask}; }
+        }
+    }
+    return best;
+}
+
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch) {
     if (B < 1 || L < 1 || D < 1) return "B, L, D must be positive";
     if (D > 512) return "D > 512 is not supported by the weight-stationary kernels";
@@ -155,6 +180,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.att_u = take(R > 0 ? BC * Dp : 0);
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
+        f.sync = take(256);
         f.total = o;
         // per-pair compose outputs for the hooks: the TreeLSTM keeps them anyway (y rows), DioraMLP writes them into an
         // optional tail of the workspace only when a hook is overridden
@@ -205,6 +231,21 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         v.slab = take(v.slab_floats);
         v.total = o;
     }
+    // ---- per-level shapes and compose geometry (the launch-per-level path and the persistent kernels use the same) ----
+    // sized for one workgroup per CU of a 256-CU part, the column blocks of a task on one XCD: ((256 / 8) / ncb) * 8 per block
+    p.compose_cap = std::max(1, (32 / std::max(1, p.fwd.ncb3))) * 8;
+    if (p.fwd.ncb3 > 32) p.compose_cap = std::max(1, 256 / p.fwd.ncb3);
+    p.persist_levels.assign((size_t)2 * L * PLEVEL_INTS, 0);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int lv = 0; lv < L; ++lv) {
+            int32_t* e = p.persist_levels.data() + ((size_t)pass * L + lv) * PLEVEL_INTS;
+            const int Lc = L - lv, N = pass ? L - lv - 1 : lv;
+            e[0] = Lc; e[1] = N; e[2] = p.level_offset[lv];
+            e[3] = (int32_t)(pass ? p.row_base_out(lv) : p.row_base_in(lv));
+            e[4] = pass ? p.lvl_base_out[lv] : p.lvl_base_in[lv];
+            const ComposeGeom q = compose_geom(B * Lc, N, p.compose_cap);
+            e[5] = q.TG; e[6] = q.SP; e[7] = q.ntask;
+        }
     return "";
 }
 
@@ -256,6 +297,7 @@ std::vector<int32_t> flatten_tables(Plan& p) {
     }
     p.dev.lvl_base_in = put(p.lvl_base_in);
     p.dev.lvl_base_out = put(p.lvl_base_out);
+    p.dev.persist_levels = put(p.persist_levels);
     if (p.arch == 1) build_row_maps(p);
     p.dev.arow = put(p.arow); p.dev.brow = put(p.brow); p.dev.trow = put(p.trow);
     if (flat.empty()) flat.push_back(0);
@@ -270,6 +312,7 @@ const std::vector<int32_t>* find_table(Plan& p, const std::string& name) {
     if (name == "pair_b_out") return &p.pair_b_out;
     if (name == "pair_lvl_base_in") return &p.lvl_base_in;
     if (name == "pair_lvl_base_out") return &p.lvl_base_out;
+    if (name == "persist_levels") return &p.persist_levels;
     if (name == "arow" || name == "brow" || name == "trow") build_row_maps(p);
     if (name == "arow") return &p.arow;
     if (name == "brow") return &p.brow;

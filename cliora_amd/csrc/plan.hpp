@@ -19,8 +19,9 @@ constexpr int ROLE_INB = 1;   // inside cell used as RIGHT child in the inside p
 constexpr int ROLE_OUTA = 2;  // inside cell used as SIBLING in the outside pass
 constexpr int ROLE_OUTB = 3;  // outside cell used as PARENT in the outside pass
 constexpr int N_ROLES = 4;
-constexpr int HP_PARTS = 4;
-constexpr int CLIORA_MAX_L = 64;   // sentence length bound: one split per lane in the score kernels   // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
+constexpr int HP_PARTS = 4;        // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
+constexpr int CLIORA_MAX_L = 64;   // sentence length bound: one split per lane in the score kernels
+constexpr int PLEVEL_INTS = 8;     // ints per entry of Plan::persist_levels (struct PLevel of persist_kernels.hpp)
 
 struct UseList {
     std::vector<int32_t> off;      // C+1, CSR offsets per cell
@@ -56,6 +57,7 @@ struct FwdLayout {
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
     size_t icp, ocp, nrmic, nrmoc, rootc;   // TreeLSTM: cell-state charts (B*C x Dp), their norms, padded root c
     size_t att_u, att_pk, att_nrmu;     // CLIORA per inside cell: u = unit(aggregate) (B*C x Dp), region probabilities (B*C x 64), |aggregate| (B*C)
+    size_t sync;                        // 256 words: the barrier counters of the persistent level-loop kernels (zeroed by every call)
     size_t total;
 };
 
@@ -94,6 +96,10 @@ struct Plan {
     // per global pair row (inside rows first, then outside rows): chart row (b*C + cell) of the
     // a-operand cell, the b-operand cell and the target cell
     std::vector<int32_t> arow, brow, trow;
+    // per (pass, level): {Lc, N, chart offset, first pair row, offset into the pass's pair tables, TG, SP, ntask} -- the level's
+    // shape and the task geometry of its compose kernel (compose_geom), inside levels first; 2 * L entries of PLEVEL_INTS ints
+    std::vector<int32_t> persist_levels;
+    int compose_cap;          // compose workgroups per column block that geometry is sized for
     FwdLayout fwd;
     BwdLayout bwd;
     // span-region scorer workspace (floats): padded/transposed region matrices, padded sum rows, slabs
@@ -102,7 +108,7 @@ struct Plan {
     // device copies (filled lazily by the HIP side)
     int32_t* d_tables = nullptr;
     size_t d_tables_count = 0;
-    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out; } dev;
+    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out, persist_levels; } dev;
 
     int Lc(int level) const { return L - level; }
     int Nin(int level) const { return level; }
@@ -110,6 +116,11 @@ struct Plan {
     long long row_base_in(int level) const { return (long long)B * lvl_base_in[level]; }
     long long row_base_out(int level) const { return R_in + (long long)B * lvl_base_out[level]; }
 };
+
+// Tasks of level_compose_fwd for a level of `ncell` target cells with N splits each: TG cell tiles per workgroup (8 / TG waves
+// each), the split range cut in SP parts, ntask = ceil(G / TG) * SP workgroup tasks; `cap` workgroups per column block.
+struct ComposeGeom { int TG, SP, ntask; };
+ComposeGeom compose_geom(int ncell, int N, int cap);
 
 // Builds every host table and the workspace layouts.  Returns "" or an error message.
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch = 0);

@@ -254,6 +254,27 @@ int cliora_set_mfma_mode(int mode);
 #define CLIORA_WAVEFRONT_ON 1
 int cliora_set_wavefront(int mode);
 
+/* The level loop as one launch.  By default (CLIORA_PERSISTENT_AUTO; the environment variable CLIORA_PERSISTENT=0|1 sets the
+ * initial value) the forward of a text-only DioraMLP plan runs every level of both passes (cliora/net/diora.py:312-331, 378-398)
+ * inside ONE persistent kernel -- one workgroup per CU that keeps its block of the compose weight in LDS across all levels,
+ * with the level boundaries as grid-wide counter barriers (csrc/persist_kernels.hpp) -- instead of two launches per level.
+ * OFF runs the launch-per-level path.  Results are bitwise identical either way.  Such a kernel owns the device while it
+ * runs: the library chains these launches device-wide; cliora_persistent_status reports (after synchronising `stream`) how
+ * many barrier waits ever gave up (another process held CUs for seconds), 0 in normal operation.  Process-wide; returns the
+ * previous mode. */
+#define CLIORA_PERSISTENT_AUTO (-1)
+#define CLIORA_PERSISTENT_OFF 0
+#define CLIORA_PERSISTENT_ON 1
+int cliora_set_persistent(int mode);
+int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
+
+/* Float offset of a named region of the forward workspace ("pi", "po", "hp", "hp_o", "sp", "pp", "ymask", "nrmi", "nrmo", "t",
+ * "qrleaf", "sync", "total"), for tests and tooling that compare two runs region by region; (size_t)-1 for an unknown name. */
+size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* name);
+
+/* Bytes of device index tables the plan uploads at its first use. */
+size_t cliora_plan_device_bytes(const cliora_plan* plan);
+
 const char* cliora_version(void);
 
 #ifdef __cplusplus
