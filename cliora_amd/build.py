@@ -17,6 +17,9 @@ LIB = os.path.join(HERE, 'libcliora_chart.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-pass-failed', '-Wno-unused-value']
 
 
+FLAGS += os.environ.get('CLIORA_BUILD_EXTRA', '').split()      # diagnostic builds (e.g. -DCLIORA_PERSIST_STAMPS); use with --force
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
 

@@ -63,6 +63,7 @@ int cliora_ensure_max_lds(const void* fn);
 // uploads the plan's index tables on first use (current device) and checks that later calls run on that device
 int cliora_plan_ready(cliora_plan* plan, hipStream_t st);
 
+constexpr size_t PERSIST_TRACE_BYTES = (size_t)256 * 4 * (CLIORA_MAX_L + 1) * 10 * 8;   // [workgroup][phase][2] stamps behind the status words
 // persistent level-loop kernels (api_persist.hip)
 namespace cliora { struct PersistFwd; }
 int cliora_launch_persist_fwd(hipStream_t st, const cliora::PersistFwd& a, int ct, int nwg);

@@ -202,8 +202,8 @@ static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
         for (int k = 0; k <= CLIORA_MAX_L; ++k) HIPOK(hipEventCreateWithFlags(&ln->level[k], hipEventDisableTiming));
         HIPOK(hipEventCreateWithFlags(&ln->persist, hipEventDisableTiming));
         HIPOK(hipEventRecord(ln->persist, st));
-        HIPOK(hipMalloc((void**)&ln->status, 64));
-        HIPOK(hipMemsetAsync(ln->status, 0, 64, st));
+        HIPOK(hipMalloc((void**)&ln->status, 64 + PERSIST_TRACE_BYTES));
+        HIPOK(hipMemsetAsync(ln->status, 0, 64 + PERSIST_TRACE_BYTES, st));
         HIPOK(hipDeviceGetAttribute(&ln->ncu, hipDeviceAttributeMultiprocessorCount, dev));
         g_lanes[dev] = ln;
     }
@@ -343,6 +343,17 @@ extern "C" int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, v
     if (!plan || !timeouts) return fail(CLIORA_EINVAL, "NULL argument");
     if (!plan->uploaded) { *timeouts = 0; return CLIORA_OK; }
     HIPOK(hipMemcpyAsync(timeouts, plan->persist_status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPOK(hipStreamSynchronize((hipStream_t)stream));
+    return CLIORA_OK;
+}
+
+// diagnostics: wall-clock stamps (100 MHz) of the last persistent launch traced with CLIORA_PERSIST_TRACE=1:
+// out[workgroup][phase 4*k + sub][2] = {after the wait, after the work}, `count` 64-bit words
+extern "C" int cliora_persistent_trace(cliora_plan* plan, unsigned long long* out, size_t count, void* stream) {
+    if (!plan || !out) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "no forward has run on this plan");
+    if (count * 8 > PERSIST_TRACE_BYTES) return fail(CLIORA_EINVAL, "trace buffer holds fewer words");
+    HIPOK(hipMemcpyAsync(out, plan->persist_status + 16, count * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPOK(hipStreamSynchronize((hipStream_t)stream));
     return CLIORA_OK;
 }

@@ -137,16 +137,23 @@ static bool wavefront_pays(const Plan& p, int env) {
 }
 
 // The level loop as ONE persistent launch (persist_kernels.hpp) when the shape allows: text-only DioraMLP, every handed-over buffer
-// within the 32-bit offsets of a buffer descriptor, at least one CU per resident weight block.  cliora_set_persistent /
-// CLIORA_PERSISTENT=0|1 force it off / on (on is still refused for shapes the kernel does not cover).
+// within the 32-bit offsets of a buffer descriptor, at least one CU per resident weight block.  Measured on MI355X
+// (tools/persist_ab.py, profiles/r03_persist_ab.txt): the one launch wins where the levels are launch-bound (D <= 64: forward
+// 0.240 -> 0.201 ms at B 8 / L 10, 0.384 -> 0.345 at B 16 / L 16) and loses at D = 400 (1.10 -> 1.22 ms at B 64 / L 20): a
+// persistent workgroup is 8 waves per CU, and the projection / score phases are latency chains that the launch-per-level
+// kernels hide with 32 waves per CU.  AUTO therefore takes it for Dp <= 64; cliora_set_persistent / CLIORA_PERSISTENT=0|1 force
+// it off / on (on is still refused for shapes the kernel does not cover).
 static bool persist_pays(const cliora_plan* plan, bool vl) {
     const Plan& p = plan->p;
     if (g_cliora_persistent == 0 || vl || p.arch != 0 || p.L < 2) return false;
+    if (g_cliora_persistent < 0 && p.Dp > 64) return false;
     const size_t lim = 0xfff00000ull;
     const size_t BC = (size_t)p.B * p.C;
     if (BC * p.nblk * p.Dp * 4 > lim || (size_t)HP_PARTS * BC * p.Dp * 4 > lim || (size_t)(p.R_in + p.R_out) * 4 > lim) return false;
     const int nslots = p.fwd.ncb3 * (p.share ? 1 : 2);
-    if (plan->ncu < nslots || plan->ncu < 8) return false;
+    if (plan->ncu < nslots || plan->ncu < 8 || p.L > PK_MAX_L) return false;
+    const size_t image = (size_t)p.fwd.ct3 * 16 * (split_bf16() ? p.fwd.S3 : p.Dp) * sizeof(uint32_t);
+    if (image + PK_LDS_EXTRA > 160 * 1024) return false;
     return true;
 }
 
@@ -405,13 +412,15 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         a.b2[0] = ws + f.b2i; a.b2[1] = ws + f.b2o;
         a.wcat_frag = ws + f.wcat3; a.bcat = ws + f.bcat; a.w1ro_frag = ws + f.w1ro3;
         a.sync = reinterpret_cast<unsigned*>(ws + f.sync); a.status = plan->persist_status;
+        static const bool trace_env = [] { const char* e = getenv("CLIORA_PERSIST_TRACE"); return e && atoi(e) != 0; }();
+        a.trace = (trace_env && plan->ncu <= 256) ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
         a.B = B; a.L = L; a.C = C; a.Dp = Dp; a.ldpi = ldpi; a.blk_plo = p.blk_plo; a.blk_qlo = p.blk_qlo; a.normalize = p.normalize;
         a.share = p.share; a.S = f.S3; a.K = Dp; a.ncb = f.ncb3; a.run_outside = run_outside;
         const size_t BC = (size_t)B * C;
         a.hp_stride_bytes = (uint32_t)(hp_stride * sizeof(float));
         a.bytes_PI = (uint32_t)(BC * ldpi * 4); a.bytes_PO = (uint32_t)(BC * Dp * 4); a.bytes_HP = (uint32_t)((size_t)HP_PARTS * BC * Dp * 4);
         a.bytes_R = (uint32_t)((size_t)(p.R_in + p.R_out) * 4); a.bytes_H = (uint32_t)(BC * Dp * 4); a.bytes_S = (uint32_t)(BC * 4);
-        HIPOK(hipMemsetAsync(a.sync, 0, 256 * sizeof(unsigned), st));
+        HIPOK(hipMemsetAsync(a.sync, 0, PK_SYNC_WORDS * sizeof(unsigned), st));
         HIPOK(hipStreamWaitEvent(st, plan->ev_persist, 0));           // never two spinning grids on one device
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);

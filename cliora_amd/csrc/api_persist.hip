@@ -16,7 +16,8 @@ static int launch_persist_fwd_inst(hipStream_t st, const PersistFwd& a, int nwg,
 int cliora_launch_persist_fwd(hipStream_t st, const PersistFwd& a, int ct, int nwg) {
     const bool f32 = !split_bf16();
     const int S = f32 ? a.Dp : a.S;
-    const size_t lds = (size_t)ct * 16 * S * sizeof(uint32_t) + (size_t)LC_SLOTS * ct * 64 * sizeof(float4) + 16;
+    const size_t lds = (size_t)ct * 16 * S * sizeof(uint32_t) + PK_LDS_EXTRA;
+    if (lds > 160 * 1024) return fail(CLIORA_EINVAL, "persistent kernel: weight block + scratch exceed LDS");
     PersistFwd b = a;
     b.S = S; b.K = a.Dp;
 #define PF_CASE(c, k16) return f32 ? launch_persist_fwd_inst<c, k16, true>(st, b, nwg, lds) : launch_persist_fwd_inst<c, k16, false>(st, b, nwg, lds)

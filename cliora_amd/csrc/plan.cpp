@@ -180,7 +180,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.att_u = take(R > 0 ? BC * Dp : 0);
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
-        f.sync = take(256);
+        f.sync = take(1280);
         f.total = o;
         // per-pair compose outputs for the hooks: the TreeLSTM keeps them anyway (y rows), DioraMLP writes them into an
         // optional tail of the workspace only when a hook is overridden
@@ -236,6 +236,9 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
     p.compose_cap = std::max(1, (32 / std::max(1, p.fwd.ncb3))) * 8;
     if (p.fwd.ncb3 > 32) p.compose_cap = std::max(1, 256 / p.fwd.ncb3);
     p.persist_levels.assign((size_t)2 * L * PLEVEL_INTS, 0);
+    // Step k of the forward composes inside level k and outside level L-k side by side (in the persistent
+    // kernel as ONE task list): each level's geometry is sized for its share of the compose workgroups, by pair rows
+    // (shared weights), or for the half that holds its weight image (unshared).
     for (int pass = 0; pass < 2; ++pass)
         for (int lv = 0; lv < L; ++lv) {
             int32_t* e = p.persist_levels.data() + ((size_t)pass * L + lv) * PLEVEL_INTS;
@@ -243,7 +246,18 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
             e[0] = Lc; e[1] = N; e[2] = p.level_offset[lv];
             e[3] = (int32_t)(pass ? p.row_base_out(lv) : p.row_base_in(lv));
             e[4] = pass ? p.lvl_base_out[lv] : p.lvl_base_in[lv];
-            const ComposeGeom q = compose_geom(B * Lc, N, p.compose_cap);
+            const int k = pass ? L - lv : lv;                      // the step this level runs in
+            const bool has_in = k >= 1 && k <= L - 1, has_out = k >= 2 && k <= L;
+            int cap = p.compose_cap;
+            if (has_in && has_out && cap >= 2) {
+                if (!p.share) cap = cap / 2;
+                else {
+                    const double rows_in = (double)(L - k) * k, rows_out = (double)k * (k - 1);
+                    const int cap_in = std::min(cap - 1, std::max(1, (int)(cap * rows_in / (rows_in + rows_out) + 0.5)));
+                    cap = pass ? cap - cap_in : cap_in;
+                }
+            }
+            const ComposeGeom q = compose_geom(B * Lc, N, cap);
             e[5] = q.TG; e[6] = q.SP; e[7] = q.ntask;
         }
     return "";

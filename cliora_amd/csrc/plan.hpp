@@ -57,7 +57,7 @@ struct FwdLayout {
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
     size_t icp, ocp, nrmic, nrmoc, rootc;   // TreeLSTM: cell-state charts (B*C x Dp), their norms, padded root c
     size_t att_u, att_pk, att_nrmu;     // CLIORA per inside cell: u = unit(aggregate) (B*C x Dp), region probabilities (B*C x 64), |aggregate| (B*C)
-    size_t sync;                        // 256 words: the barrier counters of the persistent level-loop kernels (zeroed by every call)
+    size_t sync;                        // 1280 words (PK_SYNC_WORDS): the barrier words of the persistent level-loop kernels (zeroed by every call)
     size_t total;
 };
 
