@@ -425,7 +425,10 @@ def main():
                                    '(BASELINE configs[1]); chart forward + hand-written backward; random N(0,1) weights'
                                    % (D, B, L),
                        'global_batch': world * B, 'length': L, 'dim': D, 'mfma': mfma_mode,
-                       'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU'},
+                       'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU',
+                       **({'gradient_exchange': 'RCCL all-reduce (backend %s) of one flat fp32 buffer of %d floats per step; %d of %d gradients copied in '
+                                                '(the chart backward writes the rest in place)'
+                                                % (args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
             'step_ms': dict(median=round(pct(step_ms, 0.5), 4), p10=round(pct(step_ms, 0.1), 4), p90=round(pct(step_ms, 0.9), 4),
                             note='per-step device time from HIP event pairs on the launch stream inside the timed region (rank 0)'),
             'roofline': roof,

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .diora import DioraBase, ComposeMLP, Bilinear, Chart, _ptr, _stream, _param_struct
+from .diora import DioraBase, ComposeMLP, Bilinear, Chart, _ptr, _stream, _param_struct, _grad_out
 from .index import Index
 
 DROPOUT_P = 0.1   # AttentionHead: nn.Dropout(0.1), cliora.py:32
@@ -63,7 +63,7 @@ class VLChartFunction(torch.autograd.Function):
         dev = x_span.device
         cont = lambda g: g.contiguous().float() if g is not None else None
         d_ih, d_is, d_oh, d_os = cont(d_ih), cont(d_is), cont(d_oh), cont(d_os)
-        grads = {n: (torch.empty_like(t) if t is not None else None) for n, t in ctx.ptens.items()}
+        grads = {n: (_grad_out(t) if t is not None else None) for n, t in ctx.ptens.items()}
         d_x = torch.empty_like(x_span)
         d_obj = torch.empty_like(obj_span)
         wsb = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)

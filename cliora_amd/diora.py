@@ -33,6 +33,14 @@ def _param_struct(tensors):
     return st
 
 
+def _grad_out(t):
+    """Output tensor for the gradient of the parameter that `t` (its detached view) belongs to: the parameter's slice of a live
+    flat all-reduce buffer (cliora_amd.parallel: the backward then writes straight into what RCCL reduces), else a fresh tensor."""
+    from .parallel import grad_buffer_for
+    v = grad_buffer_for(t)
+    return v if v is not None else torch.empty_like(t)
+
+
 class ChartFunction(torch.autograd.Function):
     """One autograd node for the whole inside-outside chart.
 
@@ -80,7 +88,7 @@ class ChartFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             d_x = torch.empty_like(x_span)
             pst = _param_struct(ctx.ptens)
-            g = {n: (torch.empty_like(t) if t is not None else None) for n, t in ctx.ptens.items()}
+            g = {n: (_grad_out(t) if t is not None else None) for n, t in ctx.ptens.items()}
             wsb = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)
             gst = _param_struct(g)
             rc = _lib.lib().cliora_chart_backward(

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .diora import DioraBase, Bilinear, Chart, _ptr, _stream, _param_struct
+from .diora import DioraBase, Bilinear, Chart, _ptr, _stream, _param_struct, _grad_out
 from .index import Index
 
 
@@ -66,7 +66,7 @@ class LSTMChartFunction(torch.autograd.Function):
         x_span, ih, ic, is_, oh, oc, os_ = ctx.saved_tensors
         dev = x_span.device
         cots = [g.contiguous().float() if g is not None else None for g in cots]
-        grads = {n: torch.empty_like(t) for n, t in ctx.ptens.items()}
+        grads = {n: _grad_out(t) for n, t in ctx.ptens.items()}
         d_x = torch.empty_like(x_span)
         wsb = torch.empty(plan.bwd_bytes, device=dev, dtype=torch.uint8)
         pst, gst = _param_struct(ctx.ptens), _param_struct(grads)

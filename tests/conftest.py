@@ -68,7 +68,7 @@ def grad_tol(mode, strict):
     return strict if mode == 'f32' else max(strict, 5e-4)
 
 
-def grad_check(t, ref, mode, strict, what=''):
+def grad_check(t, ref, mode, strict, what='', full_size=False):
     """Gradient parity.
 
     Exact-product mode ('f32'): every element within `strict` of the tensor's scale.
@@ -81,7 +81,11 @@ def grad_check(t, ref, mode, strict, what=''):
     against fp64, at a lower rate: tests/test_gpu_configs.py::test_c2_full_size_gradients_vs_fp64 measures both).  So the check is
     statistical: median error within grad_tol(), 99 % of the elements within 1e-2 of scale, every element within 5e-2
     (measured at full size: 2e-3 and 7e-3; the small widths of the other tests sit higher, 3.7e-2 at D = 48).  A wrong kernel (a dropped
-    k-step, a transposed tile) moves the median by orders of magnitude and fails the first bound."""
+    k-step, a transposed tile) moves the median by orders of magnitude and fails the first bound.
+
+    full_size=True (the d = 400 configurations at their own size): the bounds are what profiles/r02_accuracy_fp64_bf16x3.json shows
+    there with a margin of two -- median 2e-4 (measured <= 1.3e-4), 99th percentile 4e-3 (<= 2e-3), maximum 2e-2 (<= 7.3e-3, set by
+    ReLU kinks that the fp32 reference shows against fp64 as well)."""
     import torch
     a = (t.detach().double().cpu() if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t)).double()).flatten()
     b = (ref.detach().double().cpu() if isinstance(ref, torch.Tensor) else torch.as_tensor(np.asarray(ref)).double()).flatten()
@@ -92,7 +96,8 @@ def grad_check(t, ref, mode, strict, what=''):
         return
     sub = d[:: max(1, d.numel() // 200000)]
     med, q99 = float(sub.median()), float(torch.quantile(sub, 0.99))
-    assert med <= grad_tol(mode, strict) * scale, '%s: median err %.3e scale %.3e' % (what, med, scale)
+    tol_med, tol_q99, tol_max = (2e-4, 4e-3, 2e-2) if full_size else (grad_tol(mode, strict), 1e-2, 5e-2)
+    assert med <= tol_med * scale, '%s: median err %.3e scale %.3e' % (what, med, scale)
     if d.numel() >= 1000:          # on a 48-element bias the 99th percentile IS the maximum: the last bound covers it
-        assert q99 <= 1e-2 * scale, '%s: q99 err %.3e scale %.3e' % (what, q99, scale)
-    assert float(d.max()) <= 5e-2 * scale, '%s: max err %.3e scale %.3e' % (what, float(d.max()), scale)
+        assert q99 <= tol_q99 * scale, '%s: q99 err %.3e scale %.3e' % (what, q99, scale)
+    assert float(d.max()) <= tol_max * scale, '%s: max err %.3e scale %.3e' % (what, float(d.max()), scale)

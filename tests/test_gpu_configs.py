@@ -36,7 +36,7 @@ def _grad_full(t, ref, mode, what):
     """Full-size gradient check: exact-fp32 mode element-wise at the 99th percentile (2e-4 of scale) with the kink allowance of
     test_gpu_parity._grad_ok at the maximum; split-bf16 mode the statistical check of conftest.grad_check."""
     if mode != 'f32':
-        return grad_check(t, ref, mode, 2e-4, what)
+        return grad_check(t, ref, mode, 2e-4, what, full_size=True)
     d = (t.detach().cpu().double() - ref.detach().double()).abs().flatten()
     sc = _scale(ref)
     assert float(torch.quantile(d[:: max(1, d.numel() // 200000)], 0.99)) <= 2e-4 * sc, what
@@ -137,6 +137,123 @@ def test_c3_cliora_full_size(mfma_mode):
     with torch.no_grad():
         net(sentences.cuda(), obj.cuda(), neg.cuda())
     assert [str(t) for t in diora.cky()] == [str(t) for t in R.cky_trees(ref['pair_s_in'], B, L)]
+
+
+def test_c3_cliora_full_size_training_mode(mfma_mode):
+    """BASELINE configs[2] as the bench runs it: train() -- a recorded (B, C, R) dropout mask on the attention probabilities
+    (cliora.py:35-42) and the lazy region-max scorer behind ContrastiveLoss (trainer.py:101) -- against the oracle on the same
+    batch with the mask replayed."""
+    from cliora_amd import harness as H
+    from oracle import diora_ref as R
+    B, L, D, Rg, V, E, K = 64, 20, 400, 36, 2000, 64, 20
+    C = L * (L + 1) // 2
+    torch.manual_seed(31)
+    net = H.build_net(D, torch.nn.Embedding(V, E), obj_feats=True, img_dim=2048, k_neg=K, vg_loss=True, use_contr=True,
+                      vl_margin=0.2, alpha_contr=1.0, alpha_vg=1.0)
+    for p in net.img_encoder.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    g = torch.Generator().manual_seed(32)
+    sentences = torch.randint(0, V, (B, L), generator=g)
+    neg = torch.randperm(V, generator=g)[:K]
+    obj = torch.relu(torch.randn(B, Rg, 2048, generator=g))
+    mask = torch.nn.functional.dropout(torch.ones(B, C, Rg), 0.1, True)          # pre-scaled keep mask, chart order (leaves first)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().train()
+    net.diora.dropout_mask = mask.cuda()
+    assert net.diora.lazy_region_scores                                       # the fused region-max path is the one under test
+    out = net(sentences.cuda(), obj.cuda(), neg.cuda())
+    out['total_loss'].mean(0).sum().backward()
+    torch.cuda.synchronize()
+    diora = net.diora
+
+    P = {k[len('diora.'):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith('diora.')}
+    emb_w = sd['embed.embeddings.weight'].clone().requires_grad_(True)
+    mat, mat1 = sd['embed.mat'].clone().requires_grad_(True), sd['embed.mat1'].clone().requires_grad_(True)
+    iw = {k: sd['img_encoder.' + k].clone().requires_grad_(True) for k in ('fc.weight', 'fc.bias', 'fc_vis.weight', 'fc_vis.bias')}
+    rmat = sd['reconstruct_softmax_loss.mat'].clone().requires_grad_(True)
+    xs, xw = R.embed_forward(emb_w, mat, mat1, sentences)
+    os_, ow = R.image_encoder_forward(iw['fc.weight'], iw['fc.bias'], iw['fc_vis.weight'], iw['fc_vis.bias'], obj)
+    off = [C - (L - lv) * (L - lv + 1) // 2 for lv in range(L)] + [C]
+    calls = {'i': 0}
+    orig = R.F.dropout
+
+    def replay(x, p, training):            # one call per level, leaves first: the level's slice of the recorded mask
+        i = calls['i']
+        calls['i'] += 1
+        return x * mask[:, off[i]:off[i + 1]]
+    R.F.dropout = replay
+    try:
+        ref = R.diora_forward(P, xs, xw, os_, ow, training=True)
+    finally:
+        R.F.dropout = orig
+    assert calls['i'] == L
+    l_rec = R.reconstruction_loss(emb_w, rmat, sentences, neg, ref['outside_h'])
+    l_vg = R.vg_loss(ref['vg_atten_score'], 1.0)
+    l_con = R.contrastive_loss(ref['inside_s'], ref['outside_s'], ref['all_atten_score'], 0.2, 1.0)
+    (l_rec + l_vg + l_con).backward()
+
+    for k in ('inside_h', 'inside_s', 'outside_h', 'outside_s', 'inside_c', 'vg_atten_score', 'atten_score'):
+        assert _err(getattr(diora, k), ref[k]) <= 1e-4 * _scale(ref[k]), k
+    smax = diora.all_atten_score.max(-1).values                                 # the region maxima, without the dense tensor
+    assert _err(smax, ref['all_atten_score'].max(-1).values) <= 1e-4 * _scale(ref['all_atten_score'])
+    for name, want in (('reconstruct_softmax_loss', l_rec), ('vg_loss', l_vg), ('contrastive_loss', l_con)):
+        got = float(out[name].sum())
+        assert abs(got - float(want)) <= 1e-4 * max(1.0, abs(float(want))), (name, got, float(want))
+    named = dict(net.named_parameters())
+    for k, p in P.items():
+        if p.grad is not None:
+            _grad_full(named['diora.' + k].grad, p.grad, mfma_mode, k)
+    for k, p in iw.items():
+        _grad_full(named['img_encoder.' + k].grad, p.grad, mfma_mode, k)
+    _grad_full(named['embed.mat'].grad, mat.grad, mfma_mode, 'embed.mat')
+    _grad_full(named['embed.mat1'].grad, mat1.grad, mfma_mode, 'embed.mat1')
+
+
+def test_c5_treelstm_mixed_length_stream():
+    """BASELINE configs[4] names mixed-length batches: TreeLSTM batches of L = 10, 40, 17, 40, 10 back to back through the plan cache
+    (a different plan, workspace and launch geometry per length; the second visit of a length re-uses its cached plan), each checked
+    against the CPU oracle on its own batch.  [TreeLSTM parity is unpinned: treelstm.py]"""
+    from cliora_amd import _lib
+    from cliora_amd.treelstm import DioraTreeLSTM
+    from oracle import diora_ref as R
+    D, B = 400, 2
+    keys = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+    P = R.init_params_treelstm(D, seed=17)
+    m = DioraTreeLSTM(D)
+    sd = m.state_dict()
+    for k in sd:
+        sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].detach().clone()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    gen = torch.Generator().manual_seed(18)
+    plans_before = len(_lib._plans)
+    seen = {}
+    for step, L in enumerate((10, 40, 17, 40, 10)):
+        x = torch.randn(B, L, D, generator=gen)
+        C = L * (L + 1) // 2
+        cot = {k: torch.randn(B, C, 1 if k.endswith('_s') else D, generator=gen) for k in keys}
+        for p_ in m.parameters():
+            p_.grad = None
+        xg = x.clone().cuda().requires_grad_(True)
+        m(xg, xg)
+        torch.autograd.backward([getattr(m, k) for k in keys], [cot[k].cuda() for k in keys])
+        torch.cuda.synchronize()
+        Pc = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+        xc = x.clone().requires_grad_(True)
+        ref = R.diora_forward(Pc, xc, xc, arch='treelstm')
+        sum((ref[k] * cot[k]).sum() for k in keys).backward()
+        for k in keys:
+            assert _err(getattr(m, k), ref[k]) <= 1e-4 * _scale(ref[k]), (step, L, k)
+        named = dict(m.named_parameters())
+        for k, p in Pc.items():
+            d = (named[k].grad.detach().cpu().double() - p.grad.double()).abs().flatten()
+            sc = _scale(p.grad)
+            assert float(torch.quantile(d[:: max(1, d.numel() // 200000)], 0.99)) <= 2e-4 * sc, (step, L, k)
+            assert float(d.max()) <= 2e-2 * sc, (step, L, k, float(d.max()), sc)
+        d = (xg.grad.cpu().double() - xc.grad.double()).abs()
+        assert float(d.max()) <= 2e-2 * _scale(xc.grad), (step, L)
+        seen[L] = seen.get(L, 0) + 1
+    assert len(_lib._plans) - plans_before <= 3            # one plan per distinct length: the repeats hit the cache
 
 
 def _dist(a, ref64):

@@ -3,8 +3,9 @@ captured from the reference and against the CPU oracle on the same seeded inputs
 
 Tolerance: outputs within 1e-4 absolute in fp32 (BASELINE.json north_star) in BOTH arithmetic modes of the
 compose GEMMs; gradients within 2e-4 of the tensor's largest reference magnitude with exact fp32 products
-(mode 'f32'), and the statistical check of conftest.grad_check in the default split-bf16 mode (median 1e-3, 99 % of
-the elements 2e-2, every element 1e-1 of scale).  The parity tests run under both.
+(mode 'f32'), and the statistical check of conftest.grad_check in the default split-bf16 mode (median 5e-4, 99 % of
+the elements 1e-2, every element 5e-2 of scale; at the d = 400 sizes median 2e-4, 99 % 4e-3, every element 2e-2: what
+profiles/r02_accuracy_fp64_bf16x3.json measures there, with a margin of two).  The parity tests run under both.
 """
 import numpy as np
 import pytest
@@ -55,7 +56,7 @@ def _grad_ok(t, ref, what='', mode='f32'):
     element within 100x that.
     """
     if mode != 'f32':
-        return grad_check(t, ref, mode, GRAD_TOL, what)     # split-bf16: the statistical check of conftest.grad_check
+        return grad_check(t, ref, mode, GRAD_TOL, what, full_size=ref.shape[-1] >= 256)     # split-bf16: the statistical check of conftest.grad_check (d = 400 bounds for wide tensors)
     a = t.detach().double().cpu().flatten()
     b = ref.detach().double().cpu().flatten()
     d = (a - b).abs()

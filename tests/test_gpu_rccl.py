@@ -1,0 +1,29 @@
+"""First execution of the N > 1 path on a GPU: RCCL process-group initialisation and the flat gradient all-reduce
+(cliora_amd/parallel.py; the reference's DDP over NCCL, cliora/net/trainer.py:528-532, 572-574), at world size 1.
+
+`bench.py --force-dist` initialises the process group with backend nccl (= RCCL on ROCm) and runs FlatGradAllReduce on the GPU
+gradients every step even with one rank.  It runs as a CHILD process: the group's state stays out of the test session."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_force_dist_runs_rccl_at_world_size_one():
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '3', '--warmup', '1', '--no-extras',
+           '--no-cpu-baseline', '--no-kernel-events']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert lines, r.stdout[-2000:]
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0
+    ge = d['config'].get('gradient_exchange', '')
+    assert ge.startswith('RCCL') and '; 0 of ' in ge, d['config']        # every gradient written in place by the chart backward

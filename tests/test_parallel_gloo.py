@@ -51,6 +51,35 @@ def _worker(rank, world, port, ret):
         ref = torch.cat([p.grad.reshape(-1) for p in full] + [torch.zeros(3)]) / world
         ret['err'] = float((gathered[0] - ref).abs().max() / ref.abs().max())
         ret['extra_zero'] = bool((extra.grad == 0).all())
+    # ---- producers that write their gradient straight into the flat buffer (what ChartFunction.backward does through
+    # cliora_amd.diora._grad_out): autograd installs the view as .grad and the all-reduce has nothing to copy
+    from cliora_amd.diora import _grad_out
+
+    class WritesInPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w):
+            ctx.w = w.detach()
+            return w.sum().reshape(())
+
+        @staticmethod
+        def backward(ctx, g):
+            out = _grad_out(ctx.w)                      # the parameter's slice of the live flat buffer
+            out.copy_(torch.full_like(ctx.w, float(rank + 1)) * g)
+            return out
+    w = torch.nn.Parameter(torch.zeros(7, 3))
+    red2 = FlatGradAllReduce([w])
+    WritesInPlace.apply(w).backward()
+    in_place = w.grad.data_ptr() == red2.views[0].data_ptr()
+    red2.all_reduce_mean()
+    if rank == 0:
+        ret['in_place'] = bool(in_place) and red2.copied == 0
+        ret['in_place_mean'] = float(w.grad.mean())         # (1 + 2) / 2
+    # with a gradient already in place the producer must get a fresh tensor (autograd accumulates into .grad)
+    WritesInPlace.apply(w).backward()
+    if rank == 0:
+        ret['accumulated'] = float(w.grad.mean())           # 1.5 + 1
+    red2.close()
+    red.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,6 +91,8 @@ def test_flat_grad_allreduce_world2():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret['err'] < 1e-5, ret['err']
     assert ret['extra_zero']
+    assert ret['in_place'] and abs(ret['in_place_mean'] - 1.5) < 1e-6
+    assert abs(ret['accumulated'] - 2.5) < 1e-6
 
 
 def test_rank_chunk_matches_torch_chunk():
