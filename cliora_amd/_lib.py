@@ -89,6 +89,26 @@ def lib():
     L.cliora_contrastive_workspace_bytes.restype = sz
     L.cliora_contrastive_loss.argtypes = [i32, i32, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, sz, vp]
     L.cliora_contrastive_loss.restype = i32
+    L.cliora_proj_workspace_bytes.argtypes = [i32, i32, i32]
+    L.cliora_proj_workspace_bytes.restype = sz
+    L.cliora_proj_forward.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, sz, vp]
+    L.cliora_proj_forward.restype = i32
+    L.cliora_proj_backward.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+    L.cliora_proj_backward.restype = i32
+    L.cliora_recon_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.cliora_recon_workspace_bytes.restype = sz
+    L.cliora_recon_forward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, sz, vp]
+    L.cliora_recon_forward.restype = i32
+    L.cliora_recon_backward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.cliora_recon_backward.restype = i32
+    L.cliora_vg_workspace_bytes.argtypes = [i32, i32]
+    L.cliora_vg_workspace_bytes.restype = sz
+    L.cliora_vg_loss.argtypes = [i32, i32, i32, vp, C.c_float, vp, vp, vp, sz, vp]
+    L.cliora_vg_loss.restype = i32
+    L.cliora_clip_adam_workspace_bytes.argtypes = []
+    L.cliora_clip_adam_workspace_bytes.restype = sz
+    L.cliora_clip_adam.argtypes = [vp, vp, vp, vp, sz, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp, sz, vp]
+    L.cliora_clip_adam.restype = i32
     L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
     L.cliora_cky_decode.restype = i32
     L.cliora_prof_enable.argtypes = [i32, i32]
@@ -151,9 +171,12 @@ class Plan:
             pass
 
 
-# Plan cache: least-recently-used, bounded by the bytes of index tables the cached plans hold (host + device).  Length-bucketed
-# batches give one (B, L) key per bucket; a plan at B=64, L=40 holds ~25 MB of tables, so the budget keeps a few dozen shapes.
+# Plan cache: least-recently-used, bounded by the bytes of index tables the cached plans hold on the device AND by their number
+# (the host-side use lists of a plan are several times its device tables).  Length-bucketed batches give one (B, L) key per bucket:
+# a DioraMLP plan holds 0.1 MB (L 20) to 1 MB (L 40) of device tables, a TreeLSTM plan at B 64 / L 40 about 25 MB (its
+# batch-expanded row maps).
 PLAN_CACHE_BYTES = int(os.environ.get('CLIORA_PLAN_CACHE_MB', '512')) << 20
+PLAN_CACHE_MAX = int(os.environ.get('CLIORA_PLAN_CACHE_MAX', '128'))
 _plans = collections.OrderedDict()
 
 
@@ -165,7 +188,7 @@ def get_plan(B, L, D, share, normalize, R, device_index, arch=0):
         return pl
     pl = _plans[key] = Plan(B, L, D, share, normalize, R, arch)
     total = sum(q.table_bytes for q in _plans.values())
-    while total > PLAN_CACHE_BYTES and len(_plans) > 1:
+    while (total > PLAN_CACHE_BYTES or len(_plans) > PLAN_CACHE_MAX) and len(_plans) > 1:
         _, old = _plans.popitem(last=False)          # evicted plans free their device tables when the last user drops them
         total -= old.table_bytes
     return pl

@@ -77,6 +77,7 @@ struct ProfClass {
     long long launches = 0;
 };
 extern ProfClass g_cliora_prof[CLIORA_KCLASS_COUNT];
+extern std::mutex g_cliora_prof_mu;      // the event lists are shared by every host thread that calls into the library
 struct ProfScope {
     ProfClass* pc = nullptr;
     hipStream_t st;
@@ -84,6 +85,7 @@ struct ProfScope {
     ProfScope(int cls, hipStream_t s) : st(s) {
         ProfClass& c = g_cliora_prof[cls];
         if (!c.on) return;
+        std::lock_guard<std::mutex> lk(g_cliora_prof_mu);
         if (c.used + 2 > c.ev.size()) {
             for (int k = 0; k < 256; ++k) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c.ev.push_back(e); }
         }
@@ -113,6 +115,24 @@ static inline bool split_bf16() {
 static inline int image_stride(int K) { return (K + 31) / 32 * 32 + WS3_PAD; }
 // image argument pair (pointer, kind) of a projection weight
 #define PROJ_IMG(off) (ws + (off)), IMG_FRAG_F32
+
+// A call forks work onto the device's side streams and joins it back before it returns.  If it returns EARLY (a failed launch or
+// HIP call between fork and join), the caller drops its workspaces while side-stream kernels may still use them: this guard makes
+// the caller's stream wait for whatever the side streams hold before the error propagates.  disarm() after the regular join.
+struct ForkGuard {
+    hipStream_t st;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    explicit ForkGuard(hipStream_t caller) : st(caller) {}
+    void arm(int k, hipStream_t s, hipEvent_t e) { side[k] = s; ev[k] = e; }
+    void disarm() { side[0] = side[1] = nullptr; }
+    ~ForkGuard() {
+        for (int k = 0; k < 2; ++k)
+            if (side[k] && side[k] != st) {
+                if (hipEventRecord(ev[k], side[k]) == hipSuccess) (void)hipStreamWaitEvent(st, ev[k], 0);
+            }
+    }
+};
 
 // ------------------------------------------------------------------ launch helpers
 static int pick_tiles(int ntiles16) {

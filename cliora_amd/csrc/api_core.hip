@@ -8,7 +8,7 @@
 thread_local std::string g_cliora_err;
 ProfClass g_cliora_prof[CLIORA_KCLASS_COUNT];
 int g_cliora_split_bf16 = -1;
-static std::mutex g_prof_mu;
+std::mutex g_cliora_prof_mu;
 
 int cliora_ensure_max_lds(const void* fn) {
     static std::mutex mu;
@@ -24,14 +24,14 @@ int cliora_ensure_max_lds(const void* fn) {
 
 extern "C" int cliora_prof_enable(int cls, int on) {
     if (cls < 0 || cls >= CLIORA_KCLASS_COUNT) return fail(CLIORA_EINVAL, "bad kernel class");
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::lock_guard<std::mutex> lk(g_cliora_prof_mu);
     g_cliora_prof[cls].on = on != 0;
     return CLIORA_OK;
 }
 
 extern "C" int cliora_prof_read(int cls, double* total_ms, long long* launches, void* stream) {
     if (cls < 0 || cls >= CLIORA_KCLASS_COUNT) return fail(CLIORA_EINVAL, "bad kernel class");
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::lock_guard<std::mutex> lk(g_cliora_prof_mu);
     ProfClass& c = g_cliora_prof[cls];
     HIPOK(hipStreamSynchronize((hipStream_t)stream));
     for (size_t k = 0; k + 1 < c.used; k += 2) {

@@ -22,6 +22,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
+    ForkGuard fork_guard(st);
     const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
@@ -115,6 +116,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_fork[0], st));
         HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+        fork_guard.arm(0, sb, plan->ev_join[0]);
     }
     if (run_outside) {
         hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH, ws + f.nrmo, OS);
@@ -140,6 +142,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_join[0], sb));
         HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
+        fork_guard.disarm();
     }
     if (padded) {
         CopyTable t; t.n = 0;
@@ -168,6 +171,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
+    ForkGuard fork_guard(st);
     const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     float* wb = (float*)bwd_ws;
@@ -231,6 +235,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_fork[0], st));
         HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+        fork_guard.arm(0, sb, plan->ev_join[0]);
     }
     if (!ran_outside) {
         HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, 5 * DD * sizeof(float), st));
@@ -248,6 +253,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_join[0], sb));
         HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
+        fork_guard.disarm();
     }
     if (ran_outside)
         OKR(launch_tn(st, B * C, ldpo, Dp, Dp, PlainRowsA{dPO, ldpo}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,

@@ -170,9 +170,14 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     if (vl && !obj_span) return fail(CLIORA_EINVAL, "a CLIORA plan (R > 0) needs obj_span");
     if (!vl && obj_span) return fail(CLIORA_EINVAL, "obj_span given to a text-only plan (R = 0)");
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
+    if ((run_outside & CLIORA_FWD_PAIR_STATES) && fwd_ws_bytes < (p.fwd.total + p.fwd.pair_h_floats) * sizeof(float))
+        return fail(CLIORA_ENOMEM, "forward workspace has no room for the pair states (cliora_plan_pair_states_bytes)");
+    if (!p.share && (!P->out_w1 || !P->out_b1 || !P->out_w2 || !P->out_b2 || !P->out_mat))
+        return fail(CLIORA_EINVAL, "share=0 needs the out_* parameters");
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
+    ForkGuard fork_guard(st);                          // declared after the lock: runs (joins the side streams) before it is released
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
     const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, nb = p.nblk, ldpi = nb * Dp;
@@ -184,8 +189,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     const float* X = padded ? ws + f.xp : x_span;
     const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
     const float* w1o = p.share ? P->in_w1 : P->out_w1;
-    if (!p.share && (!P->out_w1 || !P->out_b1 || !P->out_w2 || !P->out_b2 || !P->out_mat))
-        return fail(CLIORA_EINVAL, "share=0 needs the out_* parameters");
 
     // ---- pack parameters into padded / concatenated / transposed layouts ----
     {
@@ -260,11 +263,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     run_outside = flags & 1;
     const bool keep = (flags & CLIORA_FWD_NO_BACKWARD) == 0;
     float* PH = nullptr;                               // per-pair compose outputs, only for the hooks
-    if (flags & CLIORA_FWD_PAIR_STATES) {
-        if (fwd_ws_bytes < (p.fwd.total + p.fwd.pair_h_floats) * sizeof(float))
-            return fail(CLIORA_ENOMEM, "forward workspace has no room for the pair states (cliora_plan_pair_states_bytes)");
-        PH = ws + f.pair_h;
-    }
+    if (flags & CLIORA_FWD_PAIR_STATES) PH = ws + f.pair_h;      // room checked before the first launch
     const size_t hp_stride = (size_t)B * C * Dp;
     float* HPi = ws + f.hp;                            // partial aggregates of the level being composed, one buffer per pass
     float* HPo = ws + f.hp_o;
@@ -384,6 +383,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_fork[0], st));
         HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+        fork_guard.arm(0, sb, plan->ev_join[0]);
     }
     if (run_outside) {       // root of the outside chart (diora.py:337-356) and the scores of the level below it: parents = the root only
         hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH,
@@ -444,6 +444,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_join[0], sb));
         HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
+        fork_guard.disarm();
     }
     if (padded) {
         CopyTable t; t.n = 0;
@@ -474,6 +475,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
+    ForkGuard fork_guard(st);
+    fork_guard.arm(1, plan->side2, plan->ev_join[1]);     // the weight-gradient stream takes work at several points of the call
     const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     float* wb = (float*)bwd_ws;
@@ -585,6 +588,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_fork[0], st));
         HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
+        fork_guard.arm(0, sb, plan->ev_join[0]);
     }
     if (!ran_outside) {
         HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
@@ -640,6 +644,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         }
     }
     HIPOK(hipStreamWaitEvent(st, plan->ev_join[1], 0));
+    fork_guard.disarm();                                   // both side streams have been joined above
 
     if (vl && d_obj_span) {
         float* dO = padded ? wb + bw.dobjp : d_obj_span;

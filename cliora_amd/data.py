@@ -112,8 +112,44 @@ class DeviceFeed(object):
         self._q = queue.Queue(maxsize=max(1, depth))
         self._cuda = self.device.type == 'cuda'
         self._copy_stream = torch.cuda.Stream(self.device) if self._cuda else None
+        self._stop = threading.Event()
+        self._queue_mod = queue
         self._thread = threading.Thread(target=self._produce, args=(iter(batches),), daemon=True)
         self._thread.start()
+
+    def _put(self, item):
+        """Blocking put that gives up when the consumer has closed the feed (a `break` at max_step, an exception in the step)."""
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except self._queue_mod.Full:
+                continue
+        return False
+
+    def close(self):
+        """Stop the producer and drop the staged batches (each holds pinned and device memory): call when leaving the loop early."""
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except self._queue_mod.Empty:
+            pass
+        if self._thread.is_alive() and self._thread is not __import__('threading').current_thread():
+            self._thread.join(timeout=5.0)
+
+    def __del__(self):
+        try:
+            self._stop.set()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _stage(self, v):
         if isinstance(v, dict):
@@ -139,10 +175,11 @@ class DeviceFeed(object):
                         ev.record(self._copy_stream)
                 else:
                     staged, ev = self._stage(batch), None
-                self._q.put((staged, ev))
-            self._q.put((self._END, None))
+                if not self._put((staged, ev)):
+                    return
+            self._put((self._END, None))
         except BaseException as e:                   # surfaces in the consumer
-            self._q.put((e, None))
+            self._put((e, None))
 
     def __iter__(self):
         return self
@@ -156,7 +193,14 @@ class DeviceFeed(object):
         if ev is not None:
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)
-            for v in staged.values():                # the allocator must not reuse the buffers while `cur` still reads them
-                if isinstance(v, torch.Tensor) and v.is_cuda:
-                    v.record_stream(cur)
+            self._record(staged, cur)                # the allocator must not reuse the buffers while `cur` still reads them
         return staged
+
+    @staticmethod
+    def _record(v, stream):
+        """record_stream on every device tensor of a staged batch, nested dicts included (mirrors _stage)."""
+        if isinstance(v, dict):
+            for x in v.values():
+                DeviceFeed._record(x, stream)
+        elif isinstance(v, torch.Tensor) and v.is_cuda:
+            v.record_stream(stream)

@@ -1,19 +1,29 @@
 """Minimal training harness around the native chart modules: the callers either side of the path.
 
 The reference's CLI cannot run on the GPU box (torchvision / h5py / datasets absent), so this
-module restates -- as plain torch ops, they are not on the HIP path -- what sits around
-``self.diora(...)`` in cliora/net/trainer.py: ``Embed`` (:204-224), ``ImageEncoder``
-(net/utils.py:37-55), the three losses (:25-171), ``Net.forward`` (:272-304) and the update rule
-of ``Trainer._step`` / ``gradient_update`` (:450-455, 483-501: backward, clip_grad_norm_ 5.0,
-Adam).  Module and parameter names follow the reference so that its checkpoints
+module restates what sits around ``self.diora(...)`` in cliora/net/trainer.py: ``Embed`` (:204-224),
+``ImageEncoder`` (net/utils.py:37-55), the three losses (:25-171), ``Net.forward`` (:272-304) and
+the update rule of ``Trainer._step`` / ``gradient_update`` (:450-455, 483-501: backward,
+clip_grad_norm_ 5.0, Adam).  On the GPU every one of them runs on this library's kernels
+(cliora_amd/heads.py -> csrc/api_heads.hip: gather + fp32-MFMA projections, the fused
+reconstruction / VG / contrastive heads, one clip + Adam launch sequence over a flat buffer);
+the torch formulas below them are what runs on CPU tensors (the CPU tests) and what the kernels
+are checked against.  Module and parameter names follow the reference so that its checkpoints
 (``trainer.py:383-398``) load by key.  Pinned by tests/golden/net_*.npz.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import heads
 from .diora import DioraMLP as TextDiora
 from .cliora import DioraMLP as VLDiora
+
+NATIVE_HEADS = True        # False: the torch formulas everywhere (A/B and tests)
+
+
+def _native(*tensors):
+    return NATIVE_HEADS and all(t is None or t.is_cuda for t in tensors)
 
 
 def _normal_(module):
@@ -34,6 +44,10 @@ class Embed(nn.Module):
 
     def forward(self, tokens):
         B, L = tokens.shape
+        w = self.embeddings.weight
+        if _native(w, tokens) and w.shape[1] % 16 == 0:
+            idx = tokens.reshape(-1)
+            return heads.proj(w, idx, self.mat).view(B, L, -1), heads.proj(w, idx, self.mat1).view(B, L, -1)
         e = self.embeddings(tokens.reshape(-1))
         return (e @ self.mat.t()).view(B, L, -1), (e @ self.mat1.t()).view(B, L, -1)
 
@@ -49,6 +63,10 @@ class ImageEncoder(nn.Module):
 
     def forward(self, obj_feats):
         x = obj_feats.float()
+        if _native(x) and x.shape[-1] % 16 == 0:
+            lead = x.shape[:-1]
+            return (heads.proj(x, None, self.fc.weight, self.fc.bias).view(*lead, -1),
+                    heads.proj(x, None, self.fc_vis.weight, self.fc_vis.bias).view(*lead, -1))
         return self.fc(x), self.fc_vis(x)
 
 
@@ -63,6 +81,9 @@ class ReconstructionSoftmaxLoss(nn.Module):
 
     def forward(self, tokens, neg_samples, diora):
         B, L = tokens.shape
+        w = self.embeddings.weight
+        if _native(w, tokens, neg_samples, diora.outside_h) and w.shape[1] % 16 == 0:
+            return heads.recon_loss(w, self.mat, diora.outside_h, tokens, neg_samples)
         pos = self.embeddings(tokens) @ self.mat.t()                     # B,L,D
         neg = self.embeddings(neg_samples) @ self.mat.t()                # K,D
         cell = diora.outside_h[:, :L]                                    # B,L,D  leaf outside vectors
@@ -132,6 +153,8 @@ class VGLoss(nn.Module):
 
     def forward(self, vg_atten_score):
         B, _, L, _ = vg_atten_score.shape
+        if _native(vg_atten_score):
+            return heads.vg_loss(vg_atten_score, self.alpha)
         logits = vg_atten_score.max(-1).values.sum(-1) / L
         return self.alpha * F.cross_entropy(logits, torch.arange(B, device=logits.device))
 
@@ -190,8 +213,12 @@ class Trainer(object):
     def __init__(self, net, lr=2e-3, reducer=None):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8)
         self.reducer = reducer                               # cliora_amd.parallel.FlatGradAllReduce or None
+        self.fused = _native(*self.params)                   # clip + Adam as three launches over one flat buffer (heads.FusedClipAdam)
+        if self.fused:
+            self.optimizer = heads.FusedClipAdam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0, reducer=reducer)
+        else:
+            self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8)
 
     def step(self, batch_map, train=True, compute_loss=True, sync=True):
         """One training / evaluation step (trainer.py:437-501).  sync=True returns the loss as a Python float like the reference's
@@ -206,6 +233,9 @@ class Trainer(object):
             total.backward()
             if self.reducer is not None:
                 self.reducer.all_reduce_mean()
-            torch.nn.utils.clip_grad_norm_(self.params, 5.0)
-            self.optimizer.step()
+            if self.fused:
+                self.optimizer.step(gathered=self.reducer is not None and self.optimizer.grads is self.reducer)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.params, 5.0)
+                self.optimizer.step()
         return {'total_loss': float(total.detach()) if sync else total.detach()}

@@ -1,0 +1,197 @@
+"""The callers either side of the chart path on this library's kernels (include/cliora_chart.h, csrc/api_heads.hip):
+
+  proj          Embed.forward (cliora/net/trainer.py:219-224) and ImageEncoder.forward (cliora/net/utils.py:52-55)
+  recon_loss    ReconstructionSoftmaxLoss.forward (trainer.py:46-78)
+  vg_loss       VGLoss.forward (trainer.py:139-171)
+  FusedClipAdam Trainer.gradient_update (trainer.py:450-455): clip_grad_norm_ + Adam over one flat buffer
+
+Each is a torch.autograd.Function around C-ABI calls; torch owns the memory and the autograd edges only.  The one torch op left on
+these paths is the scatter of the looked-up rows' gradient into the embedding table (index_add_), when the table is trainable.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def supported(*tensors):
+    return all(t is None or (t.is_cuda and t.dtype in (torch.float32, torch.int64)) for t in tensors)
+
+
+class Proj(torch.autograd.Function):
+    """y = gather(x, index) w^T + bias; index None = the rows of x themselves."""
+
+    @staticmethod
+    def forward(ctx, x, index, w, bias):
+        x, w = x.contiguous().float(), w.contiguous().float()
+        bias = bias.contiguous().float() if bias is not None else None
+        index = index.contiguous() if index is not None else None
+        K, D = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, K)
+        nrows = index.numel() if index is not None else x2.shape[0]
+        lib = _lib.lib()
+        with torch.cuda.device(x.device):
+            y = torch.empty((nrows, D), device=x.device, dtype=torch.float32)
+            nb = lib.cliora_proj_workspace_bytes(nrows, K, D)
+            ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
+            _lib.check(lib.cliora_proj_forward(_p(x2), _p(index), nrows, K, _p(w), _p(bias), D, _p(y), _p(ws), nb, _st()), 'cliora_proj_forward')
+        ctx.save_for_backward(x2, index, w)
+        ctx.has_bias, ctx.x_shape, ctx.ws = bias is not None, x.shape, ws
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x2, index, w = ctx.saved_tensors
+        d_y = d_y.contiguous().float()
+        nrows, D = d_y.shape
+        K = x2.shape[1]
+        lib = _lib.lib()
+        need_x = ctx.needs_input_grad[0]
+        with torch.cuda.device(d_y.device):
+            d_w = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+            d_b = torch.empty(D, device=d_y.device) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+            d_rows = torch.empty((nrows, K), device=d_y.device) if need_x else None
+            nb = ctx.ws.numel()
+            _lib.check(lib.cliora_proj_backward(_p(x2), _p(index), nrows, K, _p(w), _p(d_y), D, _p(d_w), _p(d_b), _p(d_rows), _p(ctx.ws), nb, _st()),
+                       'cliora_proj_backward')
+            d_x = None
+            if need_x:
+                if index is None:
+                    d_x = d_rows.view(ctx.x_shape)
+                else:       # the embedding table's gradient: rows of repeated tokens add up
+                    d_x = torch.zeros_like(x2).index_add_(0, index.reshape(-1), d_rows).view(ctx.x_shape)
+        return d_x, None, d_w, d_b
+
+
+def proj(x, index, w, bias=None):
+    return Proj.apply(x, index, w, bias)
+
+
+class ReconLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, mat, outside_h, tokens, neg):
+        emb, mat, outside_h = emb.contiguous().float(), mat.contiguous().float(), outside_h.contiguous().float()
+        tokens, neg = tokens.contiguous(), neg.contiguous().reshape(-1)
+        B, L = tokens.shape
+        Cc, D = outside_h.shape[1], outside_h.shape[2]
+        E, Kn = emb.shape[1], neg.numel()
+        lib = _lib.lib()
+        with torch.cuda.device(emb.device):
+            loss = torch.empty(1, device=emb.device)
+            nb = lib.cliora_recon_workspace_bytes(B * L, Kn, E, D)
+            ws = torch.empty(nb, device=emb.device, dtype=torch.uint8)
+            _lib.check(lib.cliora_recon_forward(_p(tokens), _p(neg), B, L, Cc, Kn, _p(emb), E, _p(mat), D, _p(outside_h), _p(loss), _p(ws), nb, _st()),
+                       'cliora_recon_forward')
+        ctx.save_for_backward(emb, mat, outside_h, tokens, neg)
+        ctx.ws = ws
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, mat, outside_h, tokens, neg = ctx.saved_tensors
+        B, L = tokens.shape
+        Cc, D = outside_h.shape[1], outside_h.shape[2]
+        E, Kn = emb.shape[1], neg.numel()
+        lib = _lib.lib()
+        with torch.cuda.device(emb.device):
+            g = g.contiguous().float().reshape(1)
+            d_cell = torch.empty((B * L, D), device=emb.device) if ctx.needs_input_grad[2] else None
+            d_mat = torch.empty_like(mat) if ctx.needs_input_grad[1] else None
+            d_rows = torch.empty((B * L + Kn, E), device=emb.device) if ctx.needs_input_grad[0] else None
+            nb = ctx.ws.numel()
+            _lib.check(lib.cliora_recon_backward(_p(tokens), _p(neg), B, L, Cc, Kn, _p(emb), E, _p(mat), D, _p(outside_h), _p(g), _p(d_cell), _p(d_mat),
+                                                 _p(d_rows), _p(ctx.ws), nb, _st()), 'cliora_recon_backward')
+            d_oh = None
+            if d_cell is not None:
+                d_oh = torch.zeros_like(outside_h)
+                d_oh[:, :L] = d_cell.view(B, L, D)
+            d_emb = None
+            if d_rows is not None:
+                d_emb = torch.zeros_like(emb).index_add_(0, torch.cat([tokens.reshape(-1), neg]), d_rows)
+        return d_emb, d_mat, d_oh, None, None
+
+
+def recon_loss(emb, mat, outside_h, tokens, neg):
+    return ReconLoss.apply(emb, mat, outside_h, tokens, neg)
+
+
+class VGLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vg, alpha):
+        vg = vg.contiguous().float()
+        B, _, L, R = vg.shape
+        lib = _lib.lib()
+        with torch.cuda.device(vg.device):
+            loss = torch.empty(1, device=vg.device)
+            d_vg = torch.empty_like(vg) if ctx.needs_input_grad[0] else None
+            nb = lib.cliora_vg_workspace_bytes(B, L)
+            ws = torch.empty(nb, device=vg.device, dtype=torch.uint8)
+            _lib.check(lib.cliora_vg_loss(B, L, R, _p(vg), float(alpha), _p(loss), _p(d_vg), _p(ws), nb, _st()), 'cliora_vg_loss')
+        ctx.d_vg = d_vg
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.d_vg * g if ctx.d_vg is not None else None), None
+
+
+def vg_loss(vg_atten, alpha):
+    return VGLossFn.apply(vg_atten, alpha)
+
+
+class FusedClipAdam(object):
+    """clip_grad_norm_(params, max_norm) + Adam.step() as three launches over one flat buffer (cliora_clip_adam).
+
+    The parameters are re-pointed at slices of one flat tensor (their values, names and shapes unchanged); the gradients are
+    gathered into a second one -- the data-parallel reducer's buffer when there is one (cliora_amd.parallel.FlatGradAllReduce:
+    the chart backward already writes there), else a buffer of the same kind owned here."""
+
+    def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0, reducer=None):
+        from .parallel import FlatGradAllReduce
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        o = 0
+        for p in self.params:
+            v = self.flat_p[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            o += p.numel()
+        if reducer is not None and [id(p) for p in reducer.params] == [id(p) for p in self.params]:
+            self.grads = reducer
+        else:
+            self.grads = FlatGradAllReduce(self.params)        # used as a gradient arena only: never all-reduced here
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.t = 0
+        self.ws = torch.empty(_lib.lib().cliora_clip_adam_workspace_bytes(), device=dev, dtype=torch.uint8)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, gathered=False):
+        """gathered=True: the reducer has just brought every gradient into the flat buffer (all_reduce_mean)."""
+        ar = self.grads
+        if not gathered:
+            for p, v in zip(ar.params, ar.views):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+        self.t += 1
+        with torch.cuda.device(self.flat_p.device):
+            _lib.check(_lib.lib().cliora_clip_adam(_p(self.flat_p), _p(ar.flat), _p(self.m), _p(self.v), self.flat_p.numel(), float(self.max_norm),
+                                                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.t, _p(self.ws),
+                                                  self.ws.numel(), _st()), 'cliora_clip_adam')

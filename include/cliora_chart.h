@@ -196,6 +196,50 @@ int cliora_contrastive_loss(int B, int C, const float* all_max, const float* ins
                             float alpha, float* loss, float* d_all_max, float* d_inside_s, float* d_outside_s, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* ---- the callers either side of the chart, as kernels of this library ----
+ *
+ * Projection of (optionally looked-up) rows: y (nrows, D) = gather(x, index) w^T + bias.
+ *   Embed.forward (cliora/net/trainer.py:219-224): x = embeddings.weight (V, K), index = the batch's token ids (nrows = B*L,
+ *     int64), w = mat or mat1 (D, K), bias = NULL;
+ *   ImageEncoder.forward (cliora/net/utils.py:52-55): x = obj_feats (nrows = B*R, K = 2048), index = NULL, w / bias = fc or fc_vis.
+ * K must be a multiple of 16.  Backward: d_w (D, K), d_bias (D), d_rows (nrows, K) = gradient of the looked-up rows (the
+ * caller scatters it into the table's gradient); any of them may be NULL.  Exact fp32 products (fp32-input MFMA). */
+size_t cliora_proj_workspace_bytes(int nrows, int K, int D);
+int cliora_proj_forward(const float* x, const int64_t* index, int nrows, int K, const float* w, const float* bias, int D,
+                        float* y, void* workspace, size_t workspace_bytes, void* stream);
+int cliora_proj_backward(const float* x, const int64_t* index, int nrows, int K, const float* w, const float* d_y, int D,
+                         float* d_w, float* d_bias, float* d_rows, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ReconstructionSoftmaxLoss.forward (cliora/net/trainer.py:46-78): tokens (B*L) and neg (Kn) int64 ids into emb (V, E), mat (D, E),
+ * outside_h (B, C, D) of which the leaf cells [:, :L] are read:
+ *   proj = emb[ids] mat^T;  logits_r = [proj_pos_r . cell_r | cell_r proj_neg^T];  loss = mean_r CE(logits_r, 0)
+ * E must be a multiple of 16.  The backward runs on the SAME workspace (it keeps the projections and the softmax): gscale is the
+ * upstream cotangent (a device scalar); d_cell (B*L, D) is the gradient of outside_h[:, :L], d_mat (D, E), d_rows (B*L + Kn, E)
+ * the gradient of the looked-up embedding rows (tokens first, then negatives; NULL when the embeddings are frozen). */
+size_t cliora_recon_workspace_bytes(int n_tokens, int Kn, int E, int D);
+int cliora_recon_forward(const int64_t* tokens, const int64_t* neg, int B, int L, int C, int Kn, const float* emb, int E,
+                         const float* mat, int D, const float* outside_h, float* loss, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int cliora_recon_backward(const int64_t* tokens, const int64_t* neg, int B, int L, int C, int Kn, const float* emb, int E,
+                          const float* mat, int D, const float* outside_h, const float* gscale, float* d_cell, float* d_mat,
+                          float* d_rows, void* workspace, size_t workspace_bytes, void* stream);
+
+/* VGLoss.forward (cliora/net/trainer.py:139-171, variant V1): vg_atten (B, B, L, R);
+ *   logits[a][c] = sum_l max_r vg_atten[a][c][l][r] / L;  loss = alpha * cross_entropy(logits, arange(B))
+ * The forward also leaves the gradient of the loss w.r.t. vg_atten (for an upstream cotangent of 1; it flows to the arg-max region
+ * of each word, the smallest index on ties) in d_vg_atten (B, B, L, R), or skips it when NULL. */
+size_t cliora_vg_workspace_bytes(int B, int L);
+int cliora_vg_loss(int B, int L, int R, const float* vg_atten, float alpha, float* loss, float* d_vg_atten, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* Trainer.gradient_update (cliora/net/trainer.py:450-455): torch.nn.utils.clip_grad_norm_(params, max_norm) followed by one
+ * torch.optim.Adam step (no weight decay, no amsgrad), over ONE flat fp32 buffer holding every parameter (and one holding every
+ * gradient, e.g. the buffer the data-parallel all-reduce works on): three launches whatever the number of parameters.  `step`
+ * counts from 1.  grads are left clipped, as clip_grad_norm_ leaves them. */
+size_t cliora_clip_adam_workspace_bytes(void);
+int cliora_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm, float lr, float beta1,
+                     float beta2, float eps, int step, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Un-aggregated per-split tensors the reference hands to inside_hook (diora.py:295-334)
  * for `level`: scores = (B, L-level, level) laid out exactly like the reference's
  * s.view(B, Lc, N, 1); h = the compose outputs, `rows` = B*(L-level)*level rows of D

@@ -72,3 +72,19 @@ def test_device_feed_prefetches_in_order_and_shards():
         assert False, 'the producer error must surface'
     except RuntimeError as e:
         assert 'reader failed' in str(e)
+
+
+def test_device_feed_closes_when_the_consumer_stops_early():
+    """A consumer that leaves the loop early (max_step, an exception in the step) must not leave the producer blocked on a full
+    queue holding staged batches: close() (or the context manager) stops and joins it."""
+    import threading
+    from cliora_amd.data import DeviceFeed, synthetic_batches
+    lengths = np.random.RandomState(1).randint(3, 9, size=400)
+    before = threading.active_count()
+    with DeviceFeed(synthetic_batches(50, lengths, 4, seed=5, k_neg=7), 'cpu', depth=2) as feed:
+        first = next(feed)
+        assert 'sentences' in first
+    assert not feed._thread.is_alive()
+    assert threading.active_count() <= before
+    # nested dicts are walked when the buffers are tied to the consumer's stream (CPU: a no-op that must not raise)
+    DeviceFeed._record({'a': torch.zeros(2), 'b': {'c': torch.zeros(1)}}, None)

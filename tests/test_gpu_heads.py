@@ -1,0 +1,114 @@
+"""The callers either side of the chart on this library's kernels (cliora_amd/heads.py, csrc/api_heads.hip) against the torch
+formulas of the oracle (oracle/diora_ref.py restates cliora/net/trainer.py:25-224 and net/utils.py:37-55): values and every
+gradient, at sizes with and without padding (D a multiple of 16 or not, negatives / regions not a multiple of 16 / 64).
+Tolerance: 1e-4 of the tensor's scale (fp32 products, other summation order than ATen)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, what, tol=1e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    sc = max(1.0, float(b.abs().max()))
+    assert float((a - b).abs().max()) <= tol * sc, (what, float((a - b).abs().max()), sc)
+
+
+@pytest.mark.parametrize('B,L,V,E,D', [(5, 7, 50, 32, 48), (64, 20, 2000, 1024, 400), (3, 4, 20, 16, 50)])
+def test_embed_projection(B, L, V, E, D):
+    from cliora_amd import heads
+    from oracle import diora_ref as R
+    g = torch.Generator().manual_seed(1)
+    emb, mat, mat1 = torch.randn(V, E, generator=g), torch.randn(D, E, generator=g), torch.randn(D, E, generator=g)
+    tok = torch.randint(0, V, (B, L), generator=g)
+    cs, cw = torch.randn(B, L, D, generator=g), torch.randn(B, L, D, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (emb, mat, mat1)]
+    xs, xw = R.embed_forward(ref[0], ref[1], ref[2], tok)
+    ((xs * cs).sum() + (xw * cw).sum()).backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in (emb, mat, mat1)]
+    idx = tok.cuda().reshape(-1)
+    ys, yw = heads.proj(dev[0], idx, dev[1]).view(B, L, D), heads.proj(dev[0], idx, dev[2]).view(B, L, D)
+    ((ys * cs.cuda()).sum() + (yw * cw.cuda()).sum()).backward()
+    _close(ys, xs, 'x_span'); _close(yw, xw, 'x_word')
+    for a, b, n in zip(dev, ref, ('embeddings', 'mat', 'mat1')):
+        _close(a.grad, b.grad, n)
+
+
+@pytest.mark.parametrize('B,R,K,D', [(4, 36, 2048, 400), (3, 5, 48, 50)])
+def test_image_encoder_projection(B, R, K, D):
+    from cliora_amd import heads
+    from oracle import diora_ref as Rf
+    g = torch.Generator().manual_seed(2)
+    x = torch.relu(torch.randn(B, R, K, generator=g))
+    ps = [0.05 * torch.randn(*s, generator=g) for s in ((D, K), (D,), (D, K), (D,))]
+    c0, c1 = torch.randn(B, R, D, generator=g), torch.randn(B, R, D, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in ps]
+    y0, y1 = Rf.image_encoder_forward(ref[0], ref[1], ref[2], ref[3], x)
+    ((y0 * c0).sum() + (y1 * c1).sum()).backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in ps]
+    xd = x.cuda()
+    z0 = heads.proj(xd, None, dev[0], dev[1]).view(B, R, D)
+    z1 = heads.proj(xd, None, dev[2], dev[3]).view(B, R, D)
+    ((z0 * c0.cuda()).sum() + (z1 * c1.cuda()).sum()).backward()
+    _close(z0, y0, 'span'); _close(z1, y1, 'word')
+    for a, b, n in zip(dev, ref, ('fc.weight', 'fc.bias', 'fc_vis.weight', 'fc_vis.bias')):
+        _close(a.grad, b.grad, n)
+
+
+@pytest.mark.parametrize('B,L,V,E,D,K', [(4, 6, 60, 32, 48, 7), (64, 20, 2000, 1024, 400, 100), (2, 5, 40, 16, 50, 20)])
+def test_reconstruction_loss(B, L, V, E, D, K):
+    from cliora_amd import heads
+    from oracle import diora_ref as R
+    g = torch.Generator().manual_seed(3)
+    C = L * (L + 1) // 2
+    emb, mat = torch.randn(V, E, generator=g), 0.2 * torch.randn(D, E, generator=g)
+    oh = torch.nn.functional.normalize(torch.randn(B, C, D, generator=g), dim=-1)
+    tok = torch.randint(0, V, (B, L), generator=g)
+    neg = torch.randperm(V, generator=g)[:K]
+    ref = [t.clone().requires_grad_(True) for t in (emb, mat, oh)]
+    lr = R.reconstruction_loss(ref[0], ref[1], tok, neg, ref[2])
+    (3.0 * lr).backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in (emb, mat, oh)]
+    ld = heads.recon_loss(dev[0], dev[1], dev[2], tok.cuda(), neg.cuda())
+    (3.0 * ld).backward()
+    assert abs(float(ld) - float(lr)) <= 1e-4 * max(1.0, abs(float(lr)))
+    for a, b, n in zip(dev, ref, ('embeddings', 'mat', 'outside_h')):
+        _close(a.grad, b.grad, n)
+
+
+@pytest.mark.parametrize('B,L,R', [(5, 7, 36), (64, 20, 36), (3, 4, 70), (2, 3, 1)])
+def test_vg_loss(B, L, R):
+    from cliora_amd import heads
+    from oracle import diora_ref as Rf
+    g = torch.Generator().manual_seed(4)
+    vg = torch.randn(B, B, L, R, generator=g)
+    ref = vg.clone().requires_grad_(True)
+    lr = Rf.vg_loss(ref, 0.7)
+    (2.0 * lr).backward()
+    dev = vg.clone().cuda().requires_grad_(True)
+    ld = heads.vg_loss(dev, 0.7)
+    (2.0 * ld).backward()
+    assert abs(float(ld) - float(lr)) <= 1e-5 * max(1.0, abs(float(lr)))
+    _close(dev.grad, ref.grad, 'vg_atten_score', 1e-5)
+
+
+def test_fused_clip_adam_matches_torch():
+    """clip_grad_norm_(5.0) + Adam over one flat buffer against torch's own, three steps, both the clipping and the non-clipping regime."""
+    from cliora_amd import heads
+    g = torch.Generator().manual_seed(5)
+    shapes = [(40, 30), (17,), (5, 3, 4), (1,)]
+    for scale in (0.01, 30.0):          # total norm well under / well over max_norm
+        p_ref = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+        p_dev = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
+        opt = torch.optim.Adam(p_ref, lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+        fused = heads.FusedClipAdam(p_dev, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0)
+        for step in range(3):
+            grads = [scale * torch.randn(*s, generator=g).cuda() for s in shapes]
+            for p, q, gr in zip(p_ref, p_dev, grads):
+                p.grad = gr.clone()
+                q.grad = gr.clone()
+            torch.nn.utils.clip_grad_norm_(p_ref, 5.0)
+            opt.step()
+            fused.step()
+            for p, q in zip(p_ref, p_dev):
+                assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), (scale, step)

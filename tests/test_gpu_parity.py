@@ -399,3 +399,60 @@ def test_two_host_threads_share_the_device_lanes():
         assert torch.equal(alone[i][1], together[i][1]), i
         for n in alone[i][2]:
             assert torch.equal(alone[i][2][n], together[i][2][n]), (i, n)
+
+
+def test_two_host_threads_make_their_first_call_on_one_cold_plan():
+    """Plans are shared process-wide (cliora_amd/_lib.py) and ctypes drops the GIL: two threads whose FIRST forward hits the same
+    (B, L, D) plan both find it not yet uploaded.  The upload is guarded per plan (api_core.hip: cliora_plan_ready, `uploaded`
+    published last): both calls must succeed and give the result a warm plan gives.  A TreeLSTM plan is the hard case -- its upload
+    builds the batch-expanded row maps (a std::vector resize) -- so both architectures are exercised, on shapes no other test uses."""
+    import threading
+    from cliora_amd import _lib
+    from cliora_amd.treelstm import DioraTreeLSTM
+    from oracle import diora_ref as R
+    from oracle import synth
+    for arch in ('mlp', 'treelstm'):
+        D, B, L = (80, 7, 11) if arch == 'mlp' else (48, 5, 13)
+        assert not any(k[0] == B and k[1] == L and k[2] == D for k in _lib._plans), 'shape already warm: pick another'
+        if arch == 'mlp':
+            P, x, _ = synth.diora_case(D, B, L, 77)
+            mods = [_module_from_params(P, D, True, 'unit').eval() for _ in range(2)]
+        else:
+            P = R.init_params_treelstm(D, seed=5)
+            x = torch.randn(B, L, D, generator=torch.Generator().manual_seed(6))
+            mods = []
+            for _ in range(2):
+                m = DioraTreeLSTM(D)
+                sd = m.state_dict()
+                for k in sd:
+                    sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].detach().clone()
+                m.load_state_dict(sd)
+                mods.append(m.cuda().eval())
+        go = threading.Barrier(2)
+        res, errs = {}, []
+
+        def run(i):
+            try:
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s), torch.no_grad():
+                    xg = x.clone().cuda()
+                    go.wait()
+                    mods[i](xg, xg)
+                    s.synchronize()
+                    res[i] = {k: getattr(mods[i], k).detach().clone() for k in CHARTS}
+            except BaseException as e:           # surfaces below
+                errs.append(e)
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        with torch.no_grad():
+            xg = x.clone().cuda()
+            mods[0](xg, xg)
+            torch.cuda.synchronize()
+            warm = {k: getattr(mods[0], k).detach().clone() for k in CHARTS}
+        for i in range(2):
+            for k in CHARTS:
+                assert torch.equal(res[i][k], warm[k]), (arch, i, k)
