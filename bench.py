@@ -384,14 +384,34 @@ def main():
             t_hbm = alg_bytes[dom] / (PEAK_HBM_GBS * 1e9)
             ach_tf = flops_class / t_meas / 1e12
             ach_gb = alg_bytes[dom] / t_meas / 1e9
-            traffic = None
+            # HBM traffic per launch: NOT measured in this run (PMC passes need rocprofv3) -- the figure committed under profiles/ by
+            # tools/final_profile.sh (three separate --pmc passes of this same command), labelled as such in the line
+            traffic, traffic_src = None, None
             tp = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tp):
-                traffic = json.load(open(tp)).get(dom)
+                tj = json.load(open(tp))
+                traffic = tj.get(dom)
+                traffic_src = dict(file='profiles/traffic.json', kind='committed rocprofv3 PMC figure (2 x FETCH_SIZE + WRITE_SIZE per launch, own --pmc passes), not collected in this run',
+                                   measured=tj.get('measured', 'see profiles/README.md'))
+            # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command, so that
+            # frac can be reproduced from profiles/ alone (the two clocks agree within a few per cent)
+            rocprof = None
+            for cand in ('r03_kernel_stats.csv', 'r02_kernel_stats.csv'):
+                kp = os.path.join(ROOT, 'profiles', cand)
+                if os.path.exists(kp):
+                    import csv
+                    for row in csv.DictReader(open(kp)):
+                        if ('level_' + dom) in row.get('Name', ''):
+                            avg_us = float(row['AverageNs']) / 1e3
+                            rocprof = dict(file='profiles/' + cand, avg_launch_ms=round(avg_us / 1e3, 5), calls=int(row['Calls']),
+                                           frac=round(max(alg_bytes[dom] / (PEAK_HBM_GBS * 1e9), flops_class / (peak_mfma * 1e12)) / (avg_us * 1e-6 * kern[dom]['launches'] / args.steps), 4))
+                            break
+                    break
             hbm_bound = t_hbm >= t_mfma
             roof = dict(bound='hbm' if hbm_bound else 'mfma', kernel='level_' + dom,
                         achieved=round(ach_gb if hbm_bound else ach_tf, 2), peak=PEAK_HBM_GBS if hbm_bound else round(peak_mfma, 1),
                         unit='GB/s' if hbm_bound else 'TFLOP/s', frac=round(max(t_hbm, t_mfma) / t_meas, 4), traffic=traffic,
+                        traffic_source=traffic_src, rocprof=rocprof,
                         model='SURVEY.md section 8(d): t_roof = max(algorithmic bytes / 8 TB/s, executed FLOPs / MFMA peak of the arithmetic used)',
                         hbm_term=dict(algorithmic_bytes_per_launch=round(alg_bytes[dom] / nlaunch), achieved_GBs=round(ach_gb, 1),
                                       peak_GBs=PEAK_HBM_GBS, frac=round(t_hbm / t_meas, 4)),

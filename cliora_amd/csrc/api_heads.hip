@@ -255,7 +255,7 @@ extern "C" int cliora_clip_adam(float* params, float* grads, float* exp_avg, flo
     float* w = (float*)ws;
     const int nparts = (int)std::min<size_t>(1024, (n + 255) / 256);
     hipLaunchKernelGGL(sumsq_partial, dim3(nparts), dim3(256), 0, st, n, grads, w);
-    hipLaunchKernelGGL(clip_coef, dim3(1), dim3(64), 0, st, nparts, w, max_norm, w + 1024);
+    hipLaunchKernelGGL(clip_coef, dim3(1), dim3(256), 0, st, nparts, w, max_norm, w + 1024);
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq, w + 1024, lr, beta1, beta2, eps,
                        bc1, bc2);

@@ -209,11 +209,18 @@ static __global__ __launch_bounds__(256) void sumsq_partial(size_t n, const floa
     }
     if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
-static __global__ void clip_coef(int nparts, const float* __restrict__ part, float max_norm, float* __restrict__ out /* [0] norm, [1] coef */) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < nparts; ++i) t += part[i];
-        const float norm = sqrtf(t);
+static __global__ __launch_bounds__(256) void clip_coef(int nparts, const float* __restrict__ part, float max_norm, float* __restrict__ out /* [0] norm, [1] coef */) {
+    __shared__ float sh[256];
+    float t = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) t += part[i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {                          // fixed tree: the same total for the same partial sums, run after run
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(sh[0]);
         out[0] = norm;
         out[1] = fminf(1.f, max_norm / (norm + 1e-6f));          // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
     }

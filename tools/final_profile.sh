@@ -4,6 +4,9 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
+CLIORA_PERSISTENT=1 python bench.py --no-cpu-baseline --no-extras > $O/bench_persistent_on.json 2> $O/bench_persistent_on.err
+python tools/persist_ab.py > $O/persist_ab.txt 2>&1
+CLIORA_PERSIST_TRACE=1 python tools/persist_trace.py > $O/persist_trace.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-events --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ks -- $B --steps 10 --warmup 3 > $O/prof.log 2>&1

@@ -43,5 +43,7 @@ if __name__ == '__main__':
         out[c] = round((2.0 * fetch[c] + write[c]) * 1024.0)
         out[c + '_detail'] = dict(fetch_kib_raw=fetch[c], write_kib=write[c], launches_fetch=nf.get(c, 0), launches_write=nw.get(c, 0),
                                   note='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950: FETCH_SIZE counts wide reads at half)')
+    import datetime
+    out['measured'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-cpu-baseline --no-kernel-events --no-extras --steps 2 --warmup 1` on %s (tools/final_profile.sh)' % datetime.date.today().isoformat()
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(out))
