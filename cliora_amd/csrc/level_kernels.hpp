@@ -1,15 +1,20 @@
 // Fused per-level kernels of the DioraMLP chart recursion (gfx950).
 //
-// One chart level of one pass (cliora/net/diora.py:295-310 inside_func, :358-376 outside_func) is three launches:
+// One chart level of one pass (cliora/net/diora.py:295-310 inside_func, :358-376 outside_func) is TWO launches:
 //
-//   pair_scores_fwd      split scores s_n = QL(a).h_b + s_a + s_b, their softmax p_n and the cell score   (chart_kernels.hpp)
 //   level_compose_fwd    for every split: x = relu(PL(a) + PR(b)), y = relu(W2 x + b2)   [split-bf16 MFMA, weights in LDS]
 //                        and, in the SAME kernel, the softmax-weighted sum over the splits of a cell
 //                            g = sum_n p_n y_n                                            (diora.py:137-146)
 //                        -- the softmax weights do not depend on the compose output, so the per-split rows y_n (and x_n) never
 //                        reach HBM; what is kept for the backward is one ReLU bit per element of y
-//   level_project        h = g / max(||g||, eps)  (utils.py:11-14) and the projections of the new cells
+//   level_project        h = g / max(||g||, eps)  (utils.py:11-14), the projections of the new cells
 //                            [PL | PR | QL] = h Wcat^T + bias                             (factored first compose layer + bilinear)
+//                        and -- first blocks of the same grid -- the split scores s_n = QL(a).h_b + s_a + s_b of the NEXT level,
+//                        their softmax p_n and the cell score (score_cell; diora.py:125-134): a pair has at most one operand on
+//                        the newest level and its partner is then a leaf, so the scoring needs none of the new projections
+//   (level_scores: the scoring alone, for the first level of a pass; level_finish: norm + chart rows of a level without projections)
+//
+// The same device code runs as phases of ONE persistent launch in persist_kernels.hpp (cliora_set_persistent), bitwise equal.
 //
 // Tile order.  A 16-row MFMA tile is (16 consecutive target cells t = b*Lc + p of the level) x (ONE split n): the N tiles of
 // a "cell tile" differ only in n, so the weighted sum over the splits is an element-wise FMA into a register accumulator --

@@ -89,7 +89,11 @@ __device__ __forceinline__ void cst1(pk_rsrc r, uint32_t off, float v) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // LDS behind the weight image: the compose reduction slots, the level table, the give-up flag
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int PK_TW = 4;                                     // column tiles per wave of a wide projection unit
+constexpr int PK_TW = 4;                                     // column tiles per wave of a wide projection task
+#ifndef PK_WIDE_TASKS
+#define PK_WIDE_TASKS 0
+#endif
+constexpr bool PK_WIDE = PK_WIDE_TASKS != 0;                 // 0: one column tile per task everywhere (measured faster: finer tasks balance better)
 constexpr int PK_PART_BYTES = LC_SLOTS * 5 * 64 * 16;         // the compose reduction slots [LC_SLOTS][CT <= 5][64] float4
 constexpr int PK_SS_BYTES = 0;
 constexpr int PK_MAX_L = 64;
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(512) void chart_fwd_persist(PersistFwd a) {
     const int gw = wave * NW + wg, nwv = WAVES * NW;
     auto gemm_task = [&](int role, const PCells& cl, int SP, bool wide, int rg, int ct0, int nct) {
         constexpr int NCHT = KS ? K16 : 0;
-        if (wide) pk_gemm_wave<NCHT, PK_TW, 1, 4>(a, role, cl, rg, ct0, nct, lane);
+        if (PK_WIDE && wide) pk_gemm_wave<NCHT, PK_TW, 1, 4>(a, role, cl, rg, ct0, nct, lane);
         else if (SP == 1) pk_gemm_wave<NCHT, 1, 1, 6>(a, role, cl, rg, ct0, nct, lane);
         else if (SP == 2) pk_gemm_wave<NCHT, 1, 2, 4>(a, role, cl, rg, ct0, nct, lane);
         else pk_gemm_wave<NCHT, 1, 4, 2>(a, role, cl, rg, ct0, nct, lane);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(512) void chart_fwd_persist(PersistFwd a) {
         const int nctI = a.ldpi >> 4, nctO = Dp >> 4;
         // projection tasks: PK_TW column tiles per wave while such tasks still cover half the waves, else one (more, shorter tasks)
         const int gwI = (nctI + PK_TW - 1) / PK_TW, gwO = (nctO + PK_TW - 1) / PK_TW;
-        const bool wideI = lvI.SP == 1 && 2 * nrgI * gwI >= nwv, wideO = lvO.SP == 1 && 2 * nrgO * gwO >= nwv;
+        const bool wideI = PK_WIDE && lvI.SP == 1 && 2 * nrgI * gwI >= nwv, wideO = PK_WIDE && lvO.SP == 1 && 2 * nrgO * gwO >= nwv;
         const int gI = wideI ? gwI : nctI, gO = wideO ? gwO : nctO;
         const int ngI = projI ? nrgI * gI : 0, ngO = projO ? nrgO * gO : 0;
         // scores of inside level lI+1 / outside level lO-1, chart rows (4 per task), rows of a final level
@@ -672,7 +676,14 @@ __global__ __launch_bounds__(512) void chart_fwd_persist(PersistFwd a) {
         const int nhI = projI ? (clI.ncell + 3) >> 2 : 0, nhO = projO ? (clO.ncell + 3) >> 2 : 0;
         const int nfI = finI ? clI.ncell : 0, nfO = finO ? clO.ncell : 0;
         const int g1 = ngI + ngO, e0 = g1 + nsI, e1 = e0 + nsO, e2 = e1 + nhI, e3 = e2 + nhO, e4 = e3 + nfI, total = e4 + nfO;
+#ifdef CLIORA_PERSIST_STAMPS
+        unsigned long long tacc[4] = {0, 0, 0, 0}; unsigned tcnt[4] = {0, 0, 0, 0};
+#endif
         for (int t = gw; t < total; t += nwv) {
+#ifdef CLIORA_PERSIST_STAMPS
+            const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
+            const int kind = t < g1 ? 0 : (t < e1 ? 1 : (t < e3 ? 2 : 3));
+#endif
             if (t < ngI) {
                 const int cg = t / nrgI, rg = t - cg * nrgI;
                 gemm_task(0, clI, lvI.SP, wideI, rg, cg * (wideI ? PK_TW : 1), nctI);
@@ -692,7 +703,17 @@ __global__ __launch_bounds__(512) void chart_fwd_persist(PersistFwd a) {
                 else pk_hrows<4>(a, role, cl, r0, lane);
             } else if (t < e4) pk_finish_row(a, 0, clI, lvI.SP, t - e3, lane);
             else pk_finish_row(a, 1, clO, lvO.SP, t - e4, lane);
+#ifdef CLIORA_PERSIST_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tacc[kind] += __builtin_amdgcn_s_memrealtime() - ts; tcnt[kind] += 1;
+#endif
         }
+#ifdef CLIORA_PERSIST_STAMPS
+        if (a.trace && threadIdx.x == 0) {
+            unsigned long long* f = a.trace + (size_t)NW * (2 * (L + 1)) * 2 + ((size_t)wg * (2 * (L + 1)) + tph) * 8;
+            for (int q = 0; q < 4; ++q) { f[q] = tacc[q]; f[4 + q] = tcnt[q]; }
+        }
+#endif
     };
 
     // ---- first scores of both chains: every operand is final (leaves / the outside root, written before the launch) ----

@@ -51,21 +51,14 @@ for k in range(1, L + 1):
         tot[names[sub]] += w.max()
 print('sum of max work per slot kind:', {k: round(v, 1) for k, v in tot.items()}, 'span %.1f us' % (t[:, :, 1].max() - t0))
 
-if fine[:, :, 3].max() > 0:      # diagnostic build (-DCLIORA_PERSIST_STAMPS): inside the P slots
-    print('P slots: units (inside gemm, outside gemm, wave units) rt wide | per workgroup median us: gemm-in, gemm-out, wave units (of the WGs that had each)')
+if fine.max() > 0:      # diagnostic build (-DCLIORA_PERSIST_STAMPS): wave 0 of every workgroup times its tasks in the P slots, by kind
+    print('P slots, wave 0 of each workgroup: mean us per task (tasks) for projection tiles | scores | chart rows | final rows; busiest wave total us')
     for k in range(1, L + 1):
         ph = 2 * k + 1
-        f = fine[:, ph, :].astype(np.float64) / 100.0
-        meta = int(fine[0, ph, 4]); m2 = int(fine[0, ph, 5])
-        unI, unO, wu = meta >> 40, (meta >> 20) & 0xfffff, meta & 0xfffff
-        end = f[:, 3]
-        def seg(a0, nxt):
-            have = f[:, a0] > 0
-            if not have.any():
-                return float('nan'), 0
-            stop = end.copy()
-            for j in nxt:
-                stop = np.where(f[:, j] > 0, np.minimum(stop, f[:, j]), stop)
-            return float(np.median((stop - f[:, a0])[have])), int(have.sum())
-        g0, n0 = seg(0, [1, 2]); g1, n1 = seg(1, [2]); g2, n2 = seg(2, [])
-        print('k=%2d units %4d %4d %4d  rt %d %d wide %d | %6.2f (%3d)  %6.2f (%3d)  %6.2f (%3d)' % (k, unI, unO, wu, m2 >> 40, (m2 >> 20) & 0xfffff, m2 & 3, g0, n0, g1, n1, g2, n2))
+        f = fine[:, ph, :].astype(np.float64)
+        tot, cnt = f[:, :4] / 100.0, f[:, 4:]
+        cells = []
+        for q in range(4):
+            n = cnt[:, q].sum()
+            cells.append('%6.2f (%5d)' % (tot[:, q].sum() / n, n) if n else '     - (    0)')
+        print('k=%2d  ' % k + ' | '.join(cells) + '   busiest %6.2f' % tot.sum(1).max())
