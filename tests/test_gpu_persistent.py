@@ -58,6 +58,42 @@ def test_persistent_forward_is_bitwise_the_launch_per_level_path(D, B, L, share,
         _lib.set_persistent(prev)
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_persistent_random_shapes(seed, mfma_mode):
+    """Random chart shapes (widths with and without padding, one to eight resident weight blocks, odd batch sizes, L up to the
+    64-split limit of the score tasks): forward outputs and the per-split state the backward reads, bit for bit."""
+    import random
+    from cliora_amd import _lib
+    from oracle import synth
+    rnd = random.Random(1000 + seed)
+    D = rnd.choice([16, 24, 33, 64, 80, 128, 200, 256, 400, 512])
+    L = rnd.choice([2, 3, 5, 9, 14, 23, 31, 64]) if D <= 128 else rnd.choice([2, 4, 7, 12, 18])
+    B = rnd.choice([1, 2, 3, 7, 16]) if L > 20 else rnd.choice([1, 5, 16, 37])
+    share = rnd.random() < 0.7
+    normalize = 'unit' if rnd.random() < 0.8 else 'none'
+    P, x, cot = synth.diora_case(D, B, L, 500 + seed, share=share)
+    m = _module_from_params(P, D, share, normalize)
+    prev = _lib.set_persistent('off')
+    try:
+        outs0, xg0 = _run_gpu(m, x, cot)
+        outs0 = {k: v.detach().clone() for k, v in outs0.items()}
+        g0 = _grads(m)
+        _lib.set_persistent('on')
+        for p_ in m.parameters():
+            p_.grad = None
+        outs1, xg1 = _run_gpu(m, x, cot)
+        for k in CHARTS:
+            assert torch.equal(outs0[k], outs1[k]), (D, B, L, share, normalize, k)
+        g1 = _grads(m)
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (D, B, L, share, normalize, n)
+        assert torch.equal(xg0.grad, xg1.grad)
+        plan = _lib.get_plan(B, L, D, share, normalize, 0, torch.cuda.current_device())
+        assert _lib.persistent_timeouts(plan) == 0
+    finally:
+        _lib.set_persistent(prev)
+
+
 def test_persistent_inside_only(mfma_mode):
     """outside = False (scripts/train.py:130 at eval): only the inside chain runs in the kernel; the outside charts stay zero."""
     from cliora_amd import _lib
