@@ -185,7 +185,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     const float *IS = inside_s, *OS = outside_s;
     const float* X = padded ? ws + f.xp : x_span;
     float *VH = wb + bw.vh, *VC = wb + bw.vc, *dG = wb + bw.dg, *dGc = wb + bw.dgc, *dStot = wb + bw.dstot;
-    float *DA = wb + bw.da, *DCA = wb + bw.dz, *DCB = wb + bw.dcb, *DS = wb + bw.ds, *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
+    float *DS = wb + bw.ds, *dPI = wb + bw.dpi, *dPO = wb + bw.dpo, *dU = wb + bw.du;
     const float *Y = ws + f.y, *Xc = ws + f.x, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po;
 
     const bool two_streams = wavefront_pays_lstm(p, g_cliora_wavefront) && ran_outside;
@@ -193,10 +193,10 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     float *VHo = wb + bw.vh_o, *VCo = wb + bw.vc_o, *dGo = wb + bw.dg_o, *dGco = wb + bw.dgc_o, *dStoto = wb + bw.dstot_o;
     auto outside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, true);
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(lstm_gather_bwd_out, dim3(ncell, (7 * Dp / 4 + 255) / 256), dim3(256), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os,
-                           dv.use[ROLE_OUTB], DA, DCB, DS, PI, ldpi, dPO, VHo, VCo, dStoto);
-        LAUNCHOK("lstm_gather_bwd_out");
+        const int ncell = B * g.Lc;
+        hipLaunchKernelGGL(lstm_cell_bwd_out, dim3(ncell), dim3(128), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os, dv.use[ROLE_OUTB], dv.trow,
+                           Pp, DS, PI, ldpi, PO, ldpo, IC, OC, dGo, dGco, dPO, VHo, VCo, dStoto);
+        LAUNCHOK("lstm_cell_bwd_out");
         if (level >= 1)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
                                    StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
@@ -209,17 +209,14 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, sb, g, VHo, VCo, OH, OC, ws + f.nrmo, ws + f.nrmoc, p.normalize, Y, Xc,
                            Sp, Pp, OS, dStoto, dGo, dGco, DS);
         LAUNCHOK("lstm_scores_bwd(out)");
-        hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, sb, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
-                           PO, ldpo, IC, OC, 0.0f, Xc, Pp, dGo, dGco, DA, DCA, DCB);
-        LAUNCHOK("lstm_pair_bwd(out)");
         return CLIORA_OK;
     };
     auto inside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(lstm_gather_bwd_in, dim3(ncell, (13 * Dp / 4 + 255) / 256), dim3(256), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA],
-                           dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside, DA, DCA, DCB, DS, PI, ldpi, IH, OH, dPI, VH, VC, dStot);
-        LAUNCHOK("lstm_gather_bwd_in");
+        const int ncell = B * g.Lc;
+        hipLaunchKernelGGL(lstm_cell_bwd_in, dim3(ncell), dim3(128), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA], dv.use[ROLE_INB],
+                           dv.use[ROLE_OUTA], ran_outside, dv.trow, Pp, DS, PI, ldpi, PO, ldpo, IH, IC, OH, OC, dG, dGc, dGo, dGco, dPI, VH, VC, dStot);
+        LAUNCHOK("lstm_cell_bwd_in");
         if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                                    StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
@@ -227,9 +224,6 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         hipLaunchKernelGGL(lstm_scores_bwd, dim3(ncell), dim3(256), 0, sa, g, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic, p.normalize, Y, Xc, Sp,
                            Pp, IS, dStot, dG, dGc, DS);
         LAUNCHOK("lstm_scores_bwd(in)");
-        hipLaunchKernelGGL(lstm_pair_bwd, dim3(cells_grid(nrows)), dim3(256), 0, sa, g.rowbase, nrows, Dp, dv.arow, dv.brow, dv.trow, PI, ldpi,
-                           PI + 5 * Dp, ldpi, IC, IC, 1.0f, Xc, Pp, dG, dGc, DA, DCA, DCB);
-        LAUNCHOK("lstm_pair_bwd(in)");
         return CLIORA_OK;
     };
     if (two_streams) {

@@ -128,128 +128,155 @@ static __global__ __launch_bounds__(256) void lstm_aggregate_fwd(LevelArgs g, co
     if (lane == 0) (isC ? nrmC : nrmH)[crow] = nr;
 }
 
-// ---- backward, gather for the cells of one level.  One workgroup per cell, THREADS over the
-// output columns (the projection rows are 5*Dp wide), every thread walks the cell's use lists.
-//   inside cell:  dPL(5Dp) = sum_{left uses + sibling uses} DA;  dPR(5Dp) = sum_{right uses} DA;
+// ---- backward of the cells of one level, cell-centric: one workgroup per cell, one THREAD per 16-byte column, walking the
+// cell's use lists (the span pairs it is an operand of) and RECOMPUTING each pair's gate gradients on the fly:
+//   pair (a, b) -> target t, split weight p:   [u,i,o,f0,f1] = gates(PL(a) + PR(b)),  c = f0 c_a + f1 c_b + i u,  tc = tanh(c)
+//       dh = p dGh(t),   dc = p dGc(t) + dh o (1 - tc^2)
+//       d act = [dc i (1-u^2), dc u i(1-i), dh tc o(1-o), dc c_a f0(1-f0), dc c_b f1(1-f1)]     (the same five rows for a and for b)
+//       d c_a = dc f0,   d c_b = dc f1
+//   inside cell:  dPL(5Dp) = sum_{left + sibling uses} d act;  dPR(5Dp) = sum_{right uses} d act;
 //                 dQL = sum_{left} ds H(right) + sum_{sibling} ds OH(parent);
-//                 vH = ext + sum_{right} ds QL(left);  vC = ext + sum_{left,sibling} DCA + sum_{right} DCB
-//   outside cell: dPRo(5Dp) = sum_{parent uses} DA;  vH = ext + sum ds QL(sibling);  vC = ext + sum DCB
-__device__ __forceinline__ float4 sum_rows(const UseTab& ut, int c, int b, const float* __restrict__ SRC, int ld, int col) {
-    float4 acc = f4zero();
-    const int beg = ut.off[c], end = ut.off[c + 1];
-    for (int u0 = beg; u0 < end; u0 += 8) {            // eight rows in flight; accumulation stays in use order
-        float4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int uu = min(u0 + j, end - 1);
-            const size_t r = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
-            v[j] = ld4(SRC + r * ld + col);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (u0 + j < end) acc = f4add(acc, v[j]);
-    }
-    return acc;
-}
-__device__ __forceinline__ float4 sum_scaled(const UseTab& ut, int c, int b, int bC, const float* __restrict__ DS, const float* __restrict__ SRC,
-                                             int ld, int col) {
-    float4 acc = f4zero();
-    const int beg = ut.off[c], end = ut.off[c + 1];
-    for (int u0 = beg; u0 < end; u0 += 8) {
-        float4 v[8];
-        float ds[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int uu = min(u0 + j, end - 1);
-            const size_t r = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
-            ds[j] = (u0 + j < end) ? DS[r] : 0.f;
-            v[j] = ld4(SRC + (size_t)(bC + ut.partner[uu]) * ld + col);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = f4fma(ds[j], v[j], acc);
-    }
-    return acc;
-}
-__device__ __forceinline__ float sum_ds(const UseTab& ut, int c, int b, const float* __restrict__ DS) {
-    float acc = 0.f;
-    for (int u = ut.off[c]; u < ut.off[c + 1]; ++u) acc += DS[(size_t)ut.row[u] + (size_t)b * ut.stride[u]];
-    return acc;
+//                 vH = ext + sum_{right} ds QL(left);  vC = ext + sum_{left,sibling} d c_a + sum_{right} d c_b
+//   outside cell: dPRo(5Dp) = sum_{parent uses} d act;  vH = ext + sum ds QL(sibling);  vC = ext + sum d c_b
+// Round 2 wrote the five d act rows and d c_a / d c_b of every pair to HBM (lstm_pair_bwd: 24 kB read + 11 kB written per pair) and
+// gathered them per cell (19 kB per pair); a use costs the same 12.8 kB here (the partner's five gate rows, its cell state, the
+// target's two gradient rows) and nothing is written per pair: 57.6 -> 28.8 kB per pair in the backward, and the 16 GB pair-gradient
+// buffer of B 64 / L 40 is gone.  The gate arithmetic is recomputed twice per pair (once from each operand's side): ~2 ms of
+// VALU per step at that size against ~15 ms of HBM time saved.
+struct LstmPairGrad { float4 da[5]; float4 dca, dcb; };
+__device__ __forceinline__ LstmPairGrad lstm_pair_grad(const float4 (&x)[5], float4 cA, float4 cB, float kf, float pn, float4 dGh, float4 dGc) {
+    const float4 u = f4tanh(x[0]), i = f4sig(x[1], 0.f), o = f4sig(x[2], 0.f), f0 = f4sig(x[3], kf), f1 = f4sig(x[4], kf);
+    const float4 c = f4add(f4add(f4mul(f0, cA), f4mul(f1, cB)), f4mul(i, u));          // as lstm_pair_fwd forms it
+    const float4 tc = f4tanh(c);
+    const float4 dh = f4scale(pn, dGh);
+    const float4 dc = f4add(f4scale(pn, dGc), f4mul(f4mul(dh, o), f4dtanh(tc)));
+    LstmPairGrad r;
+    r.da[0] = f4mul(f4mul(dc, i), f4dtanh(u));
+    r.da[1] = f4mul(f4mul(dc, u), f4dsig(i));
+    r.da[2] = f4mul(f4mul(dh, tc), f4dsig(o));
+    r.da[3] = f4mul(f4mul(dc, cA), f4dsig(f0));
+    r.da[4] = f4mul(f4mul(dc, cB), f4dsig(f1));
+    r.dca = f4mul(dc, f0);
+    r.dcb = f4mul(dc, f1);
+    return r;
 }
 
-static __global__ __launch_bounds__(256) void lstm_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
-                                                          const float* __restrict__ dS_ext, UseTab ina, UseTab inb, UseTab outa, int with_outside,
-                                                          const float* __restrict__ DA, const float* __restrict__ DCA, const float* __restrict__ DCB,
-                                                          const float* __restrict__ DS, const float* __restrict__ PI, int ldpi,
-                                                          const float* __restrict__ IH, const float* __restrict__ OH,
-                                                          float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ VC,
-                                                          float* __restrict__ dStot) {
-    const int t = blockIdx.x, tid = threadIdx.x;
+// One use list of the cell.  OWN_IS_A: the cell is the pair's a operand (left child / sibling) and the partner its b operand.
+//   own[5]: the cell's own gate rows at this column; PP: the partner's gate rows (row stride ldp, first block at PP);
+//   CP: the partner's cell-state chart; SC: the chart / projection the score term multiplies ds with (row stride lds)
+template <bool OWN_IS_A>
+__device__ __forceinline__ void lstm_walk_uses(const UseTab& ut, int c, int b, int bC, int c4, int Dp, const float4 (&own)[5], float4 cown,
+                                               const float* __restrict__ PP, int ldp, const float* __restrict__ CP, float kf,
+                                               const int32_t* __restrict__ trow, const float* __restrict__ Pp, const float* __restrict__ DS,
+                                               const float* __restrict__ dGh, const float* __restrict__ dGc, const float* __restrict__ SC, int lds,
+                                               float4 (&dact)[5], float4& vc, float4& sterm, float& vs) {
+    const int beg = ut.off[c], end = ut.off[c + 1];
+    constexpr int NB = 2;                              // uses in flight (16 x 16 B per thread)
+    for (int u0 = beg; u0 < end; u0 += NB) {
+        float4 pg[NB][5], pc[NB], gh[NB], gc[NB], sc[NB];
+        float pn[NB], ds[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int uu = min(u0 + j, end - 1);
+            const size_t r = (size_t)ut.row[uu] + (size_t)b * ut.stride[uu];
+            const size_t prow = (size_t)(bC + ut.partner[uu]);
+            const size_t tr = (size_t)trow[r];
+            const bool live = u0 + j < end;
+            pn[j] = live ? Pp[r] : 0.f;                // a dead slot re-reads the last use with weight zero: adds exact zeros
+            ds[j] = live ? DS[r] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pg[j][k] = ld4(PP + prow * ldp + (size_t)k * Dp + c4);
+            pc[j] = ld4(CP + prow * Dp + c4);
+            gh[j] = ld4(dGh + tr * Dp + c4);
+            gc[j] = ld4(dGc + tr * Dp + c4);
+            sc[j] = ld4(SC + prow * lds + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float4 x[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) x[k] = OWN_IS_A ? f4add(own[k], pg[j][k]) : f4add(pg[j][k], own[k]);     // PL(a) + PR(b), in that order
+            const LstmPairGrad q = lstm_pair_grad(x, OWN_IS_A ? cown : pc[j], OWN_IS_A ? pc[j] : cown, kf, pn[j], gh[j], gc[j]);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dact[k] = f4add(dact[k], q.da[k]);
+            vc = f4add(vc, OWN_IS_A ? q.dca : q.dcb);
+            sterm = f4fma(ds[j], sc[j], sterm);
+            vs += ds[j];
+        }
+    }
+}
+
+static __global__ __launch_bounds__(128) void lstm_cell_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
+                                                        const float* __restrict__ dS_ext, UseTab ina, UseTab inb, UseTab outa, int with_outside,
+                                                        const int32_t* __restrict__ trow, const float* __restrict__ Pp, const float* __restrict__ DS,
+                                                        const float* __restrict__ PI, int ldpi, const float* __restrict__ PO, int ldpo,
+                                                        const float* __restrict__ IH, const float* __restrict__ IC, const float* __restrict__ OH,
+                                                        const float* __restrict__ OC, const float* __restrict__ dGi, const float* __restrict__ dGci,
+                                                        const float* __restrict__ dGo, const float* __restrict__ dGco, float* __restrict__ dPI,
+                                                        float* __restrict__ VH, float* __restrict__ VC, float* __restrict__ dStot) {
+    const int t = blockIdx.x, v = threadIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
-    const int Dp = g.Dp, bC = b * g.C;
-    const int n5 = (5 * Dp) >> 2, n1 = Dp >> 2;
+    const int Dp = g.Dp, bC = b * g.C, nv = Dp >> 2;
+    if (v >= nv) return;
+    const int c4 = 4 * v;
+    const float* mine = PI + crow * ldpi;
+    float4 pl[5], pr[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { pl[k] = ld4(mine + (size_t)k * Dp + c4); pr[k] = ld4(mine + (size_t)(5 + k) * Dp + c4); }
+    const float4 cown = ld4(IC + crow * Dp + c4);
+    float4 dpl[5], dpr[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { dpl[k] = f4zero(); dpr[k] = f4zero(); }
+    float4 dql = f4zero();
+    float4 vh = dH_ext ? ld_ext(dH_ext + crow * D, D, c4) : f4zero();
+    float4 vc = dC_ext ? ld_ext(dC_ext + crow * D, D, c4) : f4zero();
+    float vs = 0.f;
+    // left child: partner = right child (PR blocks), score term ds * H(right)
+    lstm_walk_uses<true>(ina, c, b, bC, c4, Dp, pl, cown, PI + (size_t)5 * Dp, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, IH, Dp, dpl, vc, dql, vs);
+    // right child: partner = left child (PL blocks), score term ds * QL(left)
+    lstm_walk_uses<false>(inb, c, b, bC, c4, Dp, pr, cown, PI, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, PI + (size_t)10 * Dp, ldpi, dpr, vc, vh, vs);
+    // sibling in the outside pass: partner = parent (outside cell, PRo blocks), targets are outside cells, constant 0 (diora.py:174)
+    if (with_outside)
+        lstm_walk_uses<true>(outa, c, b, bC, c4, Dp, pl, cown, PO, ldpo, OC, 0.0f, trow, Pp, DS, dGo, dGco, OH, Dp, dpl, vc, dql, vs);
     float* o = dPI + crow * ldpi;
-    // grid.y deals the 13*Dp/4 output float4 columns out in chunks of 256: a thread walks the use lists once
-    for (int v = blockIdx.y * 256 + tid; v < 2 * n5 + 3 * n1; v += 256 * gridDim.y) {
-        if (v < n5) {                                  // dPL
-            float4 a = sum_rows(ina, c, b, DA, 5 * Dp, 4 * v);
-            if (with_outside) a = f4add(a, sum_rows(outa, c, b, DA, 5 * Dp, 4 * v));
-            st4(o + 4 * v, a);
-        } else if (v < 2 * n5) {                       // dPR
-            const int col = 4 * (v - n5);
-            st4(o + 5 * Dp + col, sum_rows(inb, c, b, DA, 5 * Dp, col));
-        } else if (v < 2 * n5 + n1) {                  // dQL
-            const int col = 4 * (v - 2 * n5);
-            float4 a = sum_scaled(ina, c, b, bC, DS, IH, Dp, col);
-            if (with_outside) a = f4add(a, sum_scaled(outa, c, b, bC, DS, OH, Dp, col));
-            st4(o + 10 * Dp + col, a);
-        } else if (v < 2 * n5 + 2 * n1) {              // vH
-            const int col = 4 * (v - 2 * n5 - n1);
-            float4 a = dH_ext ? ld_ext(dH_ext + crow * D, D, col) : f4zero();
-            a = f4add(a, sum_scaled(inb, c, b, bC, DS, PI + 10 * Dp, ldpi, col));
-            st4(VH + crow * Dp + col, a);
-        } else {                                       // vC
-            const int col = 4 * (v - 2 * n5 - 2 * n1);
-            float4 a = dC_ext ? ld_ext(dC_ext + crow * D, D, col) : f4zero();
-            a = f4add(a, sum_rows(ina, c, b, DCA, Dp, col));
-            if (with_outside) a = f4add(a, sum_rows(outa, c, b, DCA, Dp, col));
-            a = f4add(a, sum_rows(inb, c, b, DCB, Dp, col));
-            st4(VC + crow * Dp + col, a);
-        }
-    }
-    if (tid == 0 && blockIdx.y == 0) {
-        float vs = dS_ext ? dS_ext[crow] : 0.f;
-        vs += sum_ds(inb, c, b, DS) + sum_ds(ina, c, b, DS);
-        if (with_outside) vs += sum_ds(outa, c, b, DS);
-        dStot[crow] = vs;
-    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { st4(o + (size_t)k * Dp + c4, dpl[k]); st4(o + (size_t)(5 + k) * Dp + c4, dpr[k]); }
+    st4(o + (size_t)10 * Dp + c4, dql);
+    st4(VH + crow * Dp + c4, vh);
+    st4(VC + crow * Dp + c4, vc);
+    if (v == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + vs;
 }
 
-static __global__ __launch_bounds__(256) void lstm_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
-                                                           const float* __restrict__ dS_ext, UseTab outb, const float* __restrict__ DA,
-                                                           const float* __restrict__ DCB, const float* __restrict__ DS,
-                                                           const float* __restrict__ PI, int ldpi, float* __restrict__ dPO,
-                                                           float* __restrict__ VH, float* __restrict__ VC, float* __restrict__ dStot) {
-    const int t = blockIdx.x, tid = threadIdx.x;
+static __global__ __launch_bounds__(128) void lstm_cell_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
+                                                         const float* __restrict__ dS_ext, UseTab outb, const int32_t* __restrict__ trow,
+                                                         const float* __restrict__ Pp, const float* __restrict__ DS, const float* __restrict__ PI,
+                                                         int ldpi, const float* __restrict__ PO, int ldpo, const float* __restrict__ IC,
+                                                         const float* __restrict__ OC, const float* __restrict__ dGo, const float* __restrict__ dGco,
+                                                         float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ VC,
+                                                         float* __restrict__ dStot) {
+    const int t = blockIdx.x, v = threadIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
-    const int Dp = g.Dp, bC = b * g.C;
-    const int n5 = (5 * Dp) >> 2, n1 = Dp >> 2;
-    for (int v = blockIdx.y * 256 + tid; v < n5 + 2 * n1; v += 256 * gridDim.y) {
-        if (v < n5) {
-            st4(dPO + crow * 5 * Dp + 4 * v, sum_rows(outb, c, b, DA, 5 * Dp, 4 * v));
-        } else if (v < n5 + n1) {
-            const int col = 4 * (v - n5);
-            float4 a = dH_ext ? ld_ext(dH_ext + crow * D, D, col) : f4zero();
-            st4(VH + crow * Dp + col, f4add(a, sum_scaled(outb, c, b, bC, DS, PI + 10 * Dp, ldpi, col)));
-        } else {
-            const int col = 4 * (v - n5 - n1);
-            float4 a = dC_ext ? ld_ext(dC_ext + crow * D, D, col) : f4zero();
-            st4(VC + crow * Dp + col, f4add(a, sum_rows(outb, c, b, DCB, Dp, col)));
-        }
-    }
-    if (tid == 0 && blockIdx.y == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + sum_ds(outb, c, b, DS);
+    const int Dp = g.Dp, bC = b * g.C, nv = Dp >> 2;
+    if (v >= nv) return;
+    const int c4 = 4 * v;
+    float4 po[5], dpo[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { po[k] = ld4(PO + crow * ldpo + (size_t)k * Dp + c4); dpo[k] = f4zero(); }
+    const float4 cown = ld4(OC + crow * Dp + c4);
+    float4 vh = dH_ext ? ld_ext(dH_ext + crow * D, D, c4) : f4zero();
+    float4 vc = dC_ext ? ld_ext(dC_ext + crow * D, D, c4) : f4zero();
+    float vs = 0.f;
+    // parent in the outside pass: partner = sibling (inside cell, PL blocks), score term ds * QL(sibling)
+    lstm_walk_uses<false>(outb, c, b, bC, c4, Dp, po, cown, PI, ldpi, IC, 0.0f, trow, Pp, DS, dGo, dGco, PI + (size_t)10 * Dp, ldpi, dpo, vc, vh, vs);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) st4(dPO + crow * ldpo + (size_t)k * Dp + c4, dpo[k]);
+    st4(VH + crow * Dp + c4, vh);
+    st4(VC + crow * Dp + c4, vc);
+    if (v == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + vs;
 }
 
 // ---- backward, unit-norm of both vectors + softmax/score backward (one workgroup per cell)
@@ -304,47 +331,6 @@ static __global__ __launch_bounds__(256) void lstm_scores_bwd(LevelArgs g, const
     const float mean = wave_sum(pn * dp);
     const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + sn - Schart[crow]));
     if (an) DS[row0 + lane] = ds;
-}
-
-// ---- backward of one span pair (one wave per pair row): gates recomputed from PL(a) + PR(b)
-//   dh = p dGh(target), dc_in = p dGc(target);  out: DA (5 gate pre-activation grads), DCA = dc f0, DCB = dc f1
-static __global__ __launch_bounds__(256) void lstm_pair_bwd(int rowbase, int nrows, int Dp, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
-                                                     const int32_t* __restrict__ trow, const float* __restrict__ PA, int ldA,
-                                                     const float* __restrict__ PB, int ldB, const float* __restrict__ CA,
-                                                     const float* __restrict__ CB, float kf, const float* __restrict__ X,
-                                                     const float* __restrict__ Pp, const float* __restrict__ dGh, const float* __restrict__ dGc,
-                                                     float* __restrict__ DA, float* __restrict__ DCA, float* __restrict__ DCB) {
-    const int lane = threadIdx.x & 63;
-    const int rl = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rl >= nrows) return;
-    const size_t r = (size_t)rowbase + rl;
-    const int ar = arow[r], br = brow[r], tr = trow[r];
-    const float pn = Pp[r];
-    const float* pa = PA + (size_t)ar * ldA;
-    const float* pb = PB + (size_t)br * ldB;
-    const float* ca = CA + (size_t)ar * Dp;
-    const float* cb = CB + (size_t)br * Dp;
-    const int nv = Dp >> 2;
-    for (int v = lane; v < nv; v += 64) {
-        const int c4 = 4 * v;
-        const float4 u = f4tanh(f4add(ld4(pa + c4), ld4(pb + c4)));
-        const float4 i = f4sig(f4add(ld4(pa + Dp + c4), ld4(pb + Dp + c4)), 0.f);
-        const float4 o = f4sig(f4add(ld4(pa + 2 * Dp + c4), ld4(pb + 2 * Dp + c4)), 0.f);
-        const float4 f0 = f4sig(f4add(ld4(pa + 3 * Dp + c4), ld4(pb + 3 * Dp + c4)), kf);
-        const float4 f1 = f4sig(f4add(ld4(pa + 4 * Dp + c4), ld4(pb + 4 * Dp + c4)), kf);
-        const float4 cA = ld4(ca + c4), cB = ld4(cb + c4);
-        const float4 tc = f4tanh(ld4(X + r * Dp + c4));
-        const float4 dh = f4scale(pn, ld4(dGh + (size_t)tr * Dp + c4));
-        const float4 dc = f4add(f4scale(pn, ld4(dGc + (size_t)tr * Dp + c4)), f4mul(f4mul(dh, o), f4dtanh(tc)));
-        float* da = DA + r * 5 * Dp + c4;
-        st4(da, f4mul(f4mul(dc, i), f4dtanh(u)));                 // d act_u
-        st4(da + Dp, f4mul(f4mul(dc, u), f4dsig(i)));             // d act_i
-        st4(da + 2 * Dp, f4mul(f4mul(dh, tc), f4dsig(o)));        // d act_o
-        st4(da + 3 * Dp, f4mul(f4mul(dc, cA), f4dsig(f0)));       // d act_f0
-        st4(da + 4 * Dp, f4mul(f4mul(dc, cB), f4dsig(f1)));       // d act_f1
-        st4(DCA + r * Dp + c4, f4mul(dc, f0));
-        st4(DCB + r * Dp + c4, f4mul(dc, f1));
-    }
 }
 
 // ---- leaves backward: unit-norm of h and c, then the leaf gates -> dACT (3 blocks)

@@ -194,12 +194,13 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.vh = take(BC * Dp); b.dg = take(BC * Dp); b.dstot = take(BC);
         b.vh_o = take(BC * Dp); b.dg_o = take(BC * Dp); b.dstot_o = take(BC);
         b.vc_o = take(lstm * BC * Dp); b.dgc_o = take(lstm * BC * Dp);
-        b.da = take(Rt * (lstm ? 5 : 1) * Dp); b.ds = take(Rt);
-        b.dz = take(Rt * Dp);
+        // TreeLSTM keeps no per-pair gradient rows: its cell-centric backward recomputes them per use (lstm_kernels.hpp)
+        b.da = take(lstm ? 0 : Rt * Dp); b.ds = take(Rt);
+        b.dz = take(lstm ? 0 : Rt * Dp);
         b.x = take(arch == 0 ? Rt * Dp : 0);
         b.dpp = take(arch == 0 ? Rt * p.fwd.ncb3 : 0);
         b.dpb = take(arch == 0 ? Rt : 0);
-        b.dcb = take(lstm * Rt * Dp); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);
+        b.dcb = take(0); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);
         b.dpi = take(BC * nb * Dp); b.dpo = take(BC * npo * Dp);
         b.du = take(BL * nlf * Dp); b.dxp = take(padded ? BL * Dp : 0);
         // split-K slabs: at most 1024 wave-sized partial blocks of 80x80 per weight-gradient GEMM
