@@ -2,6 +2,10 @@
 #include "api_common.hpp"
 #include "lstm_kernels.hpp"
 
+#ifndef LSTM_W
+#define LSTM_W 4          // floats per thread in the cell-centric backward kernels (lstm_kernels.hpp: VecW); 1, 2 and 4 time the same on MI355X
+#endif
+
 // two streams pay under the same rule as for DioraMLP (api_mlp.hip: wavefront_pays)
 static bool wavefront_pays_lstm(const Plan& p, int mode) {
     if (p.L <= 2 || mode == 0) return false;
@@ -194,7 +198,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     auto outside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, true);
         const int ncell = B * g.Lc;
-        hipLaunchKernelGGL(lstm_cell_bwd_out, dim3(ncell), dim3(128), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os, dv.use[ROLE_OUTB], dv.trow,
+        hipLaunchKernelGGL(lstm_cell_bwd_out<LSTM_W>, dim3(ncell), dim3((Dp / LSTM_W + 63) / 64 * 64), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os, dv.use[ROLE_OUTB], dv.trow,
                            Pp, DS, PI, ldpi, PO, ldpo, IC, OC, dGo, dGco, dPO, VHo, VCo, dStoto);
         LAUNCHOK("lstm_cell_bwd_out");
         if (level >= 1)
@@ -214,7 +218,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     auto inside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
-        hipLaunchKernelGGL(lstm_cell_bwd_in, dim3(ncell), dim3(128), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA], dv.use[ROLE_INB],
+        hipLaunchKernelGGL(lstm_cell_bwd_in<LSTM_W>, dim3(ncell), dim3((Dp / LSTM_W + 63) / 64 * 64), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA], dv.use[ROLE_INB],
                            dv.use[ROLE_OUTA], ran_outside, dv.trow, Pp, DS, PI, ldpi, PO, ldpo, IH, IC, OH, OC, dG, dGc, dGo, dGco, dPI, VH, VC, dStot);
         LAUNCHOK("lstm_cell_bwd_in");
         if (level <= L - 2)

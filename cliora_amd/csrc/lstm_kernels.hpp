@@ -143,37 +143,66 @@ static __global__ __launch_bounds__(256) void lstm_aggregate_fwd(LevelArgs g, co
 // target's two gradient rows) and nothing is written per pair: 57.6 -> 28.8 kB per pair in the backward, and the 16 GB pair-gradient
 // buffer of B 64 / L 40 is gone.  The gate arithmetic is recomputed twice per pair (once from each operand's side): ~2 ms of
 // VALU per step at that size against ~15 ms of HBM time saved.
-struct LstmPairGrad { float4 da[5]; float4 dca, dcb; };
-__device__ __forceinline__ LstmPairGrad lstm_pair_grad(const float4 (&x)[5], float4 cA, float4 cB, float kf, float pn, float4 dGh, float4 dGc) {
-    const float4 u = f4tanh(x[0]), i = f4sig(x[1], 0.f), o = f4sig(x[2], 0.f), f0 = f4sig(x[3], kf), f1 = f4sig(x[4], kf);
-    const float4 c = f4add(f4add(f4mul(f0, cA), f4mul(f1, cB)), f4mul(i, u));          // as lstm_pair_fwd forms it
-    const float4 tc = f4tanh(c);
-    const float4 dh = f4scale(pn, dGh);
-    const float4 dc = f4add(f4scale(pn, dGc), f4mul(f4mul(dh, o), f4dtanh(tc)));
-    LstmPairGrad r;
-    r.da[0] = f4mul(f4mul(dc, i), f4dtanh(u));
-    r.da[1] = f4mul(f4mul(dc, u), f4dsig(i));
-    r.da[2] = f4mul(f4mul(dh, tc), f4dsig(o));
-    r.da[3] = f4mul(f4mul(dc, cA), f4dsig(f0));
-    r.da[4] = f4mul(f4mul(dc, cB), f4dsig(f1));
-    r.dca = f4mul(dc, f0);
-    r.dcb = f4mul(dc, f1);
+// W floats per thread: W = 4 is 16-byte accesses by Dp/4 threads with ~170 registers each, W = 1 a thread per column with a quarter
+// of the registers and four times the waves.  c5 at L = 40 times the same with 1, 2 and 4 (35.8 / 36.5 / 35.6 ms per step): the
+// kernels are bound by the bytes of their use lists (nine rows per use) and the gate transcendentals, not by latency hiding.
+template <int W> struct VecW { float v[W]; };
+template <int W> __device__ __forceinline__ VecW<W> vzero() { VecW<W> r; for (int q = 0; q < W; ++q) r.v[q] = 0.f; return r; }
+template <int W> __device__ __forceinline__ VecW<W> vload(const float* p) {
+    VecW<W> r;
+    if constexpr (W == 4) { const float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+    else if constexpr (W == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+    else r.v[0] = p[0];
+    return r;
+}
+template <int W> __device__ __forceinline__ void vstore(float* p, const VecW<W>& a) {
+    if constexpr (W == 4) st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+    else if constexpr (W == 2) *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
+    else p[0] = a.v[0];
+}
+template <int W> __device__ __forceinline__ VecW<W> vload_ext(const float* base, int D, int col) {      // caller's stride D, maybe unaligned
+    VecW<W> r;
+#pragma unroll
+    for (int q = 0; q < W; ++q) r.v[q] = col + q < D ? base[col + q] : 0.f;
+    return r;
+}
+
+template <int W> struct LstmPairGrad { VecW<W> da[5]; VecW<W> dca, dcb; };
+template <int W>
+__device__ __forceinline__ LstmPairGrad<W> lstm_pair_grad(const VecW<W> (&x)[5], const VecW<W>& cA, const VecW<W>& cB, float kf, float pn,
+                                                          const VecW<W>& dGh, const VecW<W>& dGc) {
+    LstmPairGrad<W> r;
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const float u = tanhf(x[0].v[q]), i = sigm(x[1].v[q] + 0.f), o = sigm(x[2].v[q] + 0.f), f0 = sigm(x[3].v[q] + kf), f1 = sigm(x[4].v[q] + kf);
+        const float c = (f0 * cA.v[q] + f1 * cB.v[q]) + i * u;          // as lstm_pair_fwd forms it
+        const float tc = tanhf(c);
+        const float dh = pn * dGh.v[q];
+        const float dc = pn * dGc.v[q] + (dh * o) * (1.f - tc * tc);
+        r.da[0].v[q] = (dc * i) * (1.f - u * u);
+        r.da[1].v[q] = (dc * u) * (i * (1.f - i));
+        r.da[2].v[q] = (dh * tc) * (o * (1.f - o));
+        r.da[3].v[q] = (dc * cA.v[q]) * (f0 * (1.f - f0));
+        r.da[4].v[q] = (dc * cB.v[q]) * (f1 * (1.f - f1));
+        r.dca.v[q] = dc * f0;
+        r.dcb.v[q] = dc * f1;
+    }
     return r;
 }
 
 // One use list of the cell.  OWN_IS_A: the cell is the pair's a operand (left child / sibling) and the partner its b operand.
 //   own[5]: the cell's own gate rows at this column; PP: the partner's gate rows (row stride ldp, first block at PP);
 //   CP: the partner's cell-state chart; SC: the chart / projection the score term multiplies ds with (row stride lds)
-template <bool OWN_IS_A>
-__device__ __forceinline__ void lstm_walk_uses(const UseTab& ut, int c, int b, int bC, int c4, int Dp, const float4 (&own)[5], float4 cown,
+template <bool OWN_IS_A, int W>
+__device__ __forceinline__ void lstm_walk_uses(const UseTab& ut, int c, int b, int bC, int c4, int Dp, const VecW<W> (&own)[5], const VecW<W>& cown,
                                                const float* __restrict__ PP, int ldp, const float* __restrict__ CP, float kf,
                                                const int32_t* __restrict__ trow, const float* __restrict__ Pp, const float* __restrict__ DS,
                                                const float* __restrict__ dGh, const float* __restrict__ dGc, const float* __restrict__ SC, int lds,
-                                               float4 (&dact)[5], float4& vc, float4& sterm, float& vs) {
+                                               VecW<W> (&dact)[5], VecW<W>& vc, VecW<W>& sterm, float& vs) {
     const int beg = ut.off[c], end = ut.off[c + 1];
-    constexpr int NB = 2;                              // uses in flight (16 x 16 B per thread)
+    constexpr int NB = W == 4 ? 2 : 4;                 // uses in flight
     for (int u0 = beg; u0 < end; u0 += NB) {
-        float4 pg[NB][5], pc[NB], gh[NB], gc[NB], sc[NB];
+        VecW<W> pg[NB][5], pc[NB], gh[NB], gc[NB], sc[NB];
         float pn[NB], ds[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -185,28 +214,34 @@ __device__ __forceinline__ void lstm_walk_uses(const UseTab& ut, int c, int b, i
             pn[j] = live ? Pp[r] : 0.f;                // a dead slot re-reads the last use with weight zero: adds exact zeros
             ds[j] = live ? DS[r] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) pg[j][k] = ld4(PP + prow * ldp + (size_t)k * Dp + c4);
-            pc[j] = ld4(CP + prow * Dp + c4);
-            gh[j] = ld4(dGh + tr * Dp + c4);
-            gc[j] = ld4(dGc + tr * Dp + c4);
-            sc[j] = ld4(SC + prow * lds + c4);
+            for (int k = 0; k < 5; ++k) pg[j][k] = vload<W>(PP + prow * ldp + (size_t)k * Dp + c4);
+            pc[j] = vload<W>(CP + prow * Dp + c4);
+            gh[j] = vload<W>(dGh + tr * Dp + c4);
+            gc[j] = vload<W>(dGc + tr * Dp + c4);
+            sc[j] = vload<W>(SC + prow * lds + c4);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            float4 x[5];
+            VecW<W> x[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) x[k] = OWN_IS_A ? f4add(own[k], pg[j][k]) : f4add(pg[j][k], own[k]);     // PL(a) + PR(b), in that order
-            const LstmPairGrad q = lstm_pair_grad(x, OWN_IS_A ? cown : pc[j], OWN_IS_A ? pc[j] : cown, kf, pn[j], gh[j], gc[j]);
+            for (int k = 0; k < 5; ++k)
 #pragma unroll
-            for (int k = 0; k < 5; ++k) dact[k] = f4add(dact[k], q.da[k]);
-            vc = f4add(vc, OWN_IS_A ? q.dca : q.dcb);
-            sterm = f4fma(ds[j], sc[j], sterm);
+                for (int q = 0; q < W; ++q) x[k].v[q] = OWN_IS_A ? own[k].v[q] + pg[j][k].v[q] : pg[j][k].v[q] + own[k].v[q];     // PL(a) + PR(b), in that order
+            const LstmPairGrad<W> g = lstm_pair_grad<W>(x, OWN_IS_A ? cown : pc[j], OWN_IS_A ? pc[j] : cown, kf, pn[j], gh[j], gc[j]);
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dact[k].v[q] += g.da[k].v[q];
+                vc.v[q] += OWN_IS_A ? g.dca.v[q] : g.dcb.v[q];
+                sterm.v[q] = fmaf(ds[j], sc[j].v[q], sterm.v[q]);
+            }
             vs += ds[j];
         }
     }
 }
 
-static __global__ __launch_bounds__(128) void lstm_cell_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
+template <int W>
+static __global__ __launch_bounds__(512) void lstm_cell_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
                                                         const float* __restrict__ dS_ext, UseTab ina, UseTab inb, UseTab outa, int with_outside,
                                                         const int32_t* __restrict__ trow, const float* __restrict__ Pp, const float* __restrict__ DS,
                                                         const float* __restrict__ PI, int ldpi, const float* __restrict__ PO, int ldpo,
@@ -218,38 +253,45 @@ static __global__ __launch_bounds__(128) void lstm_cell_bwd_in(LevelArgs g, int 
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
-    const int Dp = g.Dp, bC = b * g.C, nv = Dp >> 2;
+    const int Dp = g.Dp, bC = b * g.C, nv = Dp / W;
     if (v >= nv) return;
-    const int c4 = 4 * v;
+    const int c4 = W * v;
     const float* mine = PI + crow * ldpi;
-    float4 pl[5], pr[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { pl[k] = ld4(mine + (size_t)k * Dp + c4); pr[k] = ld4(mine + (size_t)(5 + k) * Dp + c4); }
-    const float4 cown = ld4(IC + crow * Dp + c4);
-    float4 dpl[5], dpr[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { dpl[k] = f4zero(); dpr[k] = f4zero(); }
-    float4 dql = f4zero();
-    float4 vh = dH_ext ? ld_ext(dH_ext + crow * D, D, c4) : f4zero();
-    float4 vc = dC_ext ? ld_ext(dC_ext + crow * D, D, c4) : f4zero();
-    float vs = 0.f;
-    // left child: partner = right child (PR blocks), score term ds * H(right)
-    lstm_walk_uses<true>(ina, c, b, bC, c4, Dp, pl, cown, PI + (size_t)5 * Dp, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, IH, Dp, dpl, vc, dql, vs);
-    // right child: partner = left child (PL blocks), score term ds * QL(left)
-    lstm_walk_uses<false>(inb, c, b, bC, c4, Dp, pr, cown, PI, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, PI + (size_t)10 * Dp, ldpi, dpr, vc, vh, vs);
-    // sibling in the outside pass: partner = parent (outside cell, PRo blocks), targets are outside cells, constant 0 (diora.py:174)
-    if (with_outside)
-        lstm_walk_uses<true>(outa, c, b, bC, c4, Dp, pl, cown, PO, ldpo, OC, 0.0f, trow, Pp, DS, dGo, dGco, OH, Dp, dpl, vc, dql, vs);
     float* o = dPI + crow * ldpi;
+    const VecW<W> cown = vload<W>(IC + crow * Dp + c4);
+    VecW<W> vh = dH_ext ? vload_ext<W>(dH_ext + crow * D, D, c4) : vzero<W>();
+    VecW<W> vc = dC_ext ? vload_ext<W>(dC_ext + crow * D, D, c4) : vzero<W>();
+    float vs = 0.f;
+    {   // the cell as a operand (its PL rows): left child in the inside pass, then sibling in the outside pass; one role's rows and
+        // sums are live at a time
+        VecW<W> pl[5], dpl[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { st4(o + (size_t)k * Dp + c4, dpl[k]); st4(o + (size_t)(5 + k) * Dp + c4, dpr[k]); }
-    st4(o + (size_t)10 * Dp + c4, dql);
-    st4(VH + crow * Dp + c4, vh);
-    st4(VC + crow * Dp + c4, vc);
+        for (int k = 0; k < 5; ++k) { pl[k] = vload<W>(mine + (size_t)k * Dp + c4); dpl[k] = vzero<W>(); }
+        VecW<W> dql = vzero<W>();
+        // left child: partner = right child (PR blocks), score term ds * H(right)
+        lstm_walk_uses<true, W>(ina, c, b, bC, c4, Dp, pl, cown, PI + (size_t)5 * Dp, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, IH, Dp, dpl, vc, dql, vs);
+        // sibling in the outside pass: partner = parent (outside cell, PRo blocks), targets are outside cells, constant 0 (diora.py:174)
+        if (with_outside)
+            lstm_walk_uses<true, W>(outa, c, b, bC, c4, Dp, pl, cown, PO, ldpo, OC, 0.0f, trow, Pp, DS, dGo, dGco, OH, Dp, dpl, vc, dql, vs);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vstore<W>(o + (size_t)k * Dp + c4, dpl[k]);
+        vstore<W>(o + (size_t)10 * Dp + c4, dql);
+    }
+    {   // right child: partner = left child (PL blocks), score term ds * QL(left)
+        VecW<W> pr[5], dpr[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { pr[k] = vload<W>(mine + (size_t)(5 + k) * Dp + c4); dpr[k] = vzero<W>(); }
+        lstm_walk_uses<false, W>(inb, c, b, bC, c4, Dp, pr, cown, PI, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, PI + (size_t)10 * Dp, ldpi, dpr, vc, vh, vs);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vstore<W>(o + (size_t)(5 + k) * Dp + c4, dpr[k]);
+    }
+    vstore<W>(VH + crow * Dp + c4, vh);
+    vstore<W>(VC + crow * Dp + c4, vc);
     if (v == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + vs;
 }
 
-static __global__ __launch_bounds__(128) void lstm_cell_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
+template <int W>
+static __global__ __launch_bounds__(512) void lstm_cell_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
                                                          const float* __restrict__ dS_ext, UseTab outb, const int32_t* __restrict__ trow,
                                                          const float* __restrict__ Pp, const float* __restrict__ DS, const float* __restrict__ PI,
                                                          int ldpi, const float* __restrict__ PO, int ldpo, const float* __restrict__ IC,
@@ -260,22 +302,22 @@ static __global__ __launch_bounds__(128) void lstm_cell_bwd_out(LevelArgs g, int
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
-    const int Dp = g.Dp, bC = b * g.C, nv = Dp >> 2;
+    const int Dp = g.Dp, bC = b * g.C, nv = Dp / W;
     if (v >= nv) return;
-    const int c4 = 4 * v;
-    float4 po[5], dpo[5];
+    const int c4 = W * v;
+    VecW<W> po[5], dpo[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { po[k] = ld4(PO + crow * ldpo + (size_t)k * Dp + c4); dpo[k] = f4zero(); }
-    const float4 cown = ld4(OC + crow * Dp + c4);
-    float4 vh = dH_ext ? ld_ext(dH_ext + crow * D, D, c4) : f4zero();
-    float4 vc = dC_ext ? ld_ext(dC_ext + crow * D, D, c4) : f4zero();
+    for (int k = 0; k < 5; ++k) { po[k] = vload<W>(PO + crow * ldpo + (size_t)k * Dp + c4); dpo[k] = vzero<W>(); }
+    const VecW<W> cown = vload<W>(OC + crow * Dp + c4);
+    VecW<W> vh = dH_ext ? vload_ext<W>(dH_ext + crow * D, D, c4) : vzero<W>();
+    VecW<W> vc = dC_ext ? vload_ext<W>(dC_ext + crow * D, D, c4) : vzero<W>();
     float vs = 0.f;
     // parent in the outside pass: partner = sibling (inside cell, PL blocks), score term ds * QL(sibling)
-    lstm_walk_uses<false>(outb, c, b, bC, c4, Dp, po, cown, PI, ldpi, IC, 0.0f, trow, Pp, DS, dGo, dGco, PI + (size_t)10 * Dp, ldpi, dpo, vc, vh, vs);
+    lstm_walk_uses<false, W>(outb, c, b, bC, c4, Dp, po, cown, PI, ldpi, IC, 0.0f, trow, Pp, DS, dGo, dGco, PI + (size_t)10 * Dp, ldpi, dpo, vc, vh, vs);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) st4(dPO + crow * ldpo + (size_t)k * Dp + c4, dpo[k]);
-    st4(VH + crow * Dp + c4, vh);
-    st4(VC + crow * Dp + c4, vc);
+    for (int k = 0; k < 5; ++k) vstore<W>(dPO + crow * ldpo + (size_t)k * Dp + c4, dpo[k]);
+    vstore<W>(VH + crow * Dp + c4, vh);
+    vstore<W>(VC + crow * Dp + c4, vc);
     if (v == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + vs;
 }
 
