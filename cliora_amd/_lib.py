@@ -121,6 +121,8 @@ def lib():
     L.cliora_set_mfma_mode.restype = i32
     L.cliora_set_wavefront.argtypes = [i32]
     L.cliora_set_wavefront.restype = i32
+    L.cliora_set_rows_stationary.argtypes = [i32]
+    L.cliora_set_rows_stationary.restype = i32
     L.cliora_set_persistent.argtypes = [i32]
     L.cliora_set_persistent.restype = i32
     L.cliora_persistent_status.argtypes = [vp, C.POINTER(C.c_uint), vp]
@@ -240,6 +242,16 @@ def set_persistent(mode):
     previous mode."""
     prev = lib().cliora_set_persistent(WAVEFRONT_MODES[mode])
     return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
+
+
+RS_MODES = {'auto': -1, 'off': 0, 'on': 1, 'geometry': 2}
+
+
+def set_rows_stationary(mode):
+    """Rows-stationary forward compose for big levels (include/cliora_chart.h: cliora_set_rows_stationary): 'auto', 'off', 'on'
+    or 'geometry' (its tasks on the weight-stationary kernel: bitwise the same results as 'on').  Returns the previous mode."""
+    prev = lib().cliora_set_rows_stationary(RS_MODES[mode])
+    return {v: k for k, v in RS_MODES.items()}[prev]
 
 
 def persistent_timeouts(plan, stream=0):

@@ -334,6 +334,13 @@ extern "C" int cliora_set_wavefront(int mode) {
 }
 
 int g_cliora_persistent = [] { const char* e = getenv("CLIORA_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+int g_cliora_rows_stationary = [] { const char* e = getenv("CLIORA_ROWS_STATIONARY"); return e ? atoi(e) : -1; }();
+int g_cliora_rs_min_rows = [] { const char* e = getenv("CLIORA_RS_MIN_ROWS"); return e ? atoi(e) : 0x7fffffff; }();
+extern "C" int cliora_set_rows_stationary(int mode) {
+    const int prev = g_cliora_rows_stationary;
+    g_cliora_rows_stationary = mode < 0 ? -1 : std::min(mode, 2);
+    return prev;
+}
 extern "C" int cliora_set_persistent(int mode) {
     const int prev = g_cliora_persistent;
     g_cliora_persistent = mode < 0 ? -1 : (mode != 0 ? 1 : 0);

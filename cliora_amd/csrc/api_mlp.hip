@@ -2,16 +2,46 @@
 // See include/cliora_chart.h for the contract and the reference lines it replaces.
 #include "api_common.hpp"
 #include "level_kernels.hpp"
+#include "compose_rs_kernels.hpp"
 #include "persist_kernels.hpp"
 #include "vl_kernels.hpp"
 
 // ------------------------------------------------------------------ fused level kernels (level_kernels.hpp)
 // Geometry of a level's compose launch: the plan's tasks (plan.cpp compose_geom, shared with the persistent kernel so that both
 // paths sum in the same order) on at most `cap` workgroups per column block.
-struct ComposeLaunch { int TG, SP, ntask, gx; };
-static ComposeLaunch compose_launch(const Plan& p, int level, bool outside_pass) {
+struct ComposeLaunch { int TG, SP, ntask, gx; bool rs; };
+unsigned long long* g_rs_trace_buf = nullptr;      // diagnostic builds (-DCLIORA_RS_STAMPS): the plan's trace words
+// Rows-stationary forward compose (compose_rs_kernels.hpp) for the levels whose operand gathers outweigh re-streaming the weights:
+// measured on MI355X at d 400 (tools/shapes.py, profiles/r03_rows_stationary.txt).  Only the Dp = 400 kernel is instantiated.
+static bool rows_stationary_level(const Plan& p, int ncell, int N, bool vl) {
+    if (g_cliora_rows_stationary == 0 || p.arch != 0 || p.Dp != 400 || N < 1 || N > 8 * HP_PARTS) return false;
+    (void)vl;
+    if (g_cliora_rows_stationary > 0) return true;
+    return (long long)ncell * N >= g_cliora_rs_min_rows;
+}
+static bool plan_has_rows_stationary_levels(const Plan& p) {
+    for (int pass = 0; pass < 2; ++pass)
+        for (int level = pass ? 0 : 1; level < (pass ? p.L - 1 : p.L); ++level) {
+            const int32_t* e = p.persist_levels.data() + ((size_t)(pass ? p.L : 0) + level) * PLEVEL_INTS;
+            if (rows_stationary_level(p, p.B * e[0], e[1], false)) return true;
+        }
+    return false;
+}
+static ComposeLaunch compose_launch(const cliora_plan* plan, int level, bool outside_pass, bool vl) {
+    const Plan& p = plan->p;
     const int32_t* e = p.persist_levels.data() + ((size_t)(outside_pass ? p.L : 0) + level) * PLEVEL_INTS;
-    ComposeLaunch q{e[5], e[6], e[7], std::min(e[7], p.compose_cap)};
+    if (rows_stationary_level(p, p.B * e[0], e[1], vl)) {
+        const ComposeGeom q = compose_geom_rs(p.B * e[0], e[1]);
+        if (q.TG > 0) {
+            if (g_cliora_rows_stationary == 2) {         // the same tasks on the weight-stationary kernel
+                ComposeLaunch w{q.TG, q.SP, q.ntask, std::min(q.ntask, p.compose_cap), false};
+                if (w.gx >= 8 && (w.gx + 7) / 8 * 8 <= p.compose_cap) w.gx = (w.gx + 7) / 8 * 8;
+                return w;
+            }
+            return ComposeLaunch{q.TG, q.SP, q.ntask, std::min(q.ntask, std::max(1, plan->ncu)), true};
+        }
+    }
+    ComposeLaunch q{e[5], e[6], e[7], std::min(e[7], p.compose_cap), false};
     // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8 the column blocks
     // that gather the same operand rows share one XCD's L2 (speed only, never correctness)
     if (q.gx >= 8 && (q.gx + 7) / 8 * 8 <= p.compose_cap) q.gx = (q.gx + 7) / 8 * 8;
@@ -42,6 +72,24 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? W : Wimg);
     const int S = f32 ? Dp : S3;
+    if (q.rs) {
+        unsigned long long* rs_trace = nullptr;
+#ifdef CLIORA_RS_STAMPS
+        { static const char* e = getenv("CLIORA_RS_TRACE_ROWS"); if (e && g_rs_trace_buf && lv.ncell * lv.N == atoi(e)) rs_trace = g_rs_trace_buf; }
+#endif
+        if (ct != 5 || Dp != 400 || (lv.N + q.SP - 1) / q.SP > 8 / q.TG) return fail(CLIORA_EINVAL, "rows-stationary compose: shape or geometry not covered");
+        if (f32) {
+            OKR(cliora_ensure_max_lds((const void*)level_compose_fwd_rs<5, 25, true>));
+            hipLaunchKernelGGL((level_compose_fwd_rs<5, 25, true>), dim3(q.gx), dim3(512), rs_lds_bytes<5>(), st, I, S, lv, PA, lda, PB, ldb, bias, Pp,
+                               q.TG, q.SP, q.ntask, ncb, HP, hp_stride, Dp, ymask, Y, rs_trace);
+        } else {
+            OKR(cliora_ensure_max_lds((const void*)level_compose_fwd_rs<5, 25, false>));
+            hipLaunchKernelGGL((level_compose_fwd_rs<5, 25, false>), dim3(q.gx), dim3(512), rs_lds_bytes<5>(), st, I, S, lv, PA, lda, PB, ldb, bias, Pp,
+                               q.TG, q.SP, q.ntask, ncb, HP, hp_stride, Dp, ymask, Y, rs_trace);
+        }
+        LAUNCHOK("level_compose_fwd_rs");
+        return CLIORA_OK;
+    }
 #define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, q
 #define LC_CASE(c, k16) return f32 ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
     if (ct == 5 && Dp == 400) LC_CASE(5, 25);
@@ -111,6 +159,7 @@ static int launch_level_project_sp(hipStream_t st, int SP, const float* Wfrag, i
     switch (SP) {
         case 1: return launch_level_project_inst<CT, 1>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
         case 2: return launch_level_project_inst<CT, 2>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+        case 3: return launch_level_project_inst<CT, 3>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
         default: return launch_level_project_inst<CT, 4>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
     }
 }
@@ -146,6 +195,7 @@ static bool wavefront_pays(const Plan& p, int env) {
 static bool persist_pays(const cliora_plan* plan, bool vl) {
     const Plan& p = plan->p;
     if (g_cliora_persistent == 0 || vl || p.arch != 0 || p.L < 2) return false;
+    if (plan_has_rows_stationary_levels(p)) return false;       // their geometry is not the plan's (the kernel's level table)
     if (g_cliora_persistent < 0 && p.Dp > 64) return false;
     const size_t lim = 0xfff00000ull;
     const size_t BC = (size_t)p.B * p.C;
@@ -324,7 +374,8 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
-        const ComposeLaunch cq = compose_launch(p, level, false);
+        g_rs_trace_buf = reinterpret_cast<unsigned long long*>(plan->persist_status + 16);
+        const ComposeLaunch cq = compose_launch(plan, level, false, vl);
         const int SP = cq.SP;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sa);
@@ -356,7 +407,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     auto outside_step = [&](int level) -> int {         // diora.py:358-398 for one level
         const LevelArgs g = level_args(p, level, true);
         const int ncell = B * g.Lc;
-        const ComposeLaunch cq = compose_launch(p, level, true);
+        const ComposeLaunch cq = compose_launch(plan, level, true, vl);
         const int SP = cq.SP;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sb);

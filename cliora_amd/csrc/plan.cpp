@@ -33,6 +33,20 @@ ComposeGeom compose_geom(int ncell, int N, int cap) {
     return best;
 }
 
+ComposeGeom compose_geom_rs(int ncell, int N) {
+    const int G = (ncell + 15) / 16;
+    ComposeGeom best{0, 0, 0};
+    int best_slots = 1 << 30;
+    for (int SP = 1; SP <= HP_PARTS && SP <= std::max(1, N); ++SP)
+        for (int TG : {8, 4, 2, 1}) {                   // more cell tiles per task first: less idle at equal slot count
+            const int wpg = 8 / TG;
+            if ((N + SP - 1) / SP > wpg) continue;
+            const int slots = SP * wpg;
+            if (slots < best_slots) { best_slots = slots; best = ComposeGeom{TG, SP, (G + TG - 1) / TG * SP}; }
+        }
+    return best;
+}
+
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch) {
     if (B < 1 || L < 1 || D < 1) return "B, L, D must be positive";
     if (D > 512) return "D > 512 is not supported by the weight-stationary kernels";

@@ -121,6 +121,9 @@ struct Plan {
 // each), the split range cut in SP parts, ntask = ceil(G / TG) * SP workgroup tasks; `cap` workgroups per column block.
 struct ComposeGeom { int TG, SP, ntask; };
 ComposeGeom compose_geom(int ncell, int N, int cap);
+// Geometry of the rows-stationary compose kernel (compose_rs_kernels.hpp): every wave takes ONE split, so a task covers
+// SP x (8 / TG) split slots >= N; the fullest slot table wins, fewer parts on a tie.  TG = 0: no such geometry (N > 32).
+ComposeGeom compose_geom_rs(int ncell, int N);
 
 // Builds every host table and the workspace layouts.  Returns "" or an error message.
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch = 0);

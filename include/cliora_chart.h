@@ -312,6 +312,21 @@ int cliora_set_wavefront(int mode);
 int cliora_set_persistent(int mode);
 int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
 
+/* Rows-stationary forward compose (csrc/compose_rs_kernels.hpp) for the big levels of a d = 400 DioraMLP / CLIORA plan: the two
+ * operand rows of a span pair (cliora/net/diora.py:112-118, get_inside_states) are gathered ONCE and kept in registers while the
+ * second compose layer's weight (diora.py:65-72) streams through LDS, instead of once per block of 80 output columns.  AUTO
+ * (default; CLIORA_ROWS_STATIONARY=0|1 sets the initial value) takes it for the levels with at least CLIORA_RS_MIN_ROWS pair rows
+ * and at most 32 splits -- no level by default: on MI355X the kernel ties with the weight-stationary one at L = 40 and loses
+ * below (DESIGN.md section 4c has the in-kernel trace); ON for every level with at most 32 splits; OFF never.  GEOMETRY_ONLY (2, tests) deals the tasks
+ * the rows-stationary way but runs them on the weight-stationary kernel: with the same tasks the two kernels agree to the bit.
+ * The split range of a cell is cut into parts differently in the two geometries, so AUTO / ON and OFF agree to fp32 rounding of
+ * the aggregate (sum over the splits), not to the bit.  Process-wide; returns the previous mode. */
+#define CLIORA_ROWS_STATIONARY_AUTO (-1)
+#define CLIORA_ROWS_STATIONARY_OFF 0
+#define CLIORA_ROWS_STATIONARY_ON 1
+#define CLIORA_ROWS_STATIONARY_GEOMETRY_ONLY 2
+int cliora_set_rows_stationary(int mode);
+
 /* Float offset of a named region of the forward workspace ("pi", "po", "hp", "hp_o", "sp", "pp", "ymask", "nrmi", "nrmo", "t",
  * "qrleaf", "sync", "total"), for tests and tooling that compare two runs region by region; (size_t)-1 for an unknown name. */
 size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* name);
