@@ -22,6 +22,8 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     const Plan& p = plan->p;
     if (p.arch != 1) return fail(CLIORA_EINVAL, "not a TreeLSTM plan (create it with cliora_plan_create_ex(..., arch = 1))");
     if (!P->lstm_w || !P->lstm_u || !P->lstm_b || !P->in_mat || !P->root_h || !P->root_c) return fail(CLIORA_EINVAL, "missing TreeLSTM parameter");
+    if (!p.share && (!P->lstm_u_out || !P->lstm_b_out || !P->out_mat))
+        return fail(CLIORA_EINVAL, "share = 0: missing outside TreeLSTM parameter (lstm_u_out, lstm_b_out, out_mat)");
     if (fwd_ws_bytes < p.fwd.total * sizeof(float)) return fail(CLIORA_ENOMEM, "forward workspace too small");
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
@@ -30,9 +32,11 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     const Dev dv = dev_views(p);
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
-    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, ldpi = 11 * Dp, ldpo = 5 * Dp;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, ldpi = p.nblk * Dp, ldpo = 5 * Dp;
     const size_t DD = (size_t)Dp * Dp;
     const bool padded = D != Dp;
+    // outside functions: the inside ones (diora.py:459-461) or their own U, B, mat (share = 0)
+    const float* Uo = p.share ? P->lstm_u : P->lstm_u_out;
     float *IH = padded ? ws + f.ihp : inside_h, *OH = padded ? ws + f.ohp : outside_h;
     float *IC = padded ? ws + f.icp : inside_c, *OC = padded ? ws + f.ocp : outside_c;
     float *IS = inside_s, *OS = outside_s;
@@ -51,6 +55,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         }
         add_copy(t, ws + f.wcat + 10 * DD, Dp, Dp, Dp, P->in_mat, D, D, D, 0, 0, 1);
         add_copy(t, ws + f.bcat + 5 * Dp, Dp, 1, 6 * Dp, nullptr, 0, 0, 0, 0, 0, 0);
+        if (!p.share) add_copy(t, ws + f.bcat + 16 * Dp, Dp, 1, Dp, nullptr, 0, 0, 0, 0, 0, 0);
         add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
         add_copy(t, ws + f.rootc, Dp, 1, Dp, P->root_c, D, 1, D, 0, 0, 0);
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
@@ -59,11 +64,22 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         for (int g = 0; g < 5; ++g) {
             add_copy(u, ws + f.wcatT + g * Dp, ldpi, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, 0, 1);
             add_copy(u, ws + f.wcatT + (5 + g) * Dp, ldpi, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 1);
-            add_copy(u, ws + f.w1ro + g * DD, Dp, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 0);
-            add_copy(u, ws + f.w1roT + g * Dp, ldpo, Dp, Dp, P->lstm_u, 2 * D, D, D, g * D, D, 1);
+            add_copy(u, ws + f.w1ro + g * DD, Dp, Dp, Dp, Uo, 2 * D, D, D, g * D, D, 0);           // PRo gate g: the outside U[:, D:]
+            add_copy(u, ws + f.w1roT + g * Dp, ldpo, Dp, Dp, Uo, 2 * D, D, D, g * D, D, 1);
         }
         add_copy(u, ws + f.wcatT + 10 * Dp, ldpi, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
         OKR(run_copies(st, u));
+        if (!p.share) {        // blocks 11..15: PLo = U_out[:, :D] h + B_out, block 16: QLo = mat_out^T h, of every inside cell
+            CopyTable v; v.n = 0;
+            for (int g = 0; g < 5; ++g) {
+                add_copy(v, ws + f.wcat + (11 + g) * DD, Dp, Dp, Dp, P->lstm_u_out, 2 * D, D, D, g * D, 0, 0);
+                add_copy(v, ws + f.wcatT + (11 + g) * Dp, ldpi, Dp, Dp, P->lstm_u_out, 2 * D, D, D, g * D, 0, 1);
+                add_copy(v, ws + f.bcat + (11 + g) * Dp, Dp, 1, Dp, P->lstm_b_out, 5 * D, 1, D, 0, g * D, 0);
+            }
+            add_copy(v, ws + f.wcat + 16 * DD, Dp, Dp, Dp, P->out_mat, D, D, D, 0, 0, 1);
+            add_copy(v, ws + f.wcatT + 16 * Dp, ldpi, Dp, Dp, P->out_mat, D, D, D, 0, 0, 0);
+            OKR(run_copies(st, v));
+        }
         {
             ImageList pj;
             pj.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
@@ -103,11 +119,11 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     auto outside_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, true);
         const int ncell = B * g.Lc, nrows = ncell * g.N;
-        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, sb, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, OH, IS, OS,
+        hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, sb, g, dv.arow, dv.brow, ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS,
                            ws + f.sp, ws + f.pp, OS);
         LAUNCHOK("pair_scores_fwd(out)");
-        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, sb, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
-                           ws + f.po, ldpo, IC, OC, 0.0f, ws + f.y, ws + f.x);
+        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, sb, g.rowbase, nrows, Dp, dv.arow, dv.brow,
+                           ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, ldpo, IC, OC, 0.0f, ws + f.y, ws + f.x);
         LAUNCHOK("lstm_pair_fwd(out)");
         hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, sb, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, OH, OC,
                            ws + f.nrmo, ws + f.nrmoc);
@@ -181,7 +197,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     float* wb = (float*)bwd_ws;
     const FwdLayout& f = p.fwd;
     const BwdLayout& bw = p.bwd;
-    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, ldpi = 11 * Dp, ldpo = 5 * Dp;
+    const int B = p.B, L = p.L, D = p.D, Dp = p.Dp, C = p.C, ldpi = p.nblk * Dp, ldpo = 5 * Dp;
     const size_t DD = (size_t)Dp * Dp;
     const bool padded = D != Dp;
     const float *IH = padded ? ws + f.ihp : inside_h, *OH = padded ? ws + f.ohp : outside_h;
@@ -199,7 +215,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         const LevelArgs g = level_args(p, level, true);
         const int ncell = B * g.Lc;
         hipLaunchKernelGGL(lstm_cell_bwd_out<LSTM_W>, dim3(ncell), dim3((Dp / LSTM_W + 63) / 64 * 64), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os, dv.use[ROLE_OUTB], dv.trow,
-                           Pp, DS, PI, ldpi, PO, ldpo, IC, OC, dGo, dGco, dPO, VHo, VCo, dStoto);
+                           Pp, DS, PI, ldpi, p.blk_plo, p.blk_qlo, PO, ldpo, IC, OC, dGo, dGco, dPO, VHo, VCo, dStoto);
         LAUNCHOK("lstm_cell_bwd_out");
         if (level >= 1)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
@@ -219,7 +235,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
         hipLaunchKernelGGL(lstm_cell_bwd_in<LSTM_W>, dim3(ncell), dim3((Dp / LSTM_W + 63) / 64 * 64), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA], dv.use[ROLE_INB],
-                           dv.use[ROLE_OUTA], ran_outside, dv.trow, Pp, DS, PI, ldpi, PO, ldpo, IH, IC, OH, OC, dG, dGc, dGo, dGco, dPI, VH, VC, dStot);
+                           dv.use[ROLE_OUTA], ran_outside, dv.trow, Pp, DS, PI, ldpi, p.blk_plo, p.blk_qlo, PO, ldpo, IH, IC, OH, OC, dG, dGc, dGo, dGco, dPI, VH, VC, dStot);
         LAUNCHOK("lstm_cell_bwd_in");
         if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
@@ -268,8 +284,11 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         for (int g = 0; g < 5; ++g) {
             if (G->lstm_u) {
                 add_copy(t, G->lstm_u + (size_t)g * D * 2 * D, 2 * D, D, D, wb + bw.gwcat + g * DD, Dp, D, D, 0, 0, 0);
-                add_copy(t, G->lstm_u + (size_t)g * D * 2 * D + D, 2 * D, D, D, wb + bw.gwcat + (5 + g) * DD, Dp, D, D, 0, 0, 0,
-                         wb + bw.gw1ro + g * DD, Dp, D, D, 0, 0, 0);
+                if (p.share)      // U[:, D:] serves the inside right child and the outside parent
+                    add_copy(t, G->lstm_u + (size_t)g * D * 2 * D + D, 2 * D, D, D, wb + bw.gwcat + (5 + g) * DD, Dp, D, D, 0, 0, 0,
+                             wb + bw.gw1ro + g * DD, Dp, D, D, 0, 0, 0);
+                else
+                    add_copy(t, G->lstm_u + (size_t)g * D * 2 * D + D, 2 * D, D, D, wb + bw.gwcat + (5 + g) * DD, Dp, D, D, 0, 0, 0);
             }
             if (G->lstm_b) {
                 if (g < 3) add_copy(t, G->lstm_b + g * D, D, 1, D, wb + bw.gbcat + g * Dp, Dp, 1, D, 0, 0, 0, wb + bw.gbl + g * Dp, Dp, 1, D, 0, 0, 0);
@@ -282,6 +301,18 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         if (G->root_h) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
         if (G->root_c) add_copy(t, G->root_c, D, 1, D, wb + bw.grootc, Dp, 1, D, 0, 0, 0);
         OKR(run_copies(st, t));
+        if (!p.share) {
+            CopyTable v; v.n = 0;
+            for (int g = 0; g < 5; ++g) {
+                if (G->lstm_u_out) {
+                    add_copy(v, G->lstm_u_out + (size_t)g * D * 2 * D, 2 * D, D, D, wb + bw.gwcat + (11 + g) * DD, Dp, D, D, 0, 0, 0);
+                    add_copy(v, G->lstm_u_out + (size_t)g * D * 2 * D + D, 2 * D, D, D, wb + bw.gw1ro + g * DD, Dp, D, D, 0, 0, 0);
+                }
+                if (G->lstm_b_out) add_copy(v, G->lstm_b_out + g * D, D, 1, D, wb + bw.gbcat + (11 + g) * Dp, Dp, 1, D, 0, 0, 0);
+            }
+            if (G->out_mat) add_copy(v, G->out_mat, D, D, D, wb + bw.gwcat + 16 * DD, Dp, D, D, 0, 0, 1);
+            OKR(run_copies(st, v));
+        }
     }
     return CLIORA_OK;
 }

@@ -244,7 +244,7 @@ template <int W>
 static __global__ __launch_bounds__(512) void lstm_cell_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
                                                         const float* __restrict__ dS_ext, UseTab ina, UseTab inb, UseTab outa, int with_outside,
                                                         const int32_t* __restrict__ trow, const float* __restrict__ Pp, const float* __restrict__ DS,
-                                                        const float* __restrict__ PI, int ldpi, const float* __restrict__ PO, int ldpo,
+                                                        const float* __restrict__ PI, int ldpi, int blk_plo, int blk_qlo, const float* __restrict__ PO, int ldpo,
                                                         const float* __restrict__ IH, const float* __restrict__ IC, const float* __restrict__ OH,
                                                         const float* __restrict__ OC, const float* __restrict__ dGi, const float* __restrict__ dGci,
                                                         const float* __restrict__ dGo, const float* __restrict__ dGco, float* __restrict__ dPI,
@@ -262,20 +262,29 @@ static __global__ __launch_bounds__(512) void lstm_cell_bwd_in(LevelArgs g, int 
     VecW<W> vh = dH_ext ? vload_ext<W>(dH_ext + crow * D, D, c4) : vzero<W>();
     VecW<W> vc = dC_ext ? vload_ext<W>(dC_ext + crow * D, D, c4) : vzero<W>();
     float vs = 0.f;
-    {   // the cell as a operand (its PL rows): left child in the inside pass, then sibling in the outside pass; one role's rows and
-        // sums are live at a time
+    {   // the cell as a operand: left child in the inside pass (its PL rows), then sibling in the outside pass (the same rows when the
+        // outside functions are the inside ones, else its PLo rows of the outside weights); one role's rows and sums are live at a time
         VecW<W> pl[5], dpl[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) { pl[k] = vload<W>(mine + (size_t)k * Dp + c4); dpl[k] = vzero<W>(); }
         VecW<W> dql = vzero<W>();
         // left child: partner = right child (PR blocks), score term ds * H(right)
         lstm_walk_uses<true, W>(ina, c, b, bC, c4, Dp, pl, cown, PI + (size_t)5 * Dp, ldpi, IC, 1.0f, trow, Pp, DS, dGi, dGci, IH, Dp, dpl, vc, dql, vs);
+        if (blk_plo != 0) {                 // unshared: the inside blocks are done, the sibling role has its own
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                vstore<W>(o + (size_t)k * Dp + c4, dpl[k]);
+                pl[k] = vload<W>(mine + (size_t)(blk_plo + k) * Dp + c4); dpl[k] = vzero<W>();
+            }
+            vstore<W>(o + (size_t)10 * Dp + c4, dql);
+            dql = vzero<W>();
+        }
         // sibling in the outside pass: partner = parent (outside cell, PRo blocks), targets are outside cells, constant 0 (diora.py:174)
         if (with_outside)
             lstm_walk_uses<true, W>(outa, c, b, bC, c4, Dp, pl, cown, PO, ldpo, OC, 0.0f, trow, Pp, DS, dGo, dGco, OH, Dp, dpl, vc, dql, vs);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) vstore<W>(o + (size_t)k * Dp + c4, dpl[k]);
-        vstore<W>(o + (size_t)10 * Dp + c4, dql);
+        for (int k = 0; k < 5; ++k) vstore<W>(o + (size_t)(blk_plo + k) * Dp + c4, dpl[k]);
+        vstore<W>(o + (size_t)blk_qlo * Dp + c4, dql);
     }
     {   // right child: partner = left child (PL blocks), score term ds * QL(left)
         VecW<W> pr[5], dpr[5];
@@ -294,7 +303,7 @@ template <int W>
 static __global__ __launch_bounds__(512) void lstm_cell_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dC_ext,
                                                          const float* __restrict__ dS_ext, UseTab outb, const int32_t* __restrict__ trow,
                                                          const float* __restrict__ Pp, const float* __restrict__ DS, const float* __restrict__ PI,
-                                                         int ldpi, const float* __restrict__ PO, int ldpo, const float* __restrict__ IC,
+                                                         int ldpi, int blk_plo, int blk_qlo, const float* __restrict__ PO, int ldpo, const float* __restrict__ IC,
                                                          const float* __restrict__ OC, const float* __restrict__ dGo, const float* __restrict__ dGco,
                                                          float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ VC,
                                                          float* __restrict__ dStot) {
@@ -312,8 +321,9 @@ static __global__ __launch_bounds__(512) void lstm_cell_bwd_out(LevelArgs g, int
     VecW<W> vh = dH_ext ? vload_ext<W>(dH_ext + crow * D, D, c4) : vzero<W>();
     VecW<W> vc = dC_ext ? vload_ext<W>(dC_ext + crow * D, D, c4) : vzero<W>();
     float vs = 0.f;
-    // parent in the outside pass: partner = sibling (inside cell, PL blocks), score term ds * QL(sibling)
-    lstm_walk_uses<false, W>(outb, c, b, bC, c4, Dp, po, cown, PI, ldpi, IC, 0.0f, trow, Pp, DS, dGo, dGco, PI + (size_t)10 * Dp, ldpi, dpo, vc, vh, vs);
+    // parent in the outside pass: partner = sibling (inside cell; its PL / QL blocks of the outside functions), score term ds * QL(sibling)
+    lstm_walk_uses<false, W>(outb, c, b, bC, c4, Dp, po, cown, PI + (size_t)blk_plo * Dp, ldpi, IC, 0.0f, trow, Pp, DS, dGo, dGco,
+                             PI + (size_t)blk_qlo * Dp, ldpi, dpo, vc, vh, vs);
 #pragma unroll
     for (int k = 0; k < 5; ++k) vstore<W>(dPO + crow * ldpo + (size_t)k * Dp + c4, dpo[k]);
     vstore<W>(VH + crow * Dp + c4, vh);

@@ -56,15 +56,15 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
     p.B = B; p.L = L; p.D = D; p.Dp = (D + 15) / 16 * 16; p.C = ncells(L);
     p.share = share ? 1 : 0; p.normalize = normalize; p.R = R;
     if (arch != 0 && arch != 1) return "arch must be 0 (MLP) or 1 (TreeLSTM)";
-    if (arch == 1 && (!share || R != 0)) return "TreeLSTM plans need share=1 and R=0";
+    if (arch == 1 && R != 0) return "TreeLSTM plans are text-only (R = 0)";
     p.arch = arch;
     if (arch == 0) {
         p.nblk = p.share ? 3 : 5; p.npo = 1; p.nleaf = 1; p.off_pr = 1; p.off_ql = 2;
         p.blk_plo = p.share ? 0 : 3;
         p.blk_qlo = p.share ? 2 : 4;
-    } else {   // [PL (5 gates: u,i,o,f0,f1) | PR (5) | QL]
-        p.nblk = 11; p.npo = 5; p.nleaf = 3; p.off_pr = 5; p.off_ql = 10;
-        p.blk_plo = 0; p.blk_qlo = 10;
+    } else {   // [PL (5 gates: u,i,o,f0,f1) | PR (5) | QL] and, with unshared outside functions, [PLo (5) | QLo] of the outside weights
+        p.nblk = p.share ? 11 : 17; p.npo = 5; p.nleaf = 3; p.off_pr = 5; p.off_ql = 10;
+        p.blk_plo = p.share ? 0 : 11; p.blk_qlo = p.share ? 10 : 16;
     }
     p.P_in = (L - 1) * L * (L + 1) / 6;
     p.P_out = (L - 1) * L * (L + 1) / 3;

@@ -4,12 +4,14 @@ PARITY UNPINNED.  This tree of the reference cannot build a TreeLSTM model: ``bu
 for any ``--arch`` but ``mlp`` (cliora/net/trainer.py:518-526) and the composition exists only as
 commented-out text (cliora/net/vg.py:28-76).  What is implemented is that text on the
 ``DioraBase`` skeleton (cliora/net/diora.py:205-450) the way the original DIORA wires it: inside and
-outside functions shared, ``constant`` = 1 inside and 0 outside (diora.py:174), and
-``root_vector_out_c`` a parameter (the hint at diora.py:470-471).  The oracle's restatement is
+outside functions shared or (``share=False``, diora.py:459-464) a second compose / score module for the
+outside pass, ``constant`` = 1 inside and 0 outside (diora.py:174), and ``root_vector_out_c`` a
+parameter (the hint at diora.py:470-471).  The oracle's restatement is
 checked against the commented text executed in memory (tests/golden/treelstm_recon.npz).
 
 Parameters: ``inside_compose_func.W (3D,D)``, ``.U (5D,2D)``, ``.B (5D)``, ``inside_score_func.mat``,
-``root_vector_out_h``, ``root_vector_out_c`` (``outside_*`` alias the inside modules).
+``root_vector_out_h``, ``root_vector_out_c``; ``outside_*`` alias the inside modules, or with ``share=False`` are
+``outside_compose_func.{U, B}`` and ``outside_score_func.mat`` of their own.
 """
 import ctypes as C
 
@@ -34,7 +36,7 @@ class TreeLSTM(nn.Module):
 class LSTMChartFunction(torch.autograd.Function):
     """cliora_lstm_forward / cliora_lstm_backward; six chart outputs (h, c, s for inside and outside)."""
 
-    NAMES = ('lstm_w', 'lstm_u', 'lstm_b', 'in_mat', 'root_h', 'root_c')
+    NAMES = ('lstm_w', 'lstm_u', 'lstm_b', 'in_mat', 'root_h', 'root_c', 'lstm_u_out', 'lstm_b_out', 'out_mat')
 
     @staticmethod
     @_lib.on_device(lambda ctx, plan, holder, run_outside, x_span, *a: x_span)
@@ -43,7 +45,7 @@ class LSTMChartFunction(torch.autograd.Function):
             raise _lib.ChartLibError('the chart path runs on the GPU only (got a CPU tensor)')
         B, D, Cc = plan.B, plan.D, plan.C
         x_span = x_span.contiguous().float()
-        ptens = {n: p.detach().contiguous() for n, p in zip(LSTMChartFunction.NAMES, params)}
+        ptens = {n: p.detach().contiguous() for n, p in zip(LSTMChartFunction.NAMES, params) if p is not None}
         dev = x_span.device
         new = lambda w: torch.empty((B, Cc, w), device=dev, dtype=torch.float32)
         ih, ic, is_, oh, oc, os_ = new(D), new(D), new(1), new(D), new(D), new(1)
@@ -74,17 +76,19 @@ class LSTMChartFunction(torch.autograd.Function):
                                             _ptr(os_), *[_ptr(g) for g in cots], _ptr(ctx.ws), plan.fwd_bytes, _ptr(wsb),
                                             plan.bwd_bytes, _ptr(d_x), C.byref(gst), ctx.run_outside, _stream())
         _lib.check(rc, 'cliora_lstm_backward')
-        return (None, None, None, d_x) + tuple(grads[n] for n in LSTMChartFunction.NAMES)
+        return (None, None, None, d_x) + tuple(grads.get(n) for n in LSTMChartFunction.NAMES)
 
 
 class DioraTreeLSTM(DioraBase):
     def init_parameters(self):
-        if not self.share:
-            raise NotImplementedError('DioraTreeLSTM is built with shared inside/outside functions only')
         self.inside_score_func = Bilinear(self.size)
         self.inside_compose_func = TreeLSTM(self.size, leaf=True)
-        self.outside_score_func = self.inside_score_func
-        self.outside_compose_func = self.inside_compose_func
+        if self.share:
+            self.outside_score_func = self.inside_score_func
+            self.outside_compose_func = self.inside_compose_func
+        else:                       # diora.py:462-464
+            self.outside_score_func = Bilinear(self.size)
+            self.outside_compose_func = TreeLSTM(self.size)
         self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
         self.root_vector_out_c = nn.Parameter(torch.empty(self.size))
 
@@ -97,11 +101,12 @@ class DioraTreeLSTM(DioraBase):
         B, L, D = x_span.shape
         assert D == self.size
         dev_index = x_span.device.index if x_span.is_cuda else -1
-        plan = _lib.get_plan(B, L, D, True, self.normalize, 0, dev_index, arch=1)
-        cf = self.inside_compose_func
+        plan = _lib.get_plan(B, L, D, self.share, self.normalize, 0, dev_index, arch=1)
+        cf, of = self.inside_compose_func, self.outside_compose_func
+        outer = (None, None, None) if self.share else (of.U, of.B, self.outside_score_func.mat)
         holder = []
         ih, ic, is_, oh, oc, os_ = LSTMChartFunction.apply(plan, holder, bool(self.outside), x_span, cf.W, cf.U, cf.B,
-                                                           self.inside_score_func.mat, self.root_vector_out_h, self.root_vector_out_c)
+                                                           self.inside_score_func.mat, self.root_vector_out_h, self.root_vector_out_c, *outer)
         ch = Chart()
         ch.inside_h, ch.inside_c, ch.inside_s, ch.outside_h, ch.outside_c, ch.outside_s = ih, ic, is_, oh, oc, os_
         self.chart = ch

@@ -57,9 +57,12 @@ typedef struct cliora_params {
     float *in_w1, *in_b1, *in_w2, *in_b2, *in_mat;
     float *out_w1, *out_b1, *out_w2, *out_b2, *out_mat;
     float *root_h;
-    /* DioraTreeLSTM only (composition of cliora/net/vg.py:28-76, shared inside/outside):
-     * lstm_w (3D,D) leaf, lstm_u (5D,2D), lstm_b (5D), root_c (D) = root_vector_out_c */
+    /* DioraTreeLSTM only (composition of cliora/net/vg.py:28-76):
+     * lstm_w (3D,D) leaf, lstm_u (5D,2D), lstm_b (5D), root_c (D) = root_vector_out_c;
+     * share = 0: lstm_u_out (5D,2D), lstm_b_out (5D) = outside_compose_func.{U,B}, and out_mat = outside_score_func.mat
+     * (diora.py:459-464 builds a second compose / score module when the functions are not shared) */
     float *lstm_w, *lstm_u, *lstm_b, *root_c;
+    float *lstm_u_out, *lstm_b_out;
 } cliora_params;
 
 /* A plan fixes (batch B, length L, size D, share, normalize, number of image
@@ -75,7 +78,7 @@ typedef struct cliora_params {
  * cliora/net/utils.py:67-134; cliora_amd/_lib.py keeps an LRU of plans under
  * a byte budget). */
 int cliora_plan_create(int B, int L, int D, int share, int normalize, int R, cliora_plan** out);
-/* arch: 0 = DioraMLP (as above), 1 = DioraTreeLSTM (needs share = 1, R = 0) */
+/* arch: 0 = DioraMLP (as above), 1 = DioraTreeLSTM (text-only: R = 0) */
 int cliora_plan_create_ex(int B, int L, int D, int share, int normalize, int R, int arch, cliora_plan** out);
 void cliora_plan_destroy(cliora_plan* plan);
 

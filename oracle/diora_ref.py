@@ -69,17 +69,21 @@ def init_params(D, share=True, seed=0, compress=False):
     return P
 
 
-def init_params_treelstm(D, seed=0):
-    """DioraTreeLSTM parameters ~ N(0,1) (shared inside/outside functions), in module order:
-    root_vector_out_h, root_vector_out_c, inside_score_func.mat, inside_compose_func.{W (3D,D), U (5D,2D), B (5D)}.
+def init_params_treelstm(D, seed=0, share=True):
+    """DioraTreeLSTM parameters ~ N(0,1), in module order:
+    root_vector_out_h, root_vector_out_c, inside_score_func.mat, inside_compose_func.{W (3D,D), U (5D,2D), B (5D)}, and with
+    share=False (diora.py:462-464) outside_score_func.mat, outside_compose_func.{U, B}.
     RECONSTRUCTION: the class exists in the reference only as commented-out text (cliora/net/vg.py:28-76)."""
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
-    return {
+    P = {
         'root_vector_out_h': rn(D), 'root_vector_out_c': rn(D),
         'inside_score_func.mat': rn(D, D),
         'inside_compose_func.W': rn(3 * D, D), 'inside_compose_func.U': rn(5 * D, 2 * D), 'inside_compose_func.B': rn(5 * D),
     }
+    if not share:
+        P.update({'outside_score_func.mat': rn(D, D), 'outside_compose_func.U': rn(5 * D, 2 * D), 'outside_compose_func.B': rn(5 * D)})
+    return P
 
 
 def treelstm_leaf(P, x):
@@ -92,10 +96,11 @@ def treelstm_leaf(P, x):
     return o * torch.tanh(c), c
 
 
-def treelstm_compose(P, hs, cs, constant=1.0):
+def treelstm_compose(P, hs, cs, constant=1.0, pre='inside'):
     """vg.py:63-76 (commented): [u,i,o,f0,f1] = chunk5([a;b] U^T + B);
-    c = sigmoid(f0+const) c_a + sigmoid(f1+const) c_b + sigmoid(i) tanh(u); h = sigmoid(o) tanh(c)."""
-    act = torch.matmul(torch.cat(hs, 1), P['inside_compose_func.U'].t()) + P['inside_compose_func.B']
+    c = sigmoid(f0+const) c_a + sigmoid(f1+const) c_b + sigmoid(i) tanh(u); h = sigmoid(o) tanh(c).
+    pre: which module's U, B ('outside' for the outside pass of an unshared model)."""
+    act = torch.matmul(torch.cat(hs, 1), P[pre + '_compose_func.U'].t()) + P[pre + '_compose_func.B']
     a = torch.chunk(act, 5, dim=1)
     u, i, o = torch.tanh(a[0]), torch.sigmoid(a[1]), torch.sigmoid(a[2])
     f0, f1 = torch.sigmoid(a[3] + constant), torch.sigmoid(a[4] + constant)
@@ -154,8 +159,9 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
     nrm = _normalizer(normalize)
     lstm = arch == 'treelstm'           # RECONSTRUCTION (parity unpinned): vg.py:28-76 on the DioraBase skeleton
     if lstm:
-        assert share and not vl
-        Win = Wout = dict(M=P['inside_score_func.mat'])
+        assert not vl
+        Win = dict(M=P['inside_score_func.mat'])
+        Wout = Win if share else dict(M=P['outside_score_func.mat'])
     else:
         Win, Wout = _side(P, 'inside', share), _side(P, 'outside', share)
     off = CL.level_offsets(L)
@@ -224,7 +230,7 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
             par_c, sib_c = gp(ch.outside_c, D), gs(ch.inside_c, D)
             par_s, sib_s = gp(ch.outside_s, 1), gs(ch.inside_s, 1)
             if lstm:   # outside_compose passes constant=0 (diora.py:174)
-                ph, pc = treelstm_compose(P, [sib_h, par_h], [sib_c, par_c], 0.0)
+                ph, pc = treelstm_compose(P, [sib_h, par_h], [sib_c, par_c], 0.0, 'inside' if share else 'outside')
             else:
                 ph, pc = compose_mlp(Wout, sib_h, par_h)       # order [sibling, parent] :366-368
             s = (bilinear(Wout['M'], sib_h, par_h) + sib_s + par_s).view(B, -1, Lc, 1)

@@ -269,12 +269,13 @@ def net_case(name, D, B, L, V, K, seed, vl):
     save(name, **arrs)
 
 
-def treelstm_case(name, D, B, L, seed):
+def treelstm_case(name, D, B, L, seed, share=True):
     """RECONSTRUCTION, not tested reference behaviour: the TreeLSTM class exists in the reference only as
     commented-out text (cliora/net/vg.py:28-76).  Here that text is un-commented IN MEMORY, executed, and
     plugged into the live DioraBase skeleton (cliora/net/diora.py:205-450) the way the original DIORA did
-    (inside/outside functions shared, root_vector_out_c a parameter: the hint at diora.py:470-471).
-    Only inputs and outputs are stored."""
+    (inside/outside functions shared -- or, share=False, a second compose / score module for the outside pass as
+    DioraMLP.init_parameters builds them, diora.py:459-464 -- and root_vector_out_c a parameter: the hint at
+    diora.py:470-471).  Only inputs and outputs are stored."""
     import torch.nn as nn
     src = open('/root/reference/cliora/net/vg.py').read().split('\n')[27:76]
     code = '\n'.join(l[2:] if l.startswith('# ') else l.lstrip('#') for l in src)
@@ -286,13 +287,17 @@ def treelstm_case(name, D, B, L, seed):
         def init_parameters(self):
             self.inside_score_func = ref_diora.Bilinear(self.size)
             self.inside_compose_func = TreeLSTM(self.size, leaf=True)
-            self.outside_score_func = self.inside_score_func
-            self.outside_compose_func = self.inside_compose_func
+            if self.share:
+                self.outside_score_func = self.inside_score_func
+                self.outside_compose_func = self.inside_compose_func
+            else:
+                self.outside_score_func = ref_diora.Bilinear(self.size)
+                self.outside_compose_func = TreeLSTM(self.size)
             self.root_vector_out_h = nn.Parameter(torch.FloatTensor(self.size))
             self.root_vector_out_c = nn.Parameter(torch.FloatTensor(self.size))
 
     torch.manual_seed(seed)
-    net = DioraTreeLSTM(D, outside=True, normalize='unit', compress=False, share=True)
+    net = DioraTreeLSTM(D, outside=True, normalize='unit', compress=False, share=share)
     seeded_params(net, seed)
     g = torch.Generator().manual_seed(seed + 1)
     C = L * (L + 1) // 2
@@ -317,7 +322,7 @@ def treelstm_case(name, D, B, L, seed):
     with torch.no_grad():
         net(x.detach(), x.detach())
     trees, spans = run_cky(net, B, L)
-    arrs['meta'] = np.array(json.dumps(dict(META, D=D, B=B, L=L, seed=seed, reconstruction=True,
+    arrs['meta'] = np.array(json.dumps(dict(META, D=D, B=B, L=L, seed=seed, reconstruction=True, share=bool(share),
                                             trees=[tree_to_str(t) for t in trees])))
     save(name, **arrs)
 
@@ -465,5 +470,6 @@ if __name__ == '__main__':
     net_case('net_diora.npz', D=40, B=4, L=6, V=97, K=10, seed=31, vl=False)
     net_case('net_cliora.npz', D=40, B=4, L=6, V=97, K=10, seed=33, vl=True)
     treelstm_case('treelstm_recon.npz', D=24, B=3, L=7, seed=41)
+    treelstm_case('treelstm_recon_noshare.npz', D=24, B=3, L=7, seed=43, share=False)
     sampler_case('sampler_batches.npz')
     interchange_case('interchange.npz')

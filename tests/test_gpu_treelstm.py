@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 KEYS = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
 
 
-def _module(P, D):
+def _module(P, D, share=True):
     from cliora_amd.treelstm import DioraTreeLSTM
-    m = DioraTreeLSTM(D)
+    m = DioraTreeLSTM(D, share=share)
     sd = m.state_dict()
     for k in sd:
         sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].detach().clone()
@@ -29,10 +29,11 @@ def _scale(b):
     return max(1.0, float(np.abs(np.asarray(b)).max()))
 
 
-def test_treelstm_reconstruction_fixture():
-    g = load_golden('treelstm_recon.npz')
+@pytest.mark.parametrize('name', ['treelstm_recon.npz', 'treelstm_recon_noshare.npz'])
+def test_treelstm_reconstruction_fixture(name):
+    g = load_golden(name)
     meta = g['meta']
-    m = _module(params_from_golden(g), meta['D'])
+    m = _module(params_from_golden(g), meta['D'], meta.get('share', True))
     x = torch.from_numpy(g['x_span']).cuda().requires_grad_(True)
     m(x, x)
     for k in KEYS:
@@ -50,19 +51,19 @@ def test_treelstm_reconstruction_fixture():
     assert [str(t) for t in m.cky()] == meta['trees']
 
 
-@pytest.mark.parametrize('D,B,L', [(400, 2, 12), (64, 4, 9)])
-def test_treelstm_against_oracle(D, B, L):
+@pytest.mark.parametrize('D,B,L,share', [(400, 2, 12, True), (64, 4, 9, True), (400, 3, 11, False), (48, 5, 8, False)])
+def test_treelstm_against_oracle(D, B, L, share):
     from oracle import diora_ref as R
-    P = R.init_params_treelstm(D, seed=6)
+    P = R.init_params_treelstm(D, seed=6, share=share)
     gen = torch.Generator().manual_seed(7)
     x = torch.randn(B, L, D, generator=gen)
-    m = _module(P, D)
+    m = _module(P, D, share)
     xg = x.clone().cuda().requires_grad_(True)
     m(xg, xg)
     for v in P.values():
         v.requires_grad_(True)
     xc = x.clone().requires_grad_(True)
-    ref = R.diora_forward(P, xc, xc, arch='treelstm')
+    ref = R.diora_forward(P, xc, xc, arch='treelstm', share=share)
     C = L * (L + 1) // 2
     cot = {k: torch.randn(B, C, 1 if k.endswith('_s') else D, generator=gen) for k in KEYS}
     sum((ref[k] * cot[k]).sum() for k in KEYS).backward()
@@ -103,13 +104,13 @@ def test_treelstm_hooks_receive_the_reference_states():
         assert tuple(h.shape) == (B * N * Lc, D) and _err(h, want_h) <= 1e-4 * _scale(want_h), level
 
 
-@pytest.mark.parametrize('D,B,L', [(400, 8, 14), (48, 3, 6)])
-def test_treelstm_wavefront_is_bitwise_the_sequential_order(D, B, L):
+@pytest.mark.parametrize('D,B,L,share', [(400, 8, 14, True), (48, 3, 6, True), (96, 4, 9, False)])
+def test_treelstm_wavefront_is_bitwise_the_sequential_order(D, B, L, share):
     """TreeLSTM levels on two streams (cliora_set_wavefront) against the one-stream order: every output and gradient bit."""
     from cliora_amd import _lib
     from oracle import diora_ref as R
-    P = R.init_params_treelstm(D, seed=2)
-    m = _module(P, D)
+    P = R.init_params_treelstm(D, seed=2, share=share)
+    m = _module(P, D, share)
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, L, D, generator=g).cuda().requires_grad_(True)
     C = L * (L + 1) // 2

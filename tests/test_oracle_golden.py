@@ -211,16 +211,18 @@ def test_net_losses_and_adam_steps(golden, name, vl):
         close(P[k], g['after3__' + k.replace('.', '__')], tol=2e-4, what='after3 ' + k)
 
 
-def test_treelstm_reconstruction_matches_commented_reference_code(golden):
+@pytest.mark.parametrize('name', ['treelstm_recon.npz', 'treelstm_recon_noshare.npz'])
+def test_treelstm_reconstruction_matches_commented_reference_code(golden, name):
     """TreeLSTM is PARITY-UNPINNED: the reference ships it only as commented-out text (vg.py:28-76).
-    The fixture was made by executing that text against the live DioraBase; the oracle's own
-    restatement must reproduce it."""
-    g = golden('treelstm_recon.npz')
+    The fixture was made by executing that text against the live DioraBase (shared functions, and a second
+    outside compose / score module as diora.py:462-464 builds them); the oracle's own restatement must reproduce it."""
+    g = golden(name)
     m = g['meta']
     assert m['reconstruction']
-    P = {k: v.requires_grad_(True) for k, v in params_from_golden(g).items() if not k.startswith('outside_')}
+    share = m.get('share', True)
+    P = {k: v.requires_grad_(True) for k, v in params_from_golden(g).items() if not (share and k.startswith('outside_'))}
     x = torch.from_numpy(g['x_span']).requires_grad_(True)
-    out = R.diora_forward(P, x, x, arch='treelstm', training=True, keep_pairs=True)
+    out = R.diora_forward(P, x, x, arch='treelstm', training=True, keep_pairs=True, share=share)
     keys = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
     for k in keys:
         close(out[k], g[k], what=k)
