@@ -19,7 +19,7 @@ KCLASS = {'compose_fwd': 0, 'compose_bwd': 1, 'wgrad': 2}
 
 PARAM_FIELDS = ('leaf_w', 'leaf_b', 'in_w1', 'in_b1', 'in_w2', 'in_b2', 'in_mat',
                 'out_w1', 'out_b1', 'out_w2', 'out_b2', 'out_mat', 'root_h',
-                'lstm_w', 'lstm_u', 'lstm_b', 'root_c', 'lstm_u_out', 'lstm_b_out')
+                'lstm_w', 'lstm_u', 'lstm_b', 'root_c', 'lstm_u_out', 'lstm_b_out', 'root_mat')
 
 
 class Params(C.Structure):

@@ -256,7 +256,10 @@ class DioraMLP(DioraBase):
         else:
             self.outside_score_func = Bilinear(self.size)
             self.outside_compose_func = VLComposeMLP(self.size)
-        self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
+        if self.compress:
+            self.root_mat_out = nn.Parameter(torch.empty(self.size, self.size))
+        else:
+            self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
         self.root_vector_out_c = None
         self.dropout_mask = None      # tests inject a (B, C, R) pre-scaled mask here; None = draw one per forward
         self.lazy_region_scores = True   # training mode: all_atten_score is a LazyRegionScores (False: always the dense tensor)

@@ -224,6 +224,9 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         return fail(CLIORA_ENOMEM, "forward workspace has no room for the pair states (cliora_plan_pair_states_bytes)");
     if (!p.share && (!P->out_w1 || !P->out_b1 || !P->out_w2 || !P->out_b2 || !P->out_mat))
         return fail(CLIORA_EINVAL, "share=0 needs the out_* parameters");
+    // compress = True (diora.py:342-343): the outside root is a projection of the inside root, so the passes run one after the other
+    const bool compress = P->root_mat != nullptr;
+    if (!compress && !P->root_h) return fail(CLIORA_EINVAL, "root_h (or root_mat with compress = True) is NULL");
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
@@ -271,7 +274,11 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         add_copy(t, ws + f.w2i, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 0);
         add_copy(t, ws + f.w2iT, Dp, Dp, Dp, P->in_w2, D, D, D, 0, 0, 1);
         add_copy(t, ws + f.b2i, Dp, 1, Dp, P->in_b2, D, 1, D, 0, 0, 0);
-        add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
+        if (!compress) add_copy(t, ws + f.rootp, Dp, 1, Dp, P->root_h, D, 1, D, 0, 0, 0);
+        else {
+            add_copy(t, ws + f.rootw, Dp, Dp, Dp, P->root_mat, D, D, D, 0, 0, 1);      // the projection h -> h M as a Linear weight: M^T
+            add_copy(t, ws + f.rootwT, Dp, Dp, Dp, P->root_mat, D, D, D, 0, 0, 0);
+        }
         add_copy(t, ws + f.matp, Dp, Dp, Dp, P->in_mat, D, D, D, 0, 0, 0);
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
         if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
@@ -285,6 +292,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
             pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
             pj.add(ws + f.matp, ws + f.matq3, Dp, Dp, Dp);
+            if (compress) { pj.add(ws + f.rootw, ws + f.rootw3, Dp, Dp, Dp); pj.add(ws + f.rootwT, ws + f.rootwT3, Dp, Dp, Dp); }
             OKR(build_weight_images(st, im));
             OKR(build_frag_images(st, pj));
         }
@@ -367,8 +375,8 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
-    const bool persist = persist_pays(plan, vl);
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist;
+    const bool persist = !compress && persist_pays(plan, vl);
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
     auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
@@ -436,18 +444,27 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
         fork_guard.arm(0, sb, plan->ev_join[0]);
     }
-    if (run_outside) {       // root of the outside chart (diora.py:337-356) and the scores of the level below it: parents = the root only
-        hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH,
-                           ws + f.nrmo, OS);
-        LAUNCHOK("unit_norm_rows(root)");
-        if (L > 1) {
-            OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
-            if (!persist) OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
+    // root of the outside chart (diora.py:337-356) and the scores of the level below it: parents = the root only.  compress = True:
+    // the root of sentence b is unit(inside_h[b, root] @ root_mat_out) -- one row per sentence, after the inside pass.
+    auto init_root = [&]() -> int {
+        if (run_outside) {
+            if (compress)
+                OKR(launch_rows_direct(sb, ws + f.rootw, PROJ_IMG(f.rootw3), Dp, Dp, B, LevelRowsA{IH, Dp, C, C - 1, 1},
+                                       StoreRowsE{ws + f.rootpb, Dp, nullptr, 0, Dp}));
+            hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, compress ? ws + f.rootpb : ws + f.rootp, compress ? Dp : 0, B, 1,
+                               C, C - 1, Dp, p.normalize, OH, ws + f.nrmo, OS);
+            LAUNCHOK("unit_norm_rows(root)");
+            if (L > 1) {
+                OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
+                if (!persist) OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
+            }
+        } else {
+            HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
+            HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
         }
-    } else {
-        HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
-        HIPOK(hipMemsetAsync(OS, 0, (size_t)B * C * sizeof(float), st));
-    }
+        return CLIORA_OK;
+    };
+    if (!compress) OKR(init_root());
     if (persist) {
         // ---- every level of both passes in one launch (persist_kernels.hpp): the first scores of both chains included ----
         PersistFwd a{};
@@ -484,13 +501,17 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             OKR(inside_step(k));
             if (two_streams) HIPOK(hipEventRecord(plan->ev_level[k], sa));
         }
-        if (run_outside && k >= 2) {
+        if (run_outside && k >= 2 && !compress) {
             const int level = L - k;
             // compose reads the siblings' projections of inside levels <= k-2, the riding scores (level >= 1) those of level k-1
             const int need = level >= 1 ? k - 1 : k - 2;
             if (two_streams && need >= 1) HIPOK(hipStreamWaitEvent(sb, plan->ev_level[need], 0));
             OKR(outside_step(level));
         }
+    }
+    if (compress) {           // the outside pass after the inside pass, on the caller's stream
+        OKR(init_root());
+        for (int level = L - 2; level >= 0 && run_outside; --level) OKR(outside_step(level));
     }
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_join[0], sb));
@@ -513,7 +534,6 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                      const float* d_inside_s, const float* d_outside_h, const float* d_outside_s,
                                      void* fwd_ws, size_t fwd_ws_bytes, void* bwd_ws, size_t bwd_ws_bytes, float* d_x_span,
                                      float* d_obj_span, const cliora_params* G, int ran_outside, void* stream) {
-    (void)P;
     if (!plan || !x_span || !inside_h || !inside_s || !outside_h || !outside_s || !fwd_ws || !bwd_ws || !G)
         return fail(CLIORA_EINVAL, "NULL argument");
     const Plan& p = plan->p;
@@ -564,7 +584,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // The backward of outside level t only feeds inside cells of levels <= L-2-t (its siblings), so the backward of the inside
     // pass does not have to wait for the whole outside backward: step j runs outside level j on the plan's side stream and
     // inside level L-1-j on the caller's stream, which waits for the event of outside step j-1 (see cliora_chart_forward).
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside;
+    // compress = True: the outside root's gradient flows into the inside root, so the outside backward ends before the inside one starts
+    const bool compress = P && P->root_mat;
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside && !compress;
     hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
     float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
 
@@ -578,6 +600,11 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                             StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == L - 1) {
+            if (compress) {      // per-sentence roots: the unit-norm backward of each, kept in dGo for the inside root and d root_mat_out
+                hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, VHo, OH, ws + f.nrmo, p.normalize, dGo);
+                LAUNCHOK("cell_dnorm(root)");
+                return CLIORA_OK;
+            }
             hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, sb, B, C, Dp, VHo, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
             LAUNCHOK("root_bwd");
             return CLIORA_OK;
@@ -609,6 +636,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         LAUNCHOK("cell_gather_bwd_in");
         if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                            StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        else if (compress && ran_outside)       // d inside_h[root] += d root @ root_mat_out^T   (diora.py:342-343)
+            OKR(launch_rows_direct(sa, ws + f.rootwT, PROJ_IMG(f.rootwT3), Dp, Dp, ncell, LevelRowsA{dGo, Dp, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
             hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, sa, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
@@ -647,7 +677,16 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         HIPOK(hipMemsetAsync(wb + bw.gw1ro, 0, (size_t)Dp * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
     }
-    for (int j = 0; j <= L - 1; ++j) {
+    if (compress) {          // the whole outside backward (down to the per-sentence roots), then the inside backward
+        for (int j = 0; j <= L - 1 && ran_outside; ++j) OKR(outside_bwd_step(j));
+        for (int j = 0; j <= L - 1; ++j) OKR(inside_bwd_step(L - 1 - j));
+        if (ran_outside)     // d root_mat_out^T = sum_b d root[b]^T inside_h[b, root]
+            OKR(launch_tn(st, B, Dp, Dp, Dp, LevelRowsA{dGo, Dp, C, C - 1, 1}, LevelRowsA{IH, Dp, C, C - 1, 1}, wb + bw.slab, bw.slab_floats,
+                          wb + bw.groot_mat, (float*)nullptr));
+        else
+            HIPOK(hipMemsetAsync(wb + bw.groot_mat, 0, (size_t)Dp * Dp * sizeof(float), st));
+    }
+    for (int j = 0; j <= L - 1 && !compress; ++j) {
         if (ran_outside) {
             OKR(outside_bwd_step(j));
             if (two_streams) HIPOK(hipEventRecord(plan->ev_level[j], sb));
@@ -710,7 +749,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         if (vl && d_obj_span && padded) add_copy(t, d_obj_span, D, B * p.R, D, wb + bw.dobjp, Dp, B * p.R, D, 0, 0, 0);
         if (G->leaf_w) add_copy(t, G->leaf_w, D, D, D, wb + bw.gwl, Dp, D, D, 0, 0, 0);
         if (G->leaf_b) add_copy(t, G->leaf_b, D, 1, D, wb + bw.gbl, Dp, 1, D, 0, 0, 0);
-        if (G->root_h) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
+        if (G->root_h && !compress) add_copy(t, G->root_h, D, 1, D, wb + bw.groot, Dp, 1, D, 0, 0, 0);
+        if (G->root_mat && compress) add_copy(t, G->root_mat, D, D, D, wb + bw.groot_mat, Dp, D, D, 0, 0, 1);
         if (p.share) {
             if (G->in_w1) {
                 add_copy(t, G->in_w1, 2 * D, D, D, wb + bw.gwcat, Dp, D, D, 0, 0, 0);

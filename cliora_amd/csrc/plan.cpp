@@ -195,6 +195,9 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
         f.sync = take(1280);
+        f.rootw = take(arch == 0 ? Dp * Dp : 0); f.rootwT = take(arch == 0 ? Dp * Dp : 0);
+        f.rootw3 = arch == 0 ? img(Dp, Dp) : o; f.rootwT3 = arch == 0 ? img(Dp, Dp) : o;
+        f.rootpb = take(arch == 0 ? (size_t)B * Dp : 0);
         f.total = o;
         // per-pair compose outputs for the hooks: the TreeLSTM keeps them anyway (y rows), DioraMLP writes them into an
         // optional tail of the workspace only when a hook is overridden
@@ -228,6 +231,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.pmo = take(R > 0 ? BC * 64 : 0);
         b.dsc = take(R > 0 ? BC * 64 : 0);
         b.dobjp = take(R > 0 ? (size_t)B * R * Dp : 0);
+        b.groot_mat = take(arch == 0 ? Dp * Dp : 0);
         b.total = o;
     }
     {

@@ -41,6 +41,7 @@ struct FwdLayout {
     int Kp3, S3;                        // image geometry for K = Dp: k rounded up to 32, row stride in dwords
     size_t wl3, wlT3, wcat3, wcatT3, w1ro3, w1roT3;   // images of the leaf / projection weights and their transposes
     size_t rootp;                       // root vector, padded
+    size_t rootw, rootwT, rootw3, rootwT3, rootpb;   // compress = True (diora.py:342-343): root_mat_out^T / root_mat_out (padded), their fragment images, per-sentence root rows (B x Dp)
     size_t matp, matq3, qrleaf;         // inside score matrix padded (Dp x Dp), its fragment image, and QR = M h of the leaves (B*L x Dp)
     size_t xp, ihp, ohp;                // padded copies (only when D != Dp; else unused)
     size_t objp;                        // padded obj (CLIORA, D != Dp)
@@ -73,7 +74,7 @@ struct BwdLayout {
     size_t dpi, dpo;                    // grads of the projections
     size_t du, dxp;                     // leaf pre-activation grad, padded dx
     size_t slab, slab2;                 // split-K partial sums for the weight-gradient GEMMs (slab2: the side stream's)
-    size_t gwcat, gbcat, gw1ro, gw2i, gb2i, gw2o, gb2o, gwl, gbl, groot;   // packed parameter grads
+    size_t gwcat, gbcat, gw1ro, gw2i, gb2i, gw2o, gb2o, gwl, gbl, groot, groot_mat;   // packed parameter grads (groot_mat: d root_mat_out^T, compress = True)
     size_t dctx, pmo, dsc, dobjp;       // CLIORA: d context (B*C x Dp), p*mask and d score per region (B*C x 64 each), d obj (B*R x Dp)
     size_t total;
     size_t slab_floats;

@@ -131,8 +131,6 @@ class DioraBase(nn.Module):
     def __init__(self, size, word_mat=None, cate_mat=None, outside=True, normalize='unit', compress=False, share=True):
         super().__init__()
         assert normalize in ('none', 'unit'), 'Does not support "{}".'.format(normalize)
-        if compress:
-            raise NotImplementedError('compress=True is never enabled by the reference (trainer.py:552) and is not built')
         self.size = size
         self.share = share
         self.outside = outside
@@ -210,7 +208,11 @@ class DioraBase(nn.Module):
         ic, isf = self.inside_compose_func, self.inside_score_func
         t = dict(leaf_w=ic.leaf_fc.weight, leaf_b=ic.leaf_fc.bias,
                  in_w1=ic.h_fcs[0].weight, in_b1=ic.h_fcs[0].bias, in_w2=ic.h_fcs[2].weight, in_b2=ic.h_fcs[2].bias,
-                 in_mat=isf.mat, root_h=self.root_vector_out_h)
+                 in_mat=isf.mat)
+        if self.compress:           # diora.py:342-343, 466-467: the outside root is inside_h[root] @ root_mat_out
+            t['root_mat'] = self.root_mat_out
+        else:
+            t['root_h'] = self.root_vector_out_h
         if not self.share:
             oc, osf = self.outside_compose_func, self.outside_score_func
             t.update(out_w1=oc.h_fcs[0].weight, out_b1=oc.h_fcs[0].bias, out_w2=oc.h_fcs[2].weight,
@@ -334,5 +336,8 @@ class DioraMLP(DioraBase):
         else:
             self.outside_score_func = Bilinear(self.size)
             self.outside_compose_func = ComposeMLP(self.size)
-        self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
+        if self.compress:
+            self.root_mat_out = nn.Parameter(torch.empty(self.size, self.size))
+        else:
+            self.root_vector_out_h = nn.Parameter(torch.empty(self.size))
         self.root_vector_out_c = None

@@ -81,6 +81,8 @@ class LSTMChartFunction(torch.autograd.Function):
 
 class DioraTreeLSTM(DioraBase):
     def init_parameters(self):
+        if self.compress:
+            raise NotImplementedError('DioraTreeLSTM with compress=True is not built (the reference never enables compress: trainer.py:552)')
         self.inside_score_func = Bilinear(self.size)
         self.inside_compose_func = TreeLSTM(self.size, leaf=True)
         if self.share:

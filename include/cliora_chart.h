@@ -48,7 +48,7 @@ typedef struct cliora_plan cliora_plan;
  *   w1 (D,2D), b1 (D)                 *_compose_func.h_fcs.0.{weight,bias}
  *   w2 (D,D),  b2 (D)                 *_compose_func.h_fcs.2.{weight,bias}
  *   mat (D,D)                         *_score_func.mat
- *   root_h (D)                        root_vector_out_h
+ *   root_h (D)                        root_vector_out_h   (NULL with compress = True: see root_mat below)
  * With share=1 the out_* pointers are ignored (the reference aliases the modules,
  * diora.py:459-461).  The same struct carries gradients (same shapes, written,
  * not accumulated). */
@@ -63,6 +63,9 @@ typedef struct cliora_params {
      * (diora.py:459-464 builds a second compose / score module when the functions are not shared) */
     float *lstm_w, *lstm_u, *lstm_b, *root_c;
     float *lstm_u_out, *lstm_b_out;
+    /* compress = True (diora.py:342-343, 466-467): root_mat (D,D) = root_mat_out replaces root_h -- the outside root of a
+     * sentence is unit(inside_h[root] @ root_mat_out), so the outside pass starts only after the inside pass has ended */
+    float *root_mat;
 } cliora_params;
 
 /* A plan fixes (batch B, length L, size D, share, normalize, number of image

@@ -48,8 +48,9 @@ def init_params(D, share=True, seed=0, compress=False):
     """All parameters ~ N(0,1): diora.py:234-237 with the shapes of :453-471."""
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
-    P = {
-        'root_vector_out_h': rn(D),
+    # the reference registers the root parameter first; compress = True: root_mat_out (D, D) instead of root_vector_out_h (diora.py:466-467)
+    P = {'root_mat_out': rn(D, D)} if compress else {'root_vector_out_h': rn(D)}
+    P.update({
         'inside_score_func.mat': rn(D, D),
         'inside_compose_func.leaf_fc.weight': rn(D, D),
         'inside_compose_func.leaf_fc.bias': rn(D),
@@ -57,7 +58,7 @@ def init_params(D, share=True, seed=0, compress=False):
         'inside_compose_func.h_fcs.0.bias': rn(D),
         'inside_compose_func.h_fcs.2.weight': rn(D, D),
         'inside_compose_func.h_fcs.2.bias': rn(D),
-    }
+    })
     if not share:
         P.update({
             'outside_score_func.mat': rn(D, D),
@@ -214,7 +215,10 @@ def diora_forward(P, x_span, x_word=None, obj_span=None, obj_word=None, *, outsi
 
     # ---- outside pass: diora.py:337-398
     if outside:
-        rh_ = nrm(P['root_vector_out_h'].view(1, 1, D).expand(B, 1, D))
+        if 'root_mat_out' in P:      # compress = True (diora.py:342-343)
+            rh_ = nrm(torch.matmul(ch.inside_h[:, -1:], P['root_mat_out']))
+        else:
+            rh_ = nrm(P['root_vector_out_h'].view(1, 1, D).expand(B, 1, D))
         if lstm:      # diora.py:346-350 with a root_vector_out_c parameter (the commented hint at diora.py:470-471)
             rc_ = nrm(P['root_vector_out_c'].view(1, 1, D).expand(B, 1, D))
         else:

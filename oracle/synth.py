@@ -10,9 +10,9 @@ from . import chart_layout as CL
 from .diora_ref import init_params
 
 
-def diora_case(D, B, L, seed, share=True):
+def diora_case(D, B, L, seed, share=True, compress=False):
     """-> (params, x_span, cotangents) exactly as make_golden.diora_case drew them."""
-    P = init_params(D, share=share, seed=seed)
+    P = init_params(D, share=share, seed=seed, compress=compress)
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(B, L, D, generator=g)
     C = CL.n_cells(L)

@@ -92,9 +92,9 @@ def run_cky(net, B, L):
     return trees, spans
 
 
-def diora_case(name, D, B, L, seed, share=True, normalize='unit', full=True):
+def diora_case(name, D, B, L, seed, share=True, normalize='unit', full=True, compress=False):
     torch.manual_seed(seed)
-    net = ref_diora.DioraMLP(D, outside=True, normalize=normalize, compress=False, share=share)
+    net = ref_diora.DioraMLP(D, outside=True, normalize=normalize, compress=compress, share=share)
     seeded_params(net, seed)
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(B, L, D, generator=g).requires_grad_(True)
@@ -119,7 +119,7 @@ def diora_case(name, D, B, L, seed, share=True, normalize='unit', full=True):
     for level in range(1, L):
         hook['hook_s_%d' % level] = torch.stack([net.saved_scalars[level][p] for p in range(L - level)], 1).numpy()
     trees, spans = run_cky(net, B, L)
-    meta = dict(META, D=D, B=B, L=L, seed=seed, share=share, normalize=normalize,
+    meta = dict(META, D=D, B=B, L=L, seed=seed, share=share, normalize=normalize, **({'compress': True} if compress else {}),
                 trees=[tree_to_str(t) for t in trees], spans=[[list(s) for s in sp] for sp in spans])
     arrs = dict(meta=np.array(json.dumps(meta)))
     if full:
@@ -463,6 +463,10 @@ if __name__ == '__main__':
     index_tables()
     diora_case('diora_c1.npz', D=50, B=8, L=10, seed=1234)                       # BASELINE config 1
     diora_case('diora_noshare.npz', D=24, B=3, L=7, seed=7, share=False)
+    # diora.py:342-343 (never enabled by trainer.py:552).  With compress every gradient depends on every ReLU through the root, so the
+    # seed is one whose second-layer pre-activations all stay 7e-5 of their scale away from zero (seed 19 has one at 1.5e-7: the
+    # split-bf16 mode lands on the other side of that kink and every gradient of the 24-d case moves by 1e-4 .. 4e-3)
+    diora_case('diora_compress.npz', D=24, B=3, L=7, seed=21, compress=True)
     diora_case('diora_nonorm.npz', D=16, B=2, L=5, seed=9, normalize='none')
     diora_case('diora_len2.npz', D=20, B=2, L=2, seed=11)
     diora_case('diora_c2_small.npz', D=400, B=2, L=20, seed=1234, full=False)    # config 2 shape, B=2

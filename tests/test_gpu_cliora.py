@@ -85,19 +85,20 @@ def test_cliora_train_with_recorded_dropout_and_grads(mfma_mode):
         grad_check(tt, v, mfma_mode, GRAD_TOL, k)
 
 
-@pytest.mark.parametrize('D,B,L,R,share', [(64, 3, 5, 36, True), (48, 2, 6, 10, False), (400, 2, 7, 36, True), (32, 2, 5, 64, True), (32, 2, 4, 1, True)])
-def test_cliora_against_oracle(D, B, L, R, share, mfma_mode):
+@pytest.mark.parametrize('D,B,L,R,share,compress', [(64, 3, 5, 36, True, False), (48, 2, 6, 10, False, False), (400, 2, 7, 36, True, False),
+                                                     (32, 2, 5, 64, True, False), (32, 2, 4, 1, True, False), (64, 3, 6, 36, True, True)])
+def test_cliora_against_oracle(D, B, L, R, share, compress, mfma_mode):
     """Other shapes (Dp == D and Dp != D, R not a multiple of 4... of 16, unshared weights) vs the CPU oracle."""
     from cliora_amd.cliora import DioraMLP
     from oracle import diora_ref as Rf
     torch.manual_seed(5)
-    P = Rf.init_params(D, share=share, seed=3)
+    P = Rf.init_params(D, share=share, seed=3, compress=compress)        # compress: cliora.py:355-356, as diora.py:342-343
     gen = torch.Generator().manual_seed(4)
     x_span, x_word = torch.randn(B, L, D, generator=gen), torch.randn(B, L, D, generator=gen)
     obj_span, obj_word = 0.3 * torch.randn(B, R, D, generator=gen), 0.3 * torch.randn(B, R, D, generator=gen)
     C = L * (L + 1) // 2
     mask = torch.nn.functional.dropout(torch.ones(B, C, R), 0.1, True)
-    m = DioraMLP(D, share=share)
+    m = DioraMLP(D, share=share, compress=compress)
     sd = m.state_dict()
     for k in sd:
         sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].clone()

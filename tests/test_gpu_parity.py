@@ -23,7 +23,7 @@ CHARTS = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
 
 def _module_from_params(P, D, share, normalize, outside=True):
     from cliora_amd.diora import DioraMLP
-    m = DioraMLP(D, outside=outside, normalize=normalize, compress=False, share=share)
+    m = DioraMLP(D, outside=outside, normalize=normalize, compress='root_mat_out' in P, share=share)
     sd = m.state_dict()
     for k in sd:
         src = k
@@ -76,7 +76,7 @@ def _run_gpu(m, x, cot):
     return outs, xg
 
 
-@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_nonorm.npz', 'diora_len2.npz'])
+@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_nonorm.npz', 'diora_len2.npz', 'diora_compress.npz'])
 def test_golden_forward_backward(name, mfma_mode):
     g = load_golden(name)
     meta = g['meta']
@@ -100,7 +100,7 @@ def test_golden_forward_backward(name, mfma_mode):
         grad_check(t, v, mfma_mode, GRAD_TOL, k)
 
 
-@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_len2.npz'])
+@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_len2.npz', 'diora_compress.npz'])
 def test_hook_scores_and_trees(name, mfma_mode):
     from oracle import diora_ref as R
     g = load_golden(name)
@@ -243,6 +243,39 @@ def test_inside_only_eval_mode(mfma_mode):
         else:
             grad_check(named[k].grad, p.grad, mfma_mode, GRAD_TOL, k)
     grad_check(xg.grad, xc.grad, mfma_mode, GRAD_TOL, 'x_span')
+
+
+@pytest.mark.parametrize('D,B,L,share', [(400, 3, 9, True), (48, 5, 6, False), (64, 2, 2, True), (33, 4, 1, True)])
+def test_compress_root_against_oracle(D, B, L, share, mfma_mode):
+    """compress = True (diora.py:342-343): the outside root of a sentence is unit(inside_h[root] @ root_mat_out), so the outside pass
+    follows the inside pass and its gradient flows back into the inside root.  The reference's own output for this mode is
+    tests/golden/diora_compress.npz (test_golden_forward_backward); here other widths, unshared weights, L = 2 and L = 1."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    P, x, cot = synth.diora_case(D, B, L, 31, share=share, compress=True)
+    m = _module_from_params(P, D, share, 'unit')
+    assert m.compress and hasattr(m, 'root_mat_out') and not hasattr(m, 'root_vector_out_h')
+    outs, xg = _run_gpu(m, x, cot)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, share=share, training=True)
+    sum((ref[k] * cot[k]).sum() for k in CHARTS).backward()
+    for k in CHARTS:
+        assert _err(outs[k], ref[k]) <= OUT_TOL * _scale(ref[k].detach().numpy()), k
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        if p.grad is None:           # L = 1: the leaves and the root only, no compose / score parameter is used
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
+        else:
+            _grad_ok(named[k].grad, p.grad, k, mfma_mode)        # kink-tolerant: with compress one ReLU on the fence moves EVERY gradient
+    _grad_ok(xg.grad, xc.grad, 'x_span', mfma_mode)
+    # the inside pass alone (scripts/train.py:130 at eval): no root is formed, root_mat_out gets a zero gradient
+    m2 = _module_from_params(P, D, share, 'unit', outside=False)
+    cot_in = {k: cot[k] for k in ('inside_h', 'inside_s')}
+    outs2, _ = _run_gpu(m2, x, cot_in)
+    assert torch.equal(outs2['inside_h'].detach(), outs['inside_h'].detach()) and float(outs2['outside_h'].detach().abs().max()) == 0.0
+    assert float(m2.root_mat_out.grad.abs().max()) == 0.0
 
 
 def test_cpu_tensor_fails_loudly():

@@ -57,7 +57,7 @@ def _run_diora(P, x, cot, share, normalize):
     return out, x
 
 
-@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_nonorm.npz', 'diora_len2.npz'])
+@pytest.mark.parametrize('name', ['diora_c1.npz', 'diora_noshare.npz', 'diora_nonorm.npz', 'diora_len2.npz', 'diora_compress.npz'])
 def test_diora_full_cases(golden, name):
     g = golden(name)
     m = g['meta']
@@ -65,7 +65,7 @@ def test_diora_full_cases(golden, name):
     if m['share']:   # the reference state_dict lists the aliased outside_* twins; drop them
         P = {k: v for k, v in P.items() if not k.startswith('outside_')}
     # the seeded synthesiser reproduces the stored parameters and inputs bit for bit
-    P2, x2, cot2 = synth.diora_case(m['D'], m['B'], m['L'], m['seed'], share=m['share'])
+    P2, x2, cot2 = synth.diora_case(m['D'], m['B'], m['L'], m['seed'], share=m['share'], compress=m.get('compress', False))
     for k in P2:
         assert torch.equal(P2[k], P[k]), k
     assert np.array_equal(x2.numpy(), g['x_span'])
