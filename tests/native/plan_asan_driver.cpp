@@ -37,7 +37,6 @@ int main() {
             for (int D : {1, 16, 50, 64, 400, 512})
                 for (int B : {1, 3, 64})
                     for (int share = 0; share < 2; ++share) {
-                        if (arch == 1 && !share) continue;
                         if ((long long)B * L * L * L > 3000000) continue;
                         Plan p;
                         const std::string e = build_plan(p, B, L, D, share, 1, 0, arch);
@@ -54,7 +53,14 @@ int main() {
                     }
     Plan bad;
     if (build_plan(bad, 1, 65, 16, 1, 1, 0, 0).empty()) return 20;      // L > 64 is refused
-    if (build_plan(bad, 1, 4, 16, 0, 1, 0, 1).empty()) return 21;       // unshared TreeLSTM is refused
+    if (build_plan(bad, 1, 4, 16, 1, 1, 3, 1).empty()) return 21;       // TreeLSTM with image regions is refused
+    {   // geometry of the rows-stationary compose kernel: one split per wave, fullest slot table
+        for (int N = 1; N <= 40; ++N) {
+            const ComposeGeom q = compose_geom_rs(64 * 7, N);
+            if (N > 8 * HP_PARTS) { if (q.TG != 0) return 22; continue; }
+            if (q.TG < 1 || q.SP < 1 || q.SP > HP_PARTS || (N + q.SP - 1) / q.SP > 8 / q.TG) return 23;
+        }
+    }
     printf("plans ok: %d\n", n);
     return 0;
 }
