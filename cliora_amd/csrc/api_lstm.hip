@@ -2,6 +2,9 @@
 #include "api_common.hpp"
 #include "lstm_kernels.hpp"
 
+#ifndef LSTM_FW
+#define LSTM_FW 4         // floats per thread in the cell-centric forward kernel
+#endif
 #ifndef LSTM_W
 #define LSTM_W 4          // floats per thread in the cell-centric backward kernels (lstm_kernels.hpp: VecW); 1, 2 and 4 time the same on MI355X
 #endif
@@ -97,20 +100,23 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
     // The two passes as a wavefront (see cliora_chart_forward): step k runs inside level k on the caller's stream and outside level
     // L-k on the side stream, which needs the inside projections of the levels <= k-2 (its siblings).
+    // run_outside carries the flag bits of cliora_chart_forward: without a backward to come and without a hook the per-split rows
+    // h_n, c_n are not written at all
+    const int flags = run_outside;
+    run_outside = flags & 1;
+    const bool keep_pairs = (flags & CLIORA_FWD_NO_BACKWARD) == 0 || (flags & CLIORA_FWD_PAIR_STATES) != 0;
     const bool two_streams = wavefront_pays_lstm(p, g_cliora_wavefront) && run_outside;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
     auto inside_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        const int ncell = B * g.Lc;
         hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, sa, g, dv.arow, dv.brow, ws + f.pi + 10 * Dp, ldpi, IH, IS, IS,
                            ws + f.sp, ws + f.pp, IS);
         LAUNCHOK("pair_scores_fwd");
-        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, sa, g.rowbase, nrows, Dp, dv.arow, dv.brow, ws + f.pi, ldpi,
-                           ws + f.pi + 5 * Dp, ldpi, IC, IC, 1.0f, ws + f.y, ws + f.x);
-        LAUNCHOK("lstm_pair_fwd");
-        hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, sa, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, IH, IC,
+        hipLaunchKernelGGL(lstm_cell_fwd<LSTM_FW>, dim3(ncell), dim3((Dp / LSTM_FW + 63) / 64 * 64), 0, sa, g, dv.arow, dv.brow, ws + f.pi, ldpi,
+                           ws + f.pi + 5 * Dp, ldpi, IC, IC, 1.0f, ws + f.pp, p.normalize, keep_pairs ? ws + f.y : nullptr, ws + f.x, IH, IC,
                            ws + f.nrmi, ws + f.nrmic);
-        LAUNCHOK("lstm_aggregate_fwd");
+        LAUNCHOK("lstm_cell_fwd");
         if (level < L - 1)
             OKR(launch_rows_direct(sa, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
                                    StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
@@ -118,16 +124,14 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
     };
     auto outside_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, true);
-        const int ncell = B * g.Lc, nrows = ncell * g.N;
+        const int ncell = B * g.Lc;
         hipLaunchKernelGGL(pair_scores_fwd, dim3(ncell), dim3(256), 0, sb, g, dv.arow, dv.brow, ws + f.pi + (size_t)p.blk_qlo * Dp, ldpi, OH, IS, OS,
                            ws + f.sp, ws + f.pp, OS);
         LAUNCHOK("pair_scores_fwd(out)");
-        hipLaunchKernelGGL(lstm_pair_fwd, dim3(cells_grid(nrows)), dim3(256), 0, sb, g.rowbase, nrows, Dp, dv.arow, dv.brow,
-                           ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, ldpo, IC, OC, 0.0f, ws + f.y, ws + f.x);
-        LAUNCHOK("lstm_pair_fwd(out)");
-        hipLaunchKernelGGL(lstm_aggregate_fwd, dim3(ncell), dim3(256), 0, sb, g, ws + f.y, ws + f.x, ws + f.pp, p.normalize, OH, OC,
-                           ws + f.nrmo, ws + f.nrmoc);
-        LAUNCHOK("lstm_aggregate_fwd(out)");
+        hipLaunchKernelGGL(lstm_cell_fwd<LSTM_FW>, dim3(ncell), dim3((Dp / LSTM_FW + 63) / 64 * 64), 0, sb, g, dv.arow, dv.brow,
+                           ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, ldpo, IC, OC, 0.0f, ws + f.pp, p.normalize,
+                           keep_pairs ? ws + f.y : nullptr, ws + f.x, OH, OC, ws + f.nrmo, ws + f.nrmoc);
+        LAUNCHOK("lstm_cell_fwd(out)");
         if (level >= 1)
             OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
                                    StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));

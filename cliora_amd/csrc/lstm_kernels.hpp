@@ -6,7 +6,7 @@
 // Factored like the MLP: every CELL is projected once (PL = U[:, :D] h + B and PR = U[:, D:] h,
 // five gate blocks each, plus QL = mat^T h), so a span PAIR needs no matmul at all -- only the
 // gate arithmetic on PL(a) + PR(b) and the two child cell states.  The whole TreeLSTM pair path is
-// therefore HBM-bound: 12 D floats read and 2 D written per pair in the forward.
+// therefore HBM-bound: 12 D floats read and (when a backward or a hook follows) 2 D written per pair in the forward.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -62,72 +62,6 @@ static __global__ __launch_bounds__(256) void lstm_leaf_fwd(int B, int L, int C,
     if (lane == 0) { nrmH[crow] = nh; nrmC[crow] = nc; S[crow] = 0.f; }
 }
 
-// ---- one span pair per wave: gates from PL(a) + PR(b), child cell states, -> Y = h, X = c
-static __global__ __launch_bounds__(256) void lstm_pair_fwd(int rowbase, int nrows, int Dp, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
-                                                     const float* __restrict__ PA, int ldA, const float* __restrict__ PB, int ldB,
-                                                     const float* __restrict__ CA, const float* __restrict__ CB, float kf,
-                                                     float* __restrict__ Y, float* __restrict__ X) {
-    const int lane = threadIdx.x & 63;
-    const int rl = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rl >= nrows) return;
-    const size_t r = (size_t)rowbase + rl;
-    const int ar = arow[r], br = brow[r];
-    const float* pa = PA + (size_t)ar * ldA;
-    const float* pb = PB + (size_t)br * ldB;
-    const float* ca = CA + (size_t)ar * Dp;
-    const float* cb = CB + (size_t)br * Dp;
-    const int nv = Dp >> 2;
-    for (int v = lane; v < nv; v += 64) {
-        const int c4 = 4 * v;
-        const float4 u = f4tanh(f4add(ld4(pa + c4), ld4(pb + c4)));
-        const float4 i = f4sig(f4add(ld4(pa + Dp + c4), ld4(pb + Dp + c4)), 0.f);
-        const float4 o = f4sig(f4add(ld4(pa + 2 * Dp + c4), ld4(pb + 2 * Dp + c4)), 0.f);
-        const float4 f0 = f4sig(f4add(ld4(pa + 3 * Dp + c4), ld4(pb + 3 * Dp + c4)), kf);
-        const float4 f1 = f4sig(f4add(ld4(pa + 4 * Dp + c4), ld4(pb + 4 * Dp + c4)), kf);
-        const float4 c = f4add(f4add(f4mul(f0, ld4(ca + c4)), f4mul(f1, ld4(cb + c4))), f4mul(i, u));
-        st4(X + r * Dp + c4, c);
-        st4(Y + r * Dp + c4, f4mul(o, f4tanh(c)));
-    }
-}
-
-// ---- softmax-weighted sums of h and c over the splits + unit norm of both (one workgroup per cell)
-static __global__ __launch_bounds__(256) void lstm_aggregate_fwd(LevelArgs g, const float* __restrict__ Y, const float* __restrict__ X,
-                                                          const float* __restrict__ Pp, int normalize, float* __restrict__ H,
-                                                          float* __restrict__ Cc, float* __restrict__ nrmH, float* __restrict__ nrmC) {
-    // waves 0,1 aggregate h (columns split lane / lane+64 as elsewhere), waves 2,3 do the same for c
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
-    const int b = t / g.Lc, p = t - b * g.Lc;
-    if (wave & 1) return;                       // one wave per vector is enough (row = 2 float4 per lane)
-    const bool isC = wave >= 2;
-    const float* SRC = isC ? X : Y;
-    const int row0 = g.rowbase + t * g.N;
-    const int nv = g.Dp >> 2;
-    const bool a0 = lane < nv, a1 = lane + 64 < nv;
-    float4 v0 = f4zero(), v1 = f4zero();
-    for (int n0 = 0; n0 < g.N; n0 += 4) {
-        float pn[4];
-        float4 y0[4], y1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + j, g.N - 1);
-            pn[j] = (n0 + j < g.N) ? Pp[row0 + n] : 0.f;
-            const float* y = SRC + (size_t)(row0 + n) * g.Dp;
-            y0[j] = a0 ? ld4(y + 4 * lane) : f4zero();
-            y1[j] = a1 ? ld4(y + 4 * (lane + 64)) : f4zero();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v0 = f4fma(pn[j], y0[j], v0); v1 = f4fma(pn[j], y1[j], v1); }
-    }
-    const float nr = sqrtf(wave_sum(f4dot(v0, v0) + f4dot(v1, v1)));
-    const float den = normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
-    const size_t crow = (size_t)b * g.C + g.off + p;
-    float* h = (isC ? Cc : H) + crow * g.Dp;
-    if (a0) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
-    if (a1) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
-    if (lane == 0) (isC ? nrmC : nrmH)[crow] = nr;
-}
-
 // ---- backward of the cells of one level, cell-centric: one workgroup per cell, one THREAD per 16-byte column, walking the
 // cell's use lists (the span pairs it is an operand of) and RECOMPUTING each pair's gate gradients on the fly:
 //   pair (a, b) -> target t, split weight p:   [u,i,o,f0,f1] = gates(PL(a) + PR(b)),  c = f0 c_a + f1 c_b + i u,  tc = tanh(c)
@@ -175,7 +109,7 @@ __device__ __forceinline__ LstmPairGrad<W> lstm_pair_grad(const VecW<W> (&x)[5],
 #pragma unroll
     for (int q = 0; q < W; ++q) {
         const float u = tanhf(x[0].v[q]), i = sigm(x[1].v[q] + 0.f), o = sigm(x[2].v[q] + 0.f), f0 = sigm(x[3].v[q] + kf), f1 = sigm(x[4].v[q] + kf);
-        const float c = (f0 * cA.v[q] + f1 * cB.v[q]) + i * u;          // as lstm_pair_fwd forms it
+        const float c = (f0 * cA.v[q] + f1 * cB.v[q]) + i * u;          // as lstm_cell_fwd forms it
         const float tc = tanhf(c);
         const float dh = pn * dGh.v[q];
         const float dc = pn * dGc.v[q] + (dh * o) * (1.f - tc * tc);
@@ -329,6 +263,95 @@ static __global__ __launch_bounds__(512) void lstm_cell_bwd_out(LevelArgs g, int
     vstore<W>(VH + crow * Dp + c4, vh);
     vstore<W>(VC + crow * Dp + c4, vc);
     if (v == 0) dStot[crow] = (dS_ext ? dS_ext[crow] : 0.f) + vs;
+}
+
+// ---- forward of the cells of one level, cell-centric: one workgroup per target cell,
+// one THREAD per W columns; the splits of the cell are walked NB at a time, each split's gates formed from PL(a) + PR(b) and the
+// two child cell states, and h = sum_n p_n h_n, c = sum_n p_n c_n accumulate in registers in split order.  The per-split rows h_n, c_n go to Y / X only when the backward (its softmax term needs
+// dG . h_n + dGc . c_n) or a hook will read them: the forward moves 12 rows per pair without them, 14 with (16 as the pair + aggregate
+// kernels of round 2).  Measured on MI355X at B 64 / L 40: the training step does not move (36.3-37.0 ms against 35.6-36.8, one, two
+// or four floats per thread alike) -- the backward's use lists set it; the evaluation forward is what gains.
+//   PA / PB: the gate blocks of the a / b operand (row strides ldA / ldB), CA / CB their cell-state charts, kf the forget constant
+template <int W>
+static __global__ __launch_bounds__(512) void lstm_cell_fwd(LevelArgs g, const int32_t* __restrict__ arow, const int32_t* __restrict__ brow,
+                                                     const float* __restrict__ PA, int ldA, const float* __restrict__ PB, int ldB,
+                                                     const float* __restrict__ CA, const float* __restrict__ CB, float kf,
+                                                     const float* __restrict__ Pp, int normalize, float* __restrict__ Y, float* __restrict__ X,
+                                                     float* __restrict__ H, float* __restrict__ Cc, float* __restrict__ nrmH,
+                                                     float* __restrict__ nrmC) {
+    __shared__ float sh_n[2][8];
+    const int t = blockIdx.x, v = threadIdx.x;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int Dp = g.Dp, nv = Dp / W;
+    const bool act = v < nv;
+    const int c4 = W * (act ? v : 0);
+    const size_t row0 = (size_t)g.rowbase + (size_t)t * g.N;
+    VecW<W> vh = vzero<W>(), vc = vzero<W>();
+    constexpr int NB = W == 4 ? 2 : 4;
+    for (int n0 = 0; n0 < g.N; n0 += NB) {
+        VecW<W> ga[NB][5], gb[NB][5], ca[NB], cb[NB];
+        float pn[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const size_t r = row0 + min(n0 + j, g.N - 1);
+            const size_t ar = (size_t)arow[r], br = (size_t)brow[r];
+            pn[j] = n0 + j < g.N ? Pp[r] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                ga[j][k] = vload<W>(PA + ar * ldA + (size_t)k * Dp + c4);
+                gb[j][k] = vload<W>(PB + br * ldB + (size_t)k * Dp + c4);
+            }
+            ca[j] = vload<W>(CA + ar * Dp + c4);
+            cb[j] = vload<W>(CB + br * Dp + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (n0 + j < g.N) {
+                VecW<W> hh, cc;
+#pragma unroll
+                for (int q = 0; q < W; ++q) {
+                    const float u = tanhf(ga[j][0].v[q] + gb[j][0].v[q]);
+                    const float i = sigm((ga[j][1].v[q] + gb[j][1].v[q]) + 0.f);
+                    const float o = sigm((ga[j][2].v[q] + gb[j][2].v[q]) + 0.f);
+                    const float f0 = sigm((ga[j][3].v[q] + gb[j][3].v[q]) + kf);
+                    const float f1 = sigm((ga[j][4].v[q] + gb[j][4].v[q]) + kf);
+                    const float c = (f0 * ca[j].v[q] + f1 * cb[j].v[q]) + i * u;
+                    cc.v[q] = c;
+                    hh.v[q] = o * tanhf(c);
+                    vh.v[q] = fmaf(pn[j], hh.v[q], vh.v[q]);
+                    vc.v[q] = fmaf(pn[j], c, vc.v[q]);
+                }
+                if (Y && act) {
+                    const size_t r = row0 + n0 + j;
+                    vstore<W>(Y + r * Dp + c4, hh);
+                    vstore<W>(X + r * Dp + c4, cc);
+                }
+            }
+        }
+    }
+    // norms of both vectors over the workgroup: wave sums, then the waves in order
+    float sh = 0.f, sc = 0.f;
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) { sh = fmaf(vh.v[q], vh.v[q], sh); sc = fmaf(vc.v[q], vc.v[q], sc); }
+    }
+    sh = wave_sum(sh); sc = wave_sum(sc);
+    const int wave = v >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((v & 63) == 0) { sh_n[0][wave] = sh; sh_n[1][wave] = sc; }
+    __syncthreads();
+    float th = 0.f, tc = 0.f;
+    for (int w = 0; w < nw; ++w) { th += sh_n[0][w]; tc += sh_n[1][w]; }
+    const float nh = sqrtf(th), nc = sqrtf(tc);
+    const float dh = normalize ? fmaxf(nh, UNIT_EPS) : 1.f, dc = normalize ? fmaxf(nc, UNIT_EPS) : 1.f;
+    const size_t crow = (size_t)b * g.C + g.off + p;
+    if (act) {
+        VecW<W> oh, oc;
+#pragma unroll
+        for (int q = 0; q < W; ++q) { oh.v[q] = vh.v[q] / dh; oc.v[q] = vc.v[q] / dc; }
+        vstore<W>(H + crow * Dp + c4, oh);
+        vstore<W>(Cc + crow * Dp + c4, oc);
+    }
+    if (v == 0) { nrmH[crow] = nh; nrmC[crow] = nc; }
 }
 
 // ---- backward, unit-norm of both vectors + softmax/score backward (one workgroup per cell)

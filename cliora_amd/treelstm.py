@@ -54,7 +54,7 @@ class LSTMChartFunction(torch.autograd.Function):
         rc = _lib.lib().cliora_lstm_forward(plan.handle, C.byref(pst), _ptr(x_span), _ptr(ih), _ptr(ic), _ptr(is_), _ptr(oh), _ptr(oc),
                                            _ptr(os_), _ptr(ws), plan.fwd_bytes, int(run_outside), _stream())
         _lib.check(rc, 'cliora_lstm_forward')
-        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside), ws, ptens
+        ctx.plan, ctx.run_outside, ctx.ws, ctx.ptens = plan, int(run_outside) & 1, ws, ptens
         ctx.save_for_backward(x_span, ih, ic, is_, oh, oc, os_)
         ctx.set_materialize_grads(False)
         holder.clear()
@@ -107,7 +107,12 @@ class DioraTreeLSTM(DioraBase):
         cf, of = self.inside_compose_func, self.outside_compose_func
         outer = (None, None, None) if self.share else (of.U, of.B, self.outside_score_func.mat)
         holder = []
-        ih, ic, is_, oh, oc, os_ = LSTMChartFunction.apply(plan, holder, bool(self.outside), x_span, cf.W, cf.U, cf.B,
+        # eval / torch.no_grad without a hook override: the per-split rows h_n, c_n are not written (flag bits of cliora_chart_forward)
+        params = (cf.W, cf.U, cf.B, self.inside_score_func.mat, self.root_vector_out_h, self.root_vector_out_c) + outer
+        needs_grad = torch.is_grad_enabled() and (x_span.requires_grad or any(t is not None and t.requires_grad for t in params))
+        hooks = self._hook_overridden('inside_hook') or self._hook_overridden('outside_hook')
+        flags = int(bool(self.outside)) | (0 if needs_grad else _lib.FWD_NO_BACKWARD) | (_lib.FWD_PAIR_STATES if hooks else 0)
+        ih, ic, is_, oh, oc, os_ = LSTMChartFunction.apply(plan, holder, flags, x_span, cf.W, cf.U, cf.B,
                                                            self.inside_score_func.mat, self.root_vector_out_h, self.root_vector_out_c, *outer)
         ch = Chart()
         ch.inside_h, ch.inside_c, ch.inside_s, ch.outside_h, ch.outside_c, ch.outside_s = ih, ic, is_, oh, oc, os_
