@@ -23,6 +23,20 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in _lib.lib().cliora_version()
 
 
+def test_parameter_struct_is_the_headers_in_every_binding():
+    """struct cliora_params: the ctypes mirror (cliora_amd/_lib.py) and the stub a maintainer would copy list the
+    header's fields in the header's order -- a shorter struct would let the library read past it (root_mat selects compress)."""
+    hdr = open(os.path.join(ROOT, 'include', 'cliora_chart.h')).read()
+    body = re.search(r'typedef struct cliora_params \{(.*?)\} cliora_params;', hdr, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = re.findall(r'\*\s*([a-z_0-9]+)\s*[,;]', body)
+    assert tuple(fields) == tuple(_lib.PARAM_FIELDS)
+    assert ctypes.sizeof(_lib.Params) == len(fields) * ctypes.sizeof(ctypes.c_void_p)
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = re.search(r'class Params\(C\.Structure\):.*?_fields_ = \[\(n, C\.c_void_p\) for n in \((.*?)\)\]', doc, re.S).group(1)
+    assert tuple(re.findall(r"'([a-z_0-9]+)'", stub)) == tuple(fields)
+
+
 @pytest.mark.parametrize('L', [2, 3, 4, 7, 10, 20, 33, 40])
 def test_tables_match_reference(golden, L):
     g = golden('index_tables.npz')
