@@ -30,29 +30,48 @@ constexpr int RS_NT = 3;              // thirds of the reduction
 // LDS: two stage buffers + the reduction slots
 template <int CT> constexpr size_t rs_lds_bytes() { return (size_t)2 * CT * 16 * RS_STRIDE * 4 + (size_t)LC_SLOTS * CT * 64 * sizeof(float4); }
 
-// One third of a column block's image -> a stage buffer.  Every lane fills the 16-byte slots q = e of the linear buffer it is
-// dealt (LDS-DMA writes lane-linear); slot q is piece w = q % 42 of row q / 42: w < 20 the hi piece (k-steps s0 ..), 20 <= w < 40 the
-// lo piece, the rest padding.  Exact-fp32 mode: 40 slots of fp32 per row (32 per k-step).
+// One third of a column block's image -> a stage buffer.  LDS-DMA writes lane-linear, so every lane fills the 16-byte slots
+// q = it * 512 + thread of the linear buffer; slot q is piece w = q % 42 of row q / 42: w < 20 the hi piece (k-steps s0 ..),
+// 20 <= w < 40 the lo piece, the rest padding (exact-fp32 mode: 40 slots of fp32 per row, 32 per k-step).  What a slot reads does
+// not depend on the block or the third except for a uniform base, so each thread keeps its RS_NIT slot descriptors in registers
+// (source offset in dwords | piece index << 16 | valid << 31): the per-lane address arithmetic was half of the 0.85 us a third's
+// issue cost (tools/rs_trace.py).
+constexpr int RS_NIT = 7;             // ceil(80 rows * 42 slots / 512 threads)
 template <int CT, bool F32>
-__device__ __forceinline__ void rs_stage(const uint32_t* __restrict__ Wimg, int S, int half, int K, int col0, int s0, int ns, uint32_t* buf, int wave,
-                                         int lane) {
+__device__ __forceinline__ void rs_describe(int S, int half, uint32_t (&desc)[RS_NIT]) {
     constexpr int SLOTS_ROW = RS_STRIDE / 4, NSLOT = CT * 16 * SLOTS_ROW;
-    for (int e0 = wave * 64; e0 < NSLOT; e0 += 512) {
-        const int q = e0 + lane;
+    static_assert((NSLOT + 511) / 512 <= RS_NIT, "descriptor count");
+#pragma unroll
+    for (int it = 0; it < RS_NIT; ++it) {
+        const int q = it * 512 + (int)threadIdx.x;
         const int c = q / SLOTS_ROW, w = q - c * SLOTS_ROW;
-        bool ok = q < NSLOT;
-        const uint32_t* src;
+        uint32_t d;
         if constexpr (F32) {
-            const int k = 32 * s0 + 4 * w;
-            ok = ok && w < 8 * ns && k < K;
-            src = Wimg + (size_t)(col0 + c) * S + k;
+            const bool ok = q < NSLOT && w < 2 * (RS_HALF / 4);
+            d = (uint32_t)(c * S + 4 * w) | ((uint32_t)w << 16) | (ok ? 0x80000000u : 0u);
         } else {
             const bool lo = w >= RS_HALF / 4;
             const int wp = lo ? w - RS_HALF / 4 : w;
-            ok = ok && wp < 4 * ns && w < 2 * (RS_HALF / 4);
-            src = Wimg + (size_t)(col0 + c) * S + (lo ? half : 0) + 16 * s0 + 4 * wp;
+            const bool ok = q < NSLOT && w < 2 * (RS_HALF / 4);
+            d = (uint32_t)(c * S + (lo ? half : 0) + 4 * wp) | ((uint32_t)wp << 16) | (ok ? 0x80000000u : 0u);
         }
-        if (ok) __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + e0 * 4), 16, 0, 0);
+        desc[it] = d;
+    }
+}
+template <int CT, bool F32>
+__device__ __forceinline__ void rs_stage(const uint32_t* __restrict__ Wimg, int S, int K, int col0, int s0, int ns, uint32_t* buf,
+                                         const uint32_t (&desc)[RS_NIT], int wave) {
+    const uint32_t* base = Wimg + (size_t)col0 * S + (F32 ? 32 : 16) * s0;
+    const int lim = (F32 ? 8 : 4) * ns;
+#pragma unroll
+    for (int it = 0; it < RS_NIT; ++it) {
+        const uint32_t d = desc[it];
+        const int wp = (int)((d >> 16) & 0xffu);
+        bool ok = (d >> 31) != 0 && wp < lim;
+        if constexpr (F32) ok = ok && 32 * s0 + 4 * wp < K;
+        if (ok)
+            __builtin_amdgcn_global_load_lds((const void*)(base + (d & 0xffffu)),
+                                             (__attribute__((address_space(3))) void*)(buf + (it * 512 + wave * 64) * 4), 16, 0, 0);
     }
 }
 
@@ -138,11 +157,13 @@ __global__ __launch_bounds__(512) void level_compose_fwd_rs(const uint32_t* __re
     const int G = (lv.ncell + 15) >> 4;
     const int Ns = (lv.N + SP - 1) / SP;
     const int nstage = RS_NT * ncb;
+    uint32_t desc[RS_NIT];
+    rs_describe<CT, F32>(S, half, desc);
 
     for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
         RS_STAMP();
         // every wave is past its last read of both buffers (barrier at the end of the previous task): the first third may land
-        rs_stage<CT, F32>(Wimg, S, half, K, 0, SB[0], SB[1] - SB[0], buf0, wave, lane);
+        rs_stage<CT, F32>(Wimg, S, K, 0, SB[0], SB[1] - SB[0], buf0, desc, wave);
         const int gg = task / SP, s = task - gg * SP;
         const int gt = gg * TG + j;
         const bool have = gt < G;
@@ -158,28 +179,37 @@ __global__ __launch_bounds__(512) void level_compose_fwd_rs(const uint32_t* __re
             const float* pa = PA + ((size_t)b * lv.C + lv.pa[idx]) * lda;
             const float* pb = PB + ((size_t)b * lv.C + lv.pb[idx]) * ldb;
             if (work) {
-                constexpr int GB = 4;                                        // k-steps of raw rows in flight
-#pragma unroll
-                for (int base = 0; base < NSTEPS; base += GB) {
-                    float4 ua[GB][2], ub[GB][2];
+                // GB k-steps of raw rows per batch, TWO batches in flight: the next batch is on its way while this one is formed
+                constexpr int GB = 4, NBATCH = (NSTEPS + GB - 1) / GB;
+                float4 ua[2][GB][2], ub[2][GB][2];
+                auto fetch = [&](int slot, int base) {
 #pragma unroll
                     for (int q = 0; q < GB; ++q) {
                         const int st = base + q < NSTEPS ? base + q : NSTEPS - 1;
                         const int k = 32 * st + 4 * lg;
                         const int k2 = k + (32 * st + 16 < K ? 16 : 0);
-                        ua[q][0] = ld4(pa + k); ub[q][0] = ld4(pb + k);
-                        ua[q][1] = ld4(pa + k2); ub[q][1] = ld4(pb + k2);
+                        ua[slot][q][0] = ld4(pa + k); ub[slot][q][0] = ld4(pb + k);
+                        ua[slot][q][1] = ld4(pa + k2); ub[slot][q][1] = ld4(pb + k2);
                     }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int bi = 0; bi < NBATCH; ++bi) {
+                    if (bi + 1 < NBATCH) fetch((bi + 1) & 1, (bi + 1) * GB);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < GB; ++q) {
-                        if (base + q < NSTEPS) {
-                            const float4 f0 = make_float4(fmaxf(ua[q][0].x + ub[q][0].x, 0.f), fmaxf(ua[q][0].y + ub[q][0].y, 0.f),
-                                                          fmaxf(ua[q][0].z + ub[q][0].z, 0.f), fmaxf(ua[q][0].w + ub[q][0].w, 0.f));
-                            const float4 f1 = make_float4(fmaxf(ua[q][1].x + ub[q][1].x, 0.f), fmaxf(ua[q][1].y + ub[q][1].y, 0.f),
-                                                          fmaxf(ua[q][1].z + ub[q][1].z, 0.f), fmaxf(ua[q][1].w + ub[q][1].w, 0.f));
-                            xop[base + q] = make_operand<F32>(psrc, f0, f1);
+                        if (bi * GB + q < NSTEPS) {
+                            const float4 (&A)[2] = ua[bi & 1][q];
+                            const float4 (&Bv)[2] = ub[bi & 1][q];
+                            const float4 f0 = make_float4(fmaxf(A[0].x + Bv[0].x, 0.f), fmaxf(A[0].y + Bv[0].y, 0.f),
+                                                          fmaxf(A[0].z + Bv[0].z, 0.f), fmaxf(A[0].w + Bv[0].w, 0.f));
+                            const float4 f1 = make_float4(fmaxf(A[1].x + Bv[1].x, 0.f), fmaxf(A[1].y + Bv[1].y, 0.f),
+                                                          fmaxf(A[1].z + Bv[1].z, 0.f), fmaxf(A[1].w + Bv[1].w, 0.f));
+                            xop[bi * GB + q] = make_operand<F32>(psrc, f0, f1);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
@@ -206,7 +236,7 @@ __global__ __launch_bounds__(512) void level_compose_fwd_rs(const uint32_t* __re
                 __syncthreads();
                 if (sidx + 1 < nstage) {
                     const int nt3 = (t3 + 1) % RS_NT, ncol0 = t3 + 1 < RS_NT ? col0 : col0 + CT * 16;
-                    rs_stage<CT, F32>(Wimg, S, half, K, ncol0, SB[nt3], SB[nt3 + 1] - SB[nt3], (sidx & 1) ? buf0 : buf1, wave, lane);
+                    rs_stage<CT, F32>(Wimg, S, K, ncol0, SB[nt3], SB[nt3 + 1] - SB[nt3], (sidx & 1) ? buf0 : buf1, desc, wave);
                 }
                 const uint32_t* wimg = (sidx & 1) ? buf1 : buf0;
                 if (work) {
