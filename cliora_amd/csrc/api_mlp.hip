@@ -6,6 +6,13 @@
 #include "persist_kernels.hpp"
 #include "vl_kernels.hpp"
 
+// the attention kernels keep a wave's regions in registers: 9 per wave cover R <= 36 (the reference's 36 boxes), 16 cover R <= 64
+#define ATTEND_LAUNCH(kern, R_, grid, stream, ...)                                                              \
+    do {                                                                                                      \
+        if ((R_) <= 36) hipLaunchKernelGGL(kern<9>, grid, dim3(256), 0, stream, __VA_ARGS__);                  \
+        else hipLaunchKernelGGL(kern<16>, grid, dim3(256), 0, stream, __VA_ARGS__);                            \
+    } while (0)
+
 // ------------------------------------------------------------------ fused level kernels (level_kernels.hpp)
 // Geometry of a level's compose launch: the plan's tasks (plan.cpp compose_geom, shared with the persistent kernel so that both
 // paths sum in the same order) on at most `cap` workgroups per column block.
@@ -302,7 +309,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
-        hipLaunchKernelGGL(cell_attend_fwd, dim3(B * L), dim3(256), 0, st, g0, L, (const float*)nullptr, (size_t)0, 0,
+        ATTEND_LAUNCH(cell_attend_fwd, p.R, dim3(B * L), st, g0, L, (const float*)nullptr, (size_t)0, 0,
                            ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
                            inside_c, D, IS);
         LAUNCHOK("cell_attend_fwd(leaves)");
@@ -391,7 +398,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                                      ws + f.pi + Dp, ldpi, ws + f.b2i, ws + f.pp, HPi, hp_stride, YM, PH, cq));
         }
         if (vl) {   // cliora.py:140-157: attention residual between the aggregate and the second unit norm, then the projections
-            hipLaunchKernelGGL(cell_attend_fwd, dim3(ncell), dim3(256), 0, sa, g, L, HPi, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
+            ATTEND_LAUNCH(cell_attend_fwd, p.R, dim3(ncell), sa, g, L, HPi, hp_stride, SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
                                ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
             LAUNCHOK("cell_attend_fwd");
             if (level < L - 1) {
@@ -641,7 +648,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             OKR(launch_rows_direct(sa, ws + f.rootwT, PROJ_IMG(f.rootwT3), Dp, Dp, ncell, LevelRowsA{dGo, Dp, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
-            hipLaunchKernelGGL(cell_attend_bwd, dim3(ncell), dim3(256), 0, sa, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
+            ATTEND_LAUNCH(cell_attend_bwd, p.R, dim3(ncell), sa, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
                                drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
             LAUNCHOK("cell_attend_bwd");
         }

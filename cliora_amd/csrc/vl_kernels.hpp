@@ -8,8 +8,10 @@
 //   inside_aggregate                 cliora.py:140-157          h = unit(unit(sum_n p_n y_n) + ctx)
 //   span-region / word-region scorers  cliora.py:453-468       einsum('abx,cdx->acbd', ...)
 //
-// One wavefront per chart cell; the R region vectors of the sentence (R x D, 58 kB at R=36, D=400)
-// are read from L2 twice per cell (scores, then context), four regions in flight.
+// One workgroup (4 waves) per chart cell.  A wave's share of the R region vectors of the sentence (regions w, w+4, ...: NRW of
+// them, 9 at R = 36) is fetched into registers at the START of the kernel -- the loads do not depend on the cell's own row -- and
+// serves both the scores and the context.  The kernels are latency chains (22 us per launch for 64 cells as for 1 280 when the
+// regions were fetched four at a time, twice: round 3 trace), not bandwidth: one round trip instead of seven.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,6 +28,7 @@ constexpr int VL_MAXR = 64;     // regions per image (one per lane in the softma
 // norms, and for the leaves inside_c = unit(ctx).
 // ---------------------------------------------------------------------------------
 // The aggregate g = sum_n p_n y_n of the level's cells comes from level_compose_fwd as SP partial rows (HP).
+template <int NRW>
 static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L, const float* __restrict__ HP, size_t hp_stride, int SP,
                                                        const float* __restrict__ T, const float* __restrict__ OBJ, int R,
                                                        const float* __restrict__ mask, int normalize,
@@ -51,6 +54,15 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
         if (a0) x0 = f4add(f4add(f4add(sh_v[0][lane], sh_v[1][lane]), sh_v[2][lane]), sh_v[3][lane]);
         if (a1) x1 = f4add(f4add(f4add(sh_v[0][lane + 64], sh_v[1][lane + 64]), sh_v[2][lane + 64]), sh_v[3][lane + 64]);
     };
+    // this wave's regions, on their way before anything else
+    const float* ob = OBJ + (size_t)b * R * Dp;
+    float4 o0[NRW], o1[NRW];
+#pragma unroll
+    for (int m = 0; m < NRW; ++m) {
+        const float* o = ob + (size_t)min(wave + 4 * m, R - 1) * Dp;
+        o0[m] = a0 ? ld4(o + c0) : f4zero();
+        o1[m] = a1 ? ld4(o + c1) : f4zero();
+    }
     float4 v0 = f4zero(), v1 = f4zero();
     if (g.N == 0) {
         const float* s = T + ((size_t)b * L + p) * Dp;
@@ -70,21 +82,14 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
     const float4 u0 = make_float4(v0.x / du, v0.y / du, v0.z / du, v0.w / du);
     const float4 u1 = make_float4(v1.x / du, v1.y / du, v1.z / du, v1.w / du);
     // scores over the regions of this sentence: wave w takes regions w, w+4, ...
-    const float* ob = OBJ + (size_t)b * R * Dp;
-    for (int k0 = wave; k0 < R; k0 += 16) {
-        float d[4];
+    {
+        float d[NRW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* o = ob + (size_t)min(k0 + 4 * j, R - 1) * Dp;
-            float s = 0.f;
-            if (a0) s = f4dot(u0, ld4(o + c0));
-            if (a1) s += f4dot(u1, ld4(o + c1));
-            d[j] = s;
-        }
+        for (int m = 0; m < NRW; ++m) d[m] = f4dot(u0, o0[m]) + f4dot(u1, o1[m]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s = wave_sum(d[j]);
-            if (lane == 0 && k0 + 4 * j < R) sh_sc[k0 + 4 * j] = s;
+        for (int m = 0; m < NRW; ++m) {
+            const float s = wave_sum(d[m]);
+            if (lane == 0 && wave + 4 * m < R) sh_sc[wave + 4 * m] = s;
         }
     }
     __syncthreads();
@@ -94,22 +99,14 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
     const float pk = e / wave_sum(e);
     const float pm = (mask && lane < R) ? pk * mask[crow * R + lane] : pk;   // pre-scaled dropout mask (0 or 1/(1-p))
     if (wave == 0 && lane < R) PK[crow * VL_MAXR + lane] = pk;
-    // context = sum_k pm_k o_k, the wave's regions first
+    // context = sum_k pm_k o_k, the wave's regions first (from the registers the scores used)
     float4 x0 = f4zero(), x1 = f4zero();
-    for (int k0 = wave; k0 < R; k0 += 16) {
-        float w[4];
-        float4 o0[4], o1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = min(k0 + 4 * j, R - 1);
-            const float pj = __shfl(pm, k);
-            w[j] = (k0 + 4 * j < R) ? pj : 0.f;
-            const float* o = ob + (size_t)k * Dp;
-            o0[j] = a0 ? ld4(o + c0) : f4zero();
-            o1[j] = a1 ? ld4(o + c1) : f4zero();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { x0 = f4fma(w[j], o0[j], x0); x1 = f4fma(w[j], o1[j], x1); }
+    for (int m = 0; m < NRW; ++m) {
+        const int k = wave + 4 * m;
+        const float pj = __shfl(pm, min(k, R - 1));
+        const float w = k < R ? pj : 0.f;
+        x0 = f4fma(w, o0[m], x0); x1 = f4fma(w, o1[m], x1);
     }
     sum_waves(x0, x1);
     if (wave != 0) return;
@@ -141,6 +138,7 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
 // which are handed U / |g| instead of H / |v|), DCTX = dv, and per region PMo = p*mask, DSC = dsc
 // for the per-sentence reduction of d obj (obj_grad_reduce).
 // ---------------------------------------------------------------------------------
+template <int NRW>
 static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __restrict__ VH, const float* __restrict__ H,
                                                        const float* __restrict__ nrmV, int normalize, const float* __restrict__ OBJ,
                                                        int R, const float* __restrict__ mask, const float* __restrict__ PK,
@@ -155,25 +153,26 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
     const int Dp = g.Dp, nv = Dp >> 2;
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
     const int c0 = 4 * lane, c1 = 4 * (lane + 64);
+    const float* ob = OBJ + (size_t)b * R * Dp;
+    float4 o0[NRW], o1[NRW];                              // this wave's regions (w, w+4, ...), fetched once for both uses
+#pragma unroll
+    for (int m = 0; m < NRW; ++m) {
+        const float* o = ob + (size_t)min(wave + 4 * m, R - 1) * Dp;
+        o0[m] = a0 ? ld4(o + c0) : f4zero();
+        o1[m] = a1 ? ld4(o + c1) : f4zero();
+    }
     float4 v0 = f4zero(), v1 = f4zero(), h0 = f4zero(), h1 = f4zero();
     if (a0) { v0 = ld4(VH + crow * Dp + c0); h0 = ld4(H + crow * Dp + c0); }
     if (a1) { v1 = ld4(VH + crow * Dp + c1); h1 = ld4(H + crow * Dp + c1); }
     unit_norm_bwd(v0, v1, h0, h1, nrmV[crow], normalize);        // v = dL/d(u + ctx), the same in every wave
-    const float* ob = OBJ + (size_t)b * R * Dp;
-    for (int k0 = wave; k0 < R; k0 += 16) {
-        float d[4];
+    {
+        float d[NRW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* o = ob + (size_t)min(k0 + 4 * j, R - 1) * Dp;
-            float s = 0.f;
-            if (a0) s = f4dot(v0, ld4(o + c0));
-            if (a1) s += f4dot(v1, ld4(o + c1));
-            d[j] = s;
-        }
+        for (int m = 0; m < NRW; ++m) d[m] = f4dot(v0, o0[m]) + f4dot(v1, o1[m]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s = wave_sum(d[j]);
-            if (lane == 0 && k0 + 4 * j < R) sh_d[k0 + 4 * j] = s;
+        for (int m = 0; m < NRW; ++m) {
+            const float s = wave_sum(d[m]);
+            if (lane == 0 && wave + 4 * m < R) sh_d[wave + 4 * m] = s;
         }
     }
     __syncthreads();
@@ -186,20 +185,12 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
     const float dsc = pk * (dp - mean);
     if (wave == 0 && ak) { PMo[crow * VL_MAXR + lane] = pk * mk; DSC[crow * VL_MAXR + lane] = dsc; }
     float4 u0 = wave == 0 ? v0 : f4zero(), u1 = wave == 0 ? v1 : f4zero();
-    for (int k0 = wave; k0 < R; k0 += 16) {
-        float w[4];
-        float4 o0[4], o1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = min(k0 + 4 * j, R - 1);
-            const float dj = __shfl(dsc, k);
-            w[j] = (k0 + 4 * j < R) ? dj : 0.f;
-            const float* o = ob + (size_t)k * Dp;
-            o0[j] = a0 ? ld4(o + c0) : f4zero();
-            o1[j] = a1 ? ld4(o + c1) : f4zero();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { u0 = f4fma(w[j], o0[j], u0); u1 = f4fma(w[j], o1[j], u1); }
+    for (int m = 0; m < NRW; ++m) {
+        const int k = wave + 4 * m;
+        const float dj = __shfl(dsc, min(k, R - 1));
+        const float w = k < R ? dj : 0.f;
+        u0 = f4fma(w, o0[m], u0); u1 = f4fma(w, o1[m], u1);
     }
     if (a0) sh_v[wave][lane] = u0;
     if (a1) sh_v[wave][lane + 64] = u1;
