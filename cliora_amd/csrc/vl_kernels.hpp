@@ -54,7 +54,8 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
         if (a0) x0 = f4add(f4add(f4add(sh_v[0][lane], sh_v[1][lane]), sh_v[2][lane]), sh_v[3][lane]);
         if (a1) x1 = f4add(f4add(f4add(sh_v[0][lane + 64], sh_v[1][lane + 64]), sh_v[2][lane + 64]), sh_v[3][lane + 64]);
     };
-    // this wave's regions, on their way before anything else
+    // this wave's regions and this lane's dropout factor, on their way before anything else
+    const float mk_pre = (mask && lane < R) ? mask[crow * R + lane] : 1.f;
     const float* ob = OBJ + (size_t)b * R * Dp;
     float4 o0[NRW], o1[NRW];
 #pragma unroll
@@ -97,7 +98,7 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
     const float mx = wave_max(my_sc);
     const float e = lane < R ? expf(my_sc - mx) : 0.f;
     const float pk = e / wave_sum(e);
-    const float pm = (mask && lane < R) ? pk * mask[crow * R + lane] : pk;   // pre-scaled dropout mask (0 or 1/(1-p))
+    const float pm = (mask && lane < R) ? pk * mk_pre : pk;   // pre-scaled dropout mask (0 or 1/(1-p))
     if (wave == 0 && lane < R) PK[crow * VL_MAXR + lane] = pk;
     // context = sum_k pm_k o_k, the wave's regions first (from the registers the scores used)
     float4 x0 = f4zero(), x1 = f4zero();
@@ -154,6 +155,9 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
     const int c0 = 4 * lane, c1 = 4 * (lane + 64);
     const float* ob = OBJ + (size_t)b * R * Dp;
+    const bool ak = lane < R;
+    const float pk = ak ? PK[crow * VL_MAXR + lane] : 0.f;          // the softmax and the dropout factor of this lane's region: no later round trip
+    const float mk = (mask && ak) ? mask[crow * R + lane] : 1.f;
     float4 o0[NRW], o1[NRW];                              // this wave's regions (w, w+4, ...), fetched once for both uses
 #pragma unroll
     for (int m = 0; m < NRW; ++m) {
@@ -176,10 +180,7 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
         }
     }
     __syncthreads();
-    const bool ak = lane < R;
     const float dpm = ak ? sh_d[lane] : 0.f;
-    const float pk = ak ? PK[crow * VL_MAXR + lane] : 0.f;
-    const float mk = (mask && ak) ? mask[crow * R + lane] : 1.f;
     const float dp = ak ? dpm * mk : 0.f;
     const float mean = wave_sum(pk * dp);
     const float dsc = pk * (dp - mean);
@@ -212,11 +213,12 @@ static __global__ __launch_bounds__(256) void obj_grad_reduce(int B, int C, int 
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
     const int c0 = 4 * lane, c1 = 4 * (lane + 64);
     float4 s0 = f4zero(), s1 = f4zero();
-    for (int cc = 0; cc < C; cc += 2) {
-        float pm[2], ds[2];
-        float4 d0[2], d1[2], u0[2], u1[2];
+    constexpr int NB = 8;                 // cells in flight: the loop is a latency chain (C / NB round trips), not bandwidth
+    for (int cc = 0; cc < C; cc += NB) {
+        float pm[NB], ds[NB];
+        float4 d0[NB], d1[NB], u0[NB], u1[NB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const size_t crow = (size_t)b * C + min(cc + j, C - 1);
             const bool ok = cc + j < C;
             pm[j] = ok ? PMo[crow * VL_MAXR + k] : 0.f;
@@ -227,7 +229,7 @@ static __global__ __launch_bounds__(256) void obj_grad_reduce(int B, int C, int 
             u1[j] = a1 ? ld4(U + crow * Dp + c1) : f4zero();
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
             s0 = f4fma(pm[j], d0[j], s0); s1 = f4fma(pm[j], d1[j], s1);
             s0 = f4fma(ds[j], u0[j], s0); s1 = f4fma(ds[j], u1[j], s1);
         }
