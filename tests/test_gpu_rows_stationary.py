@@ -156,3 +156,45 @@ def test_rows_stationary_at_length_40_matches_the_plan_geometry():
             assert float((g0[n] - g1[n]).abs().max()) <= 2e-3 * sc, n
     finally:
         _lib.set_rows_stationary(prev)
+
+
+@pytest.mark.parametrize('B,L,R,share,compress', [(8, 9, 36, True, False), (3, 6, 20, False, False), (4, 7, 36, True, True)])
+def test_rows_stationary_cliora_levels_are_bitwise(B, L, R, share, compress, mfma_mode):
+    """The CLIORA levels (attention residual between the aggregate and the projection; cliora.py:140-157) and the compress root take
+    the same compose kernels: rows-stationary against the weight-stationary kernel on the same tasks, every output and gradient bit."""
+    from cliora_amd import _lib
+    from cliora_amd.cliora import DioraMLP
+    D = 400
+    torch.manual_seed(13)
+    m = DioraMLP(D, outside=True, normalize='unit', compress=compress, share=share).cuda().train()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    C = L * (L + 1) // 2
+    m.dropout_mask = (torch.rand(B, C, R, device='cuda') > 0.1).float() / 0.9
+    g = torch.Generator().manual_seed(15)
+    t = [torch.randn(sh, generator=g).cuda().requires_grad_(True) for sh in ((B, L, D), (B, L, D), (B, R, D), (B, R, D))]
+    keys = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
+    cot = [torch.randn(B, C, 1 if k.endswith('_s') else D, generator=g).cuda() for k in keys]
+    res = None
+    prev = _lib.set_rows_stationary('geometry')
+    try:
+        for mode in ('geometry', 'on'):
+            _lib.set_rows_stationary(mode)
+            for p in m.parameters():
+                p.grad = None
+            for x in t:
+                x.grad = None
+            m(*t)
+            outs = [getattr(m, k) for k in keys]
+            loss = m.all_atten_score.max(-1).values.sum() * 1e-2 + m.vg_atten_score.sum() * 1e-2
+            torch.autograd.backward(outs + [loss], cot + [None])
+            cur = ([o.detach().clone() for o in outs], [x.grad.clone() for x in t], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+            if res is None:
+                res = cur
+                continue
+            for a, b in zip(cur[0] + cur[1], res[0] + res[1]):
+                assert torch.equal(a, b)
+            for n in res[2]:
+                assert torch.equal(cur[2][n], res[2][n]), n
+    finally:
+        _lib.set_rows_stationary(prev)
