@@ -341,6 +341,48 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
 #undef TN_CASE
 }
 
+// ---- split-bf16 weight-stationary rows GEMM (rows_gemm_ws3): out[r][j] = sum_k A(r,k) W[j][k], Wimg = split_weight_image of W
+template <int CT, int WAVES, int K16, class AP, class EP>
+static int launch_rows3_k(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    constexpr int PD = 4;     // four k-steps of row operands in flight per wave; deeper rings (6, 7) measured the same on MI355X
+    const size_t lds = (size_t)CT * 16 * S * sizeof(uint32_t);
+    OKR(cliora_ensure_max_lds((const void*)rows_gemm_ws3<CT, WAVES, PD, K16, AP, EP>));
+    const int ntiles = (nrows + 15) / 16;
+    const int gy = ncols / (16 * CT);
+    // same grid rule as the fp32 kernel: fewest passes over the row tiles, then the smallest grid that does it
+    const int cap = std::max(1, 256 / gy);
+    const int passes = (ntiles + WAVES * cap - 1) / (WAVES * cap);
+    int gx = (ntiles + WAVES * passes - 1) / (WAVES * passes);
+    if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;
+    hipLaunchKernelGGL((rows_gemm_ws3<CT, WAVES, PD, K16, AP, EP>), dim3(gx, gy), dim3(WAVES * 64), lds, st, Wimg, S, K, nrows, ap, ep);
+    LAUNCHOK("rows_gemm_ws3");
+    return CLIORA_OK;
+}
+template <int CT, int WAVES, class AP, class EP>
+static int launch_rows3_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (K == 400) return launch_rows3_k<CT, WAVES, 25>(st, Wimg, S, K, ncols, nrows, ap, ep);       // d = 400: the fully unrolled instance
+    return launch_rows3_k<CT, WAVES, 0>(st, Wimg, S, K, ncols, nrows, ap, ep);
+}
+template <class AP, class EP>
+static int launch_rows3(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0) return CLIORA_OK;
+    const size_t budget = 150 * 1024;
+    const int nt = ncols / 16;
+    const long long ntiles = (nrows + 15) / 16;
+    for (int ct : {5, 4, 2, 1}) {
+        if (nt % ct) continue;
+        if ((size_t)ct * 16 * S * sizeof(uint32_t) > budget) continue;
+        const bool two = ntiles * (nt / ct) > 1536;      // two waves per SIMD once the launch fills the chip
+        switch (ct) {
+#define WS3_CASE(c) case c: return two ? launch_rows3_inst<c, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<c, 4>(st, Wimg, S, K, ncols, nrows, ap, ep)
+            WS3_CASE(5); WS3_CASE(4); WS3_CASE(2);
+            default: return two ? launch_rows3_inst<1, 8>(st, Wimg, S, K, ncols, nrows, ap, ep) : launch_rows3_inst<1, 4>(st, Wimg, S, K, ncols, nrows, ap, ep);
+#undef WS3_CASE
+        }
+    }
+    return fail(CLIORA_EINVAL, "weight block does not fit LDS");
+}
+
 // split-bf16 images (see split_weight_image) of weight matrices already in the workspace
 struct ImageList {
     SplitImageTab tab{};

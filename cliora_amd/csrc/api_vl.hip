@@ -45,6 +45,20 @@ static void region_segments(int NRp, int ncols, int* Kseg, int* nseg) {
     *Kseg = 16; *nseg = NRp / 16;
 }
 
+// The span-region scorer GEMM  out[r][c*R + d] = A(r, :) . O[c][d][:]  (cliora.py:457-466) in the arithmetic mode in force: the
+// fp32-input MFMA (exact products) or, by default, split-bf16 products on the bf16 MFMA with the region matrix as a split image
+// (rows_gemm_ws3; 24.8 GFLOP at c3: 267 us on the fp32 MFMA).  O: (NRp x Dp) region matrix, row stride ldo.
+template <class AP, class EP>
+static int launch_scorer(hipStream_t st, const Plan& p, void* vl_ws, const float* O, int ldo, int nrows, AP ap, EP ep) {
+    const int Dp = p.Dp, NRp = p.vl.NRp;
+    if (!split_bf16() || ldo != Dp) return launch_rows(st, O, Dp, 1, NRp, nrows, ap, ep);
+    float* img = (float*)vl_ws + p.vl.oimg;
+    ImageList im;
+    im.add(O, img, NRp, ldo, Dp);
+    OKR(build_weight_images(st, im));
+    return launch_rows3(st, reinterpret_cast<const uint32_t*>(img), image_stride(Dp), Dp, NRp, nrows, ap, ep);
+}
+
 struct VlViews { float *oall, *oallT, *wall, *wallT, *sump, *xwp, *xwn, *dxn, *nrm, *gobj, *slab; };
 static VlViews vl_views(const Plan& p, void* ws) {
     float* w = (float*)ws;
@@ -75,7 +89,7 @@ extern "C" int cliora_vl_scores_forward(cliora_plan* plan, const float* inside_h
         OKR(run_copies(st, t));
     }
     const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
-    if (all_atten) OKR(launch_rows(st, inplace ? obj_span : v.oall, Dp, 1, NRp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
+    if (all_atten) OKR(launch_scorer(st, p, vl_ws, inplace ? obj_span : v.oall, Dp, B * C, sumA, ScoreStoreE{all_atten, B, C, R, nullptr, 0}));
     if (vg_atten) {
         if (training) {
             const SumRowsA xw = SumRowsA{padded ? v.xwp : x_word, nullptr, Dp};
@@ -111,7 +125,7 @@ extern "C" int cliora_vl_scores_max_forward(cliora_plan* plan, const float* insi
         OKR(run_copies(st, t));
     }
     const SumRowsA sumA = padded ? SumRowsA{v.sump, nullptr, Dp} : SumRowsA{inside_h, outside_h, Dp};
-    OKR(launch_rows(st, inplace ? obj_span : v.oall, Dp, 1, NRp, B * C, sumA, ScoreMaxE{keys, B, C, R}));
+    OKR(launch_scorer(st, p, vl_ws, inplace ? obj_span : v.oall, Dp, B * C, sumA, ScoreMaxE{keys, B, C, R}));
     hipLaunchKernelGGL(region_keys_decode, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, keys, nkeys, all_max, all_arg);
     LAUNCHOK("region_keys_decode");
     return CLIORA_OK;

@@ -333,6 +333,133 @@ __device__ __forceinline__ T pick_pod(bool c, const T& a, const T& b) {
 
 
 // ---------------------------------------------------------------------------------
+// rows_gemm_ws3: rows_gemm_ws (single weight segment) in split-bf16 arithmetic (the span-region scorers of CLIORA in the default
+// arithmetic mode: 24.8 GFLOP per step at c3, MFMA-bound on the fp32-input MFMA).
+//   Wimg   : split_weight_image() of the [ncols][K] weight; block blockIdx.y's CT*16 image rows are one
+//            contiguous piece and are copied to LDS as they are (LDS-DMA, lane-linear)
+//   a wave walks 16-row tiles; per 32-deep k-step a lane fetches its row's 8 consecutive k through the
+//   same AProd functors as the fp32 kernel (two fetches), splits them once, and issues 3*CT MFMAs.
+//   PD k-steps of operand loads are in flight per wave (register ring); the ring runs on across the wave's
+//   tiles, so the next tile's first loads are issued while the current tile's last steps compute.
+// ---------------------------------------------------------------------------------
+template <int CT, int WAVES, int PD, int K16, class AProd, class Epi>
+static __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_t* __restrict__ Wimg, int S_, int K_, int nrows, AProd ap, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    constexpr int T = WAVES * 64;
+    // K16 > 0: the reduction length K = 16*K16 is a compile-time constant -- the k-step loop unrolls completely and every
+    // LDS / global offset, ring slot and "second run inside the row" test becomes an immediate (d = 400: K16 = 25);
+    // K16 == 0: the same code with run-time K
+    constexpr bool KS = K16 > 0;
+    constexpr int UNROLL_STEPS = KS ? 64 : 1;      // the k-step loop: fully unrolled when K is a compile-time constant
+    const int K = KS ? K16 * 16 : K_;
+    const int S = KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);   // fetch-side lane map
+    const int Kp = S - WS3_PAD, half = Kp >> 1;
+    const int col0 = blockIdx.y * (CT * 16);
+    {
+        const uint32_t* src = Wimg + (size_t)col0 * S;
+        const int n16 = CT * 16 * S / 4;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        for (int e0 = wv * 64; e0 < n16; e0 += T) {
+            const int e = e0 + lane;
+            if (e < n16)
+                __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)e * 4),
+                                                 (__attribute__((address_space(3))) void*)(lds_img + e0 * 4), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int ntiles = (nrows + 15) >> 4;
+    const int stride = gridDim.x * WAVES;
+    int tile = blockIdx.x * WAVES + wave;
+    if (tile >= ntiles) return;
+    const int nsteps = Kp >> 5;
+    const int nsteps_p = (nsteps + PD - 1) / PD * PD;     // the ring's slot of k-step s is s % PD in every tile
+    int wfrag_off = i * S + 4 * g;
+    const int gy = gridDim.y, by = blockIdx.y;
+    using Raw = typename AProd::Raw;
+    auto rowof = [&](int t) { const int r = t * 16 + li; return r < nrows ? r : nrows - 1; };   // clamp: computed, never stored
+    // A lane's k at step s: 32s + 4g .. +3 and 32s + 16 + 4g .. +3 (the image's permutation; g = the lane's k-piece).  K is a multiple of 16, so
+    // the first run is always inside the row and the second is inside for every lane or for none; when it is not, the
+    // first run is fetched twice and the duplicate is discarded.  EVERY ring slot issues exactly two fetches per turn,
+    // whatever the step: the loads then stand in a fixed order, the waits before a step count the loads issued after its
+    // own (vmcnt is in order) and never drain the ring -- a fetch behind a branch forces a full drain at the join.
+    Raw ra[PD][2];
+    auto issue = [&](int slot, const decltype(ap.row(0))& c, int s) {
+        const int k = 32 * s + 4 * lg;
+        ra[slot][0] = ap.fetch(c, k);
+        ra[slot][1] = ap.fetch(c, k + (32 * s + 16 < K ? 16 : 0));
+    };
+    auto ctx = ap.row(rowof(tile));
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) issue(sl, ctx, sl < nsteps ? sl : 0);
+    while (true) {
+        const int ntile = tile + stride;
+        const bool has_next = ntile < ntiles;
+        const auto ctxn = ap.row(rowof(has_next ? ntile : tile));
+        f32x4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the weight fragments do not change from tile to tile: keep the compiler from hoisting their LDS reads out of
+        // the tile loop (hundreds of registers once the k-steps are unrolled)
+        asm volatile("" : "+v"(wfrag_off));
+        const uint32_t* wfrag = lds_img + wfrag_off;
+        int side_turn = 0;                       // k-step modulo the number of column blocks (side output shared out)
+#pragma unroll UNROLL_STEPS
+        for (int base = 0; base < nsteps_p; base += PD) {
+#pragma unroll
+            for (int sl = 0; sl < PD; ++sl) {
+                const int st = base + sl;
+                if (st < nsteps) {
+                    const bool second = 32 * st + 16 < K;
+                    const float4 f0 = ap.finish(ctx, ra[sl][0]);
+                    // beyond K this is a second copy of the first run: finite, and its weights in the image are zero
+                    const float4 f1 = ap.finish(ctx, ra[sl][1]);
+                    // optional side output of the fp32 row fragment (x / dz for the weight-gradient GEMM)
+                    if (AProd::kSide && side_turn == by) {
+                        const int k = 32 * st + 4 * lg;
+                        ap.side(ctx, k, f0);
+                        if (second) ap.side(ctx, k + 16, f1);
+                    }
+                    side_turn = side_turn + 1 == gy ? 0 : side_turn + 1;
+                    const float4 a0 = to_mfma_lanes(psrc, f0), a1 = to_mfma_lanes(psrc, f1);
+                    u32x4 xh, xl;
+                    split_bf16x8(a0, a1, xh, xl);
+                    u32x4 wh[CT], wl[CT];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        wh[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st);
+                        wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
+                    }
+                    // term by term over the CT accumulators: dependent MFMAs are CT issues apart
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wl[c], xh, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xl, acc[c]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(wh[c], xh, acc[c]);
+                }
+                // refill the slot: this tile's step st+PD, or -- in the tile's last ring turn -- the next tile's step sl
+                const int nst = st + PD;
+                const bool in_cur = nst < nsteps;
+                issue(sl, pick_pod(in_cur, ctx, ctxn), in_cur ? nst : (sl < nsteps ? sl : 0));
+            }
+        }
+        if (tile * 16 + i < nrows) {
+            const auto rc = epi.row(tile * 16 + i);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                epi.store4(rc, col0 + c * 16 + 4 * g, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
+        }
+        if (!has_next) break;
+        ctx = ctxn;
+        tile = ntile;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // rows_gemm_ksplit: same contract as rows_gemm_ws for SMALL row counts (the per-level cell
 // projections and their backward: a few hundred rows, 39 dependent levels per pass).  There the
 // weight-stationary kernel is all fixed cost (128 KiB of weights staged per workgroup for one

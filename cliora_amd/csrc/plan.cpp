@@ -245,6 +245,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         v.wall = take(on * NR * Dp); v.wallT = take(on * NR * Dp);
         v.sump = take(on * BC * Dp); v.xwp = take(on * BL * Dp); v.xwn = take(on * BL * Dp); v.dxn = take(on * BL * Dp); v.nrm = take(on * 4 * BL);
         v.gobj = take(on * NR * Dp);
+        v.oimg = take(on * NR * ((Dp + 31) / 32 * 32 + 8));      // split-bf16 image of the region matrix (the scorers' weight in the default mode)
         v.keys = take(on * 2 * (size_t)B * BC);          // (B,B,C) 64-bit (score, region) keys of the region-max scorer
         v.slab_floats = on * (8 * (NR * Dp) + 64);
         v.slab = take(v.slab_floats);

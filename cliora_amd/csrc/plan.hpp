@@ -104,7 +104,7 @@ struct Plan {
     FwdLayout fwd;
     BwdLayout bwd;
     // span-region scorer workspace (floats): padded/transposed region matrices, padded sum rows, slabs
-    struct VlLayout { size_t oall, oallT, wall, wallT, sump, xwp, xwn, dxn, nrm, gobj, keys, slab, slab_floats, total; int NRp; } vl;
+    struct VlLayout { size_t oall, oallT, wall, wallT, sump, xwp, xwn, dxn, nrm, gobj, oimg, keys, slab, slab_floats, total; int NRp; } vl;
 
     // device copies (filled lazily by the HIP side)
     int32_t* d_tables = nullptr;
