@@ -298,12 +298,24 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
     const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float) + (size_t)NJT * 2048;   // two fp32 stages + the split column fragments
     if (split_bf16() && lds3 <= 160 * 1024 && (Dp + NJT * 16) / 32 <= TN3_NP) {
         OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3<NIT, NJT, true>));
-        // whole groups of 8 slices (one per XCD), all resident at once: one workgroup per CU, no second round
-        const int nsl_cap = std::max(1, 256 / (8 * nkb)) * 8;
+        // whole groups of 8 slices (one per XCD), all resident at once: one workgroup per CU, no second round -- and a tenth of the CUs
+        // left to the small weight-gradient GEMMs of the side stream, which otherwise queue up behind this kernel (a workgroup of it fills
+        // a CU's registers): measured at c2 with 80 / 72 / 64 / 56 slices: 3.566 / 3.538 / 3.539 / 3.576 ms per step
+        static const int cap_env = [] { const char* e = getenv("CLIORA_WGRAD_SLICES"); return e ? atoi(e) : 0; }();
+        const int nsl_cap = cap_env > 0 ? cap_env : std::max(1, 230 / (8 * nkb)) * 8;
         if (nsl > nsl_cap) { nsl = nsl_cap; rps = (nrows + nsl - 1) / nsl; }
         rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
         nsl = (nrows + rps - 1) / rps;
         csl = slab + (size_t)nsl * Dp * Dp;
+        static const bool eight = [] { const char* e = getenv("CLIORA_WGRAD_WAVES"); return !e || atoi(e) != 4; }();
+        if constexpr (NIT == 7 && NJT == 9) {              // d = 400: two waves per SIMD, each with half of the block's j-tiles
+            if (eight) {                                   // (the second half has at most NJT - 5 = 4 of its 5 slots taken: the spare one holds the ones-tile)
+                OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3x<NIT, NJT, 5, true>));
+                hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
+                LAUNCHOK("tn_gemm_dma3x");
+                goto reduce;
+            }
+        }
         hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(256), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
         LAUNCHOK("tn_gemm_dma3");
     } else {
@@ -312,6 +324,7 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
         hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
         LAUNCHOK("tn_gemm_dma");
     }
+reduce:
     const size_t n = (size_t)Dp * Dp;
     hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
     LAUNCHOK("slab_reduce");

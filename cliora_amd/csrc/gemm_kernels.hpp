@@ -986,6 +986,187 @@ static __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restri
     }
 }
 
+// tn_gemm_dma3x: tn_gemm_dma3 with EIGHT waves (two per SIMD).  With one wave per SIMD everything a stage needs besides its 189 MFMAs
+// -- 17 LDS-DMA pieces (100-250 issue cycles each, the price measured in compose_rs_kernels.hpp), the operand reads and splits -- sits in
+// that wave's own instruction stream: 8 500 cycles per 32-row stage for 3 024 cycles of MFMA (28 % MFMA-busy by PMC).  Here wave w takes
+// the i-tiles of wave w & 3 of the four-wave kernel and HALF of the block's j-tiles (NJW = ceil(NJT / 2); the second half has a spare
+// slot, which carries the ones-tile of the bias gradient in block 0), so that one wave's DMA issue and operand forming run under its
+// SIMD partner's MFMAs.  Every accumulator tile is still produced by one wave in the same stage and k order: the slab is bitwise the
+// four-wave kernel's.
+template <int NIT, int NJT, int NJW, bool COLSUM>
+static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restrict__ A, const float* __restrict__ B, int nrows,
+                                                     int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
+                                                     float* __restrict__ slab, float* __restrict__ colsum) {
+    static_assert(2 * NJW > NJT, "the second half of the j-tiles needs a spare slot for the ones-tile");
+    extern __shared__ __attribute__((aligned(16))) float lds_t[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int iw = wave & 3, jw = wave >> 2;
+    const int i = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
+    const int kb = wq % nkb, slice = (wq / nkb) * 8 + xcd;
+    if (slice >= nslices) return;
+    const int NTI = Mi >> 4, NTJ = Nj >> 4;
+    const int jbase = NTJ / nkb, jrem = NTJ % nkb;
+    const int jt0 = kb * jbase + min(kb, jrem);
+    const int njt = jbase + (kb < jrem ? 1 : 0);            // j-tiles of this block (<= NJT)
+    const int ju0 = jw * NJW;                               // first j-tile (block-relative) of this wave
+    const int njw = max(0, min(njt - ju0, NJW));            // j-tiles of this wave
+    const int ibase = NTI / 4, irem = NTI % 4;
+    const int it0 = iw * ibase + min(iw, irem);
+    const int nit = max(1, ibase + (iw < irem ? 1 : 0));    // i-tiles of this wave (<= NIT)
+    const bool has_tiles = ibase + (iw < irem ? 1 : 0) > 0;
+    const int ldA = Mi, ldX = NJT * 16;
+    const int UA = TN3_RS * (Mi >> 2), UX = TN3_RS * (ldX >> 2);
+    const int bufsz = TN3_RS * (ldA + ldX);
+    const int x4 = ldX >> 2, xv4 = njt * 4;
+
+    const int rbeg = slice * rows_per_slice;
+    const int rend = min(nrows, rbeg + rows_per_slice);
+    const int nstages = rend > rbeg ? (rend - rbeg + TN3_RS - 1) / TN3_RS : 0;
+
+    f32x4 acc[NIT][NJW];
+#pragma unroll
+    for (int a = 0; a < NIT; ++a)
+#pragma unroll
+        for (int b = 0; b < NJW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool ones_here = COLSUM && kb == 0 && jw == 1;    // the spare slot NJW - 1 of the second half
+
+    constexpr int NPW = (TN3_NP + 1) / 2;                   // pieces per wave per stage, upper bound
+    const int npieces = (UA + UX) >> 6;
+    int p_rr[NPW], p_off[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int e = (wave + 8 * k) * 64 + lane;
+        if (e < UA) {
+            p_rr[k] = e / (Mi >> 2);
+            p_off[k] = 4 * (e - p_rr[k] * (Mi >> 2));
+        } else {
+            const int f = e - UA;
+            p_rr[k] = f / x4;
+            p_off[k] = jt0 * 16 + 4 * min(f - p_rr[k] * x4, xv4 - 1);
+        }
+    }
+    // pieces [k0, k1) of this wave's share of a stage
+    auto issue = [&](int stage, int k0, int k1) {
+        const int r0 = rbeg + stage * TN3_RS;
+        const int rmax = rend - 1 - r0;
+        float* buf = lds_t + (stage & 1) * bufsz;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            if (k < k0 || k >= k1) continue;
+            const int piece = wave + 8 * k;
+            if (piece < npieces) {
+                const bool isA = piece * 64 < UA;
+                const float* base = isA ? A : B;
+                const int ld = isA ? Mi : Nj;
+                const float* src = base + (size_t)(r0 + min(p_rr[k], rmax)) * ld + p_off[k];
+                __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    int aoff[NIT];
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) aoff[t] = g * ldA + (min(it0, NTI - 1) + min(t, nit - 1)) * 16 + i;
+
+    if (nstages > 0) issue(0, 0, NPW);
+    constexpr int PPT = (NPW + NIT - 1) / NIT;           // pieces of the NEXT stage issued beside each row tile's MFMAs
+    for (int st = 0; st < nstages; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // stage st has landed for every wave; buffer (st+1)&1 is free again
+        const bool more = st + 1 < nstages;      // the next stage's LDS-DMA is issued piecewise inside the MFMA loop below (its issue cost,
+                                                 // 100-250 cycles a piece, is what a stage waited for when all pieces went out up front)
+        const float* cur = lds_t + (st & 1) * bufsz;
+        const int r0 = rbeg + st * TN3_RS;
+        const int nvalid = rend - r0;
+        auto frag = [&](int off, int ld, u32x4& hi, u32x4& lo) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = cur[off + 4 * j * ld];
+            split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+        };
+        if (nvalid < TN3_RS) {
+            float* cw = lds_t + (st & 1) * bufsz;
+            for (int e = nvalid * ldA + tid; e < TN3_RS * ldA; e += 512) cw[e] = 0.f;
+        }
+        // the NJT column fragments: each wave splits its share once and leaves the operand registers of all 64 lanes in LDS
+        u32x4* bconv = reinterpret_cast<u32x4*>(lds_t + 2 * bufsz);
+        for (int u = wave; u < NJT; u += 8) {
+            u32x4 h, l;
+            frag(TN3_RS * ldA + g * ldX + min(u, njt - 1) * 16 + i, ldX, h, l);
+            bconv[(2 * u) * 64 + lane] = h;
+            bconv[(2 * u + 1) * 64 + lane] = l;
+        }
+        __syncthreads();
+        u32x4 bh[NJW], bl[NJW];
+#pragma unroll
+        for (int u = 0; u < NJW; ++u) {
+            const int uu = min(ju0 + u, NJT - 1);
+            bh[u] = bconv[(2 * uu) * 64 + lane]; bl[u] = bconv[(2 * uu + 1) * 64 + lane];
+        }
+        if (ones_here) {                 // bf16 1.0 = 0x3F80 in all eight k of the spare fragment
+            bh[NJW - 1] = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+            bl[NJW - 1] = u32x4{0u, 0u, 0u, 0u};
+        }
+        float raw[2][8];
+        u32x4 ah[2], al[2];
+        auto loadraw = [&](int t, float (&r)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = cur[aoff[t] + 4 * j * ldA];
+        };
+        auto conv = [&](const float (&r)[8], u32x4& hi, u32x4& lo) {
+            split_bf16x8(make_float4(r[0], r[1], r[2], r[3]), make_float4(r[4], r[5], r[6], r[7]), hi, lo);
+        };
+        loadraw(0, raw[0]);
+        conv(raw[0], ah[0], al[0]);
+        if (NIT > 1) loadraw(1, raw[1]);
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            if (t + 1 < NIT) conv(raw[(t + 1) & 1], ah[(t + 1) & 1], al[(t + 1) & 1]);
+            if (t + 2 < NIT) loadraw(t + 2, raw[t & 1]);
+            if (more) issue(st + 1, PPT * t, PPT * t + PPT);
+#pragma unroll
+            for (int u = 0; u < NJW; ++u) acc[t][u] = mfma32bf(al[t & 1], bh[u], acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < NJW; ++u) acc[t][u] = mfma32bf(ah[t & 1], bl[u], acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < NJW; ++u) acc[t][u] = mfma32bf(ah[t & 1], bh[u], acc[t][u]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // 1 VALU
+            }
+#pragma unroll
+            for (int k = 8; k < 3 * NJW; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (k - 8 < PPT) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // 1 VMEM: a DMA piece of the next stage
+            }
+        }
+    }
+    float* out = slab + (size_t)slice * Mi * Nj;
+    if (has_tiles) {
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+            if (t < nit)
+#pragma unroll
+                for (int u = 0; u < NJW; ++u)
+                    if (u < njw)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            out[(size_t)((it0 + t) * 16 + g * 4 + reg) * Nj + (jt0 + ju0 + u) * 16 + i] = acc[t][u][reg];
+    }
+    if (ones_here && has_tiles && i == 0) {      // every column of the ones tile holds the same sums: lane column 0 writes
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+            if (t < nit)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) colsum[(size_t)slice * Mi + (it0 + t) * 16 + g * 4 + reg] = acc[t][NJW - 1][reg];
+    }
+}
+
 // out[e] (+)= sum_s slab[s][e], fixed order.
 static __global__ void slab_reduce(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out, int accumulate = 0) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
