@@ -60,11 +60,12 @@ __device__ __forceinline__ void rs_describe(int S, int half, uint32_t (&desc)[RS
 }
 template <int CT, bool F32>
 __device__ __forceinline__ void rs_stage(const uint32_t* __restrict__ Wimg, int S, int K, int col0, int s0, int ns, uint32_t* buf,
-                                         const uint32_t (&desc)[RS_NIT], int wave) {
+                                         const uint32_t (&desc)[RS_NIT], int wave, int it0 = 0, int it1 = RS_NIT) {
     const uint32_t* base = Wimg + (size_t)col0 * S + (F32 ? 32 : 16) * s0;
     const int lim = (F32 ? 8 : 4) * ns;
 #pragma unroll
     for (int it = 0; it < RS_NIT; ++it) {
+        if (it < it0 || it >= it1) continue;          // a wave that computes issues its pieces two per k-step, beside the MFMAs
         const uint32_t d = desc[it];
         const int wp = (int)((d >> 16) & 0xffu);
         bool ok = (d >> 31) != 0 && wp < lim;
@@ -234,10 +235,12 @@ __global__ __launch_bounds__(512) void level_compose_fwd_rs(const uint32_t* __re
                 // third sidx has landed everywhere, and every wave is done with third sidx - 1: its buffer takes third sidx + 1
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (sidx + 1 < nstage) {
-                    const int nt3 = (t3 + 1) % RS_NT, ncol0 = t3 + 1 < RS_NT ? col0 : col0 + CT * 16;
-                    rs_stage<CT, F32>(Wimg, S, K, ncol0, SB[nt3], SB[nt3 + 1] - SB[nt3], (sidx & 1) ? buf0 : buf1, desc, wave);
-                }
+                const bool more = sidx + 1 < nstage;
+                const int nt3 = (t3 + 1) % RS_NT, ncol0 = t3 + 1 < RS_NT ? col0 : col0 + CT * 16;
+                uint32_t* nbuf = (sidx & 1) ? buf0 : buf1;
+                // the next third's LDS-DMA: an idle wave issues its share now; a wave that computes spreads it over its k-steps (an LDS-DMA
+                // costs 100-250 issue cycles; up front that was 0.3-0.85 us of every third, beside the MFMAs it hides)
+                if (more && !work) rs_stage<CT, F32>(Wimg, S, K, ncol0, SB[nt3], SB[nt3 + 1] - SB[nt3], nbuf, desc, wave);
                 const uint32_t* wimg = (sidx & 1) ? buf1 : buf0;
                 if (work) {
                     WFrag<CT> w = rs_read_frag<CT, F32>(wimg, i, g, 0, 32 * SB[t3] + 16 < K);
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(512) void level_compose_fwd_rs(const uint32_t* __re
                         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): w has landed; at most one k-step of reads is ever in flight
                         if (st + 1 < SB[t3 + 1]) wn = rs_read_frag<CT, F32>(wimg, i, g, st + 1 - SB[t3], 32 * (st + 1) + 16 < K);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (more) rs_stage<CT, F32>(Wimg, S, K, ncol0, SB[nt3], SB[nt3 + 1] - SB[nt3], nbuf, desc, wave, 2 * (st - SB[t3]), 2 * (st - SB[t3]) + 2);
                         rs_mfma_step<CT, F32>(w, xop[st], 32 * st + 16 < K, acc);
                         __builtin_amdgcn_sched_barrier(0);
                         w = wn;
