@@ -287,7 +287,7 @@ static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, B
 // the big weight-gradient GEMM over span-pair rows: C = DZ^T X (Mi = Nj = Dp), LDS-DMA fed, split over row slices
 template <int NIT, int NJT>
 static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, int nkb, float* slab,
-                                size_t slab_floats, float* out, float* colsum_out) {
+                                size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap) {
     const size_t per_slice = (size_t)Dp * Dp + Dp;
     int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 256 / nkb));
     nsl = std::max(1, std::min(nsl, (nrows + 63) / 64));
@@ -302,7 +302,7 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
         // left to the small weight-gradient GEMMs of the side stream, which otherwise queue up behind this kernel (a workgroup of it fills
         // a CU's registers): measured at c2 with 80 / 72 / 64 / 56 slices: 3.566 / 3.538 / 3.539 / 3.576 ms per step
         static const int cap_env = [] { const char* e = getenv("CLIORA_WGRAD_SLICES"); return e ? atoi(e) : 0; }();
-        const int nsl_cap = cap_env > 0 ? cap_env : std::max(1, 230 / (8 * nkb)) * 8;
+        const int nsl_cap = slices_cap > 0 ? slices_cap : cap_env > 0 ? cap_env : std::max(1, 230 / (8 * nkb)) * 8;
         if (nsl > nsl_cap) { nsl = nsl_cap; rps = (nrows + nsl - 1) / nsl; }
         rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
         nsl = (nrows + rps - 1) / rps;
@@ -326,16 +326,18 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
     }
 reduce:
     const size_t n = (size_t)Dp * Dp;
-    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out);
+    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, accumulate);
     LAUNCHOK("slab_reduce");
-    hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out);
+    hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out, accumulate);
     LAUNCHOK("slab_reduce(colsum)");
     return CLIORA_OK;
 }
 
+// accumulate: add to out / colsum_out instead of overwriting; slices_cap > 0: at most that many row slices (= workgroups / nkb)
 static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, float* slab, size_t slab_floats,
-                           float* out, float* colsum_out) {
+                           float* out, float* colsum_out, int accumulate = 0, int slices_cap = 0) {
     if (nrows <= 0) {
+        if (accumulate) return CLIORA_OK;
         HIPOK(hipMemsetAsync(out, 0, (size_t)Dp * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
         return CLIORA_OK;
@@ -343,7 +345,7 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
     // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
     // nkb column blocks of NJT = ceil(NT/nkb) j-tiles
     const int NT = Dp / 16;
-#define TN_CASE(nit, njt, nkb) return launch_tn_pairs_inst<nit, njt>(st, DZ, X, nrows, Dp, nkb, slab, slab_floats, out, colsum_out)
+#define TN_CASE(nit, njt, nkb) return launch_tn_pairs_inst<nit, njt>(st, DZ, X, nrows, Dp, nkb, slab, slab_floats, out, colsum_out, accumulate, slices_cap)
     if (NT <= 4) TN_CASE(1, 4, 1);
     if (NT <= 8) TN_CASE(2, 8, 1);
     if (NT <= 12) TN_CASE(3, 12, 1);

@@ -693,6 +693,19 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         else
             HIPOK(hipMemsetAsync(wb + bw.groot_mat, 0, (size_t)Dp * Dp * sizeof(float), st));
     }
+    // The pair rows' weight gradient, early part.  After step J the rows of outside levels 0..J and of inside levels L-1-J..L-1 are final,
+    // and they are ONE contiguous range of the pair rows (the inside levels end where the outside levels begin): its dW2 runs on the GEMM
+    // stream beside the last steps of the chains, whose kernels are small (the outside levels above J and the inside levels below L-1-J
+    // have few pair rows), on a part of the chip; the tail then holds the two short end ranges only.
+    // Measured on MI355X at d 400 / B 64 with J = (L-1)/2 and 32 slices (96 workgroups): L 20 3.519 -> 3.485 ms, L 30 9.39 -> 9.21,
+    // L 40 19.88 -> 19.36, L 12 unchanged; later steps or wider launches lose (the part must end before the chains do, and it takes
+    // from them nearly what it removes from the tail: profiles/r03_ubench_priority.txt).  CLIORA_WGRAD_EARLY_STEP = -1 turns it off.
+    static const int early_env = [] { const char* e = getenv("CLIORA_WGRAD_EARLY_STEP"); return e ? atoi(e) : -2; }();
+    static const int early_slices = [] { const char* e = getenv("CLIORA_WGRAD_EARLY_SLICES"); return e ? atoi(e) : 32; }();
+    const int early_auto = L >= 16 ? (L - 1) / 2 : -1;
+    const int early_pick = early_env == -2 ? early_auto : early_env;
+    const int J_early = (p.share && ran_outside && !compress && early_pick >= 0 && early_pick <= L - 3) ? early_pick : -1;
+    long long early_r0 = 0, early_r1 = 0;
     for (int j = 0; j <= L - 1 && !compress; ++j) {
         if (ran_outside) {
             OKR(outside_bwd_step(j));
@@ -701,6 +714,15 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         // the gather of inside level L-1-j reads the outside pairs whose sibling it is: outside levels <= j-1
         if (two_streams && j >= 1) HIPOK(hipStreamWaitEvent(sa, plan->ev_level[j - 1], 0));
         OKR(inside_bwd_step(L - 1 - j));
+        if (j == J_early) {
+            early_r0 = p.row_base_in(L - 1 - j);
+            early_r1 = p.row_base_out(j + 1);
+            HIPOK(hipEventRecord(plan->ev_fork[2], sa));
+            HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
+            if (two_streams) HIPOK(hipStreamWaitEvent(sw, plan->ev_level[j], 0));
+            OKR(launch_tn_pairs(sw, DZ + (size_t)early_r0 * Dp, Xp + (size_t)early_r0 * Dp, (int)(early_r1 - early_r0), Dp, wb + bw.slab2, bw.slab_floats,
+                                wb + bw.gw2o, wb + bw.gb2o, 0, early_slices));
+        }
     }
     // leaves
     hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
@@ -734,8 +756,13 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                 wb + bw.gw2o, wb + bw.gb2o));
         // shared weights: inside and outside pair rows are one contiguous range -> one launch
         const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
+        if (J_early >= 0) {          // the middle of the range is on its way on the GEMM stream (into gw2o / gb2o): the two ends here
+            OKR(launch_tn_pairs(st, DZ, Xp, (int)early_r0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+            OKR(launch_tn_pairs(st, DZ + (size_t)early_r1 * Dp, Xp + (size_t)early_r1 * Dp, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
+                                wb + bw.gw2i, wb + bw.gb2i, 1));
+        } else
         OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
-        if (p.share) {
+        if (p.share && J_early < 0) {
             HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
             HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
         }
