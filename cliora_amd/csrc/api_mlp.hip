@@ -757,9 +757,12 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         // shared weights: inside and outside pair rows are one contiguous range -> one launch
         const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
         if (J_early >= 0) {          // the middle of the range is on its way on the GEMM stream (into gw2o / gb2o): the two ends here
-            OKR(launch_tn_pairs(st, DZ, Xp, (int)early_r0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+            // the two end ranges are short and run beside the side stream's small GEMMs: two thirds of the chip each (c2: 72 / 56 / 40 / 24
+            // slices: 3.497 / 3.484 / 3.481 / 3.547 ms)
+            static const int tail_slices = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES"); return e ? atoi(e) : 48; }();
+            OKR(launch_tn_pairs(st, DZ, Xp, (int)early_r0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0, tail_slices));
             OKR(launch_tn_pairs(st, DZ + (size_t)early_r1 * Dp, Xp + (size_t)early_r1 * Dp, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
-                                wb + bw.gw2i, wb + bw.gb2i, 1));
+                                wb + bw.gw2i, wb + bw.gb2i, 1, tail_slices));
         } else
         OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
         if (p.share && J_early < 0) {
