@@ -287,7 +287,7 @@ static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, B
 // the big weight-gradient GEMM over span-pair rows: C = DZ^T X (Mi = Nj = Dp), LDS-DMA fed, split over row slices
 template <int NIT, int NJT>
 static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, int nkb, float* slab,
-                                size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap) {
+                                size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap, int ldz, int ldx) {
     const size_t per_slice = (size_t)Dp * Dp + Dp;
     int nsl = (int)std::min<size_t>(slab_floats / per_slice, (size_t)std::max(1, 256 / nkb));
     nsl = std::max(1, std::min(nsl, (nrows + 63) / 64));
@@ -296,6 +296,7 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
     nsl = (nrows + rps - 1) / rps;
     float* csl = slab + (size_t)nsl * Dp * Dp;
     const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float) + (size_t)NJT * 2048;   // two fp32 stages + the split column fragments
+    const bool strided = ldz != Dp || ldx != Dp;           // operands that are column blocks of wider matrices: the eight-wave kernel only
     if (split_bf16() && lds3 <= 160 * 1024 && (Dp + NJT * 16) / 32 <= TN3_NP) {
         OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3<NIT, NJT, true>));
         // whole groups of 8 slices (one per XCD), all resident at once: one workgroup per CU, no second round -- and a tenth of the CUs
@@ -311,14 +312,16 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
         if constexpr (NIT == 7 && NJT == 9) {              // d = 400: two waves per SIMD, each with half of the block's j-tiles
             if (eight) {                                   // (the second half has at most NJT - 5 = 4 of its 5 slots taken: the spare one holds the ones-tile)
                 OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3x<NIT, NJT, 5, true>));
-                hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
+                hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, DZ, ldz, X, ldx, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
                 LAUNCHOK("tn_gemm_dma3x");
                 goto reduce;
             }
         }
+        if (strided) return fail(CLIORA_EINVAL, "strided operands need the eight-wave weight-gradient kernel (tn_pairs_strided_ok)");
         hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(256), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
         LAUNCHOK("tn_gemm_dma3");
     } else {
+        if (strided) return fail(CLIORA_EINVAL, "strided operands need the eight-wave weight-gradient kernel (tn_pairs_strided_ok)");
         const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);
         OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma<NIT, NJT, true>));
         hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
@@ -328,24 +331,34 @@ reduce:
     const size_t n = (size_t)Dp * Dp;
     hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, accumulate);
     LAUNCHOK("slab_reduce");
-    hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out, accumulate);
-    LAUNCHOK("slab_reduce(colsum)");
+    if (colsum_out) {
+        hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out, accumulate);
+        LAUNCHOK("slab_reduce(colsum)");
+    }
     return CLIORA_OK;
 }
 
 // accumulate: add to out / colsum_out instead of overwriting; slices_cap > 0: at most that many row slices (= workgroups / nkb)
+// ldz / ldx: row strides of DZ / X when they are Dp-wide column blocks of wider matrices (0: Dp); only where tn_pairs_strided_ok()
+static bool tn_pairs_strided_ok(int Dp) {
+    static const bool eight = [] { const char* e = getenv("CLIORA_WGRAD_WAVES"); return !e || atoi(e) != 4; }();
+    const int NT = Dp / 16;
+    return split_bf16() && eight && NT > 20 && NT <= 27;       // the <7, 9> instance: d = 400
+}
 static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int nrows, int Dp, float* slab, size_t slab_floats,
-                           float* out, float* colsum_out, int accumulate = 0, int slices_cap = 0) {
+                           float* out, float* colsum_out, int accumulate = 0, int slices_cap = 0, int ldz = 0, int ldx = 0) {
+    if (ldz == 0) ldz = Dp;
+    if (ldx == 0) ldx = Dp;
     if (nrows <= 0) {
         if (accumulate) return CLIORA_OK;
         HIPOK(hipMemsetAsync(out, 0, (size_t)Dp * Dp * sizeof(float), st));
-        HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
+        if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
         return CLIORA_OK;
     }
     // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
     // nkb column blocks of NJT = ceil(NT/nkb) j-tiles
     const int NT = Dp / 16;
-#define TN_CASE(nit, njt, nkb) return launch_tn_pairs_inst<nit, njt>(st, DZ, X, nrows, Dp, nkb, slab, slab_floats, out, colsum_out, accumulate, slices_cap)
+#define TN_CASE(nit, njt, nkb) return launch_tn_pairs_inst<nit, njt>(st, DZ, X, nrows, Dp, nkb, slab, slab_floats, out, colsum_out, accumulate, slices_cap, ldz, ldx)
     if (NT <= 4) TN_CASE(1, 4, 1);
     if (NT <= 8) TN_CASE(2, 8, 1);
     if (NT <= 12) TN_CASE(3, 12, 1);

@@ -273,15 +273,29 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
         fork_guard.disarm();
     }
-    if (ran_outside)
-        OKR(launch_tn(st, B * C, ldpo, Dp, Dp, PlainRowsA{dPO, ldpo}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
-                      (float*)nullptr));
+    // Weight gradients of the cell projections: one Dp x Dp block of dP^T H per gate block.  At d = 400 in the default arithmetic every block
+    // runs on the LDS-DMA-fed eight-wave kernel of the DioraMLP pair rows (tn_gemm_dma3x; the blocks of dP are its strided A operand):
+    // 52 480 chart rows x 11 + 5 blocks at L = 40 were 4 ms of register-fed tn_gemm at the end of the step.
+    const bool blockwise = tn_pairs_strided_ok(Dp);
+    if (ran_outside) {
+        if (blockwise) {
+            for (int gI = 0; gI < 5; ++gI)
+                OKR(launch_tn_pairs(st, dPO + (size_t)gI * Dp, OH, B * C, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro + gI * DD, (float*)nullptr, 0, 0, ldpo, Dp));
+        } else
+            OKR(launch_tn(st, B * C, ldpo, Dp, Dp, PlainRowsA{dPO, ldpo}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+                          (float*)nullptr));
+    }
     hipLaunchKernelGGL(lstm_leaf_bwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, VC, IH, IC, ws + f.nrmi, ws + f.nrmic,
                        p.normalize, ws + f.t, dU);
     LAUNCHOK("lstm_leaf_bwd");
     if (d_x_span)
         OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), 3 * Dp, Dp, B * L, PlainRowsA{dU, 3 * Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
-    OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
+    if (blockwise) {
+        for (int gI = 0; gI < p.nblk; ++gI)
+            OKR(launch_tn_pairs(st, dPI + (size_t)gI * Dp, IH, B * C, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gwcat + gI * DD, wb + bw.gbcat + gI * Dp, 0, 0,
+                                ldpi, Dp));
+    } else
+        OKR(launch_tn(st, B * C, ldpi, Dp, Dp, PlainRowsA{dPI, ldpi}, PlainRowsA{IH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
     OKR(launch_tn(st, B * L, 3 * Dp, Dp, Dp, PlainRowsA{dU, 3 * Dp}, PlainRowsA{X, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
     {
         CopyTable t; t.n = 0;

@@ -994,7 +994,7 @@ static __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restri
 // SIMD partner's MFMAs.  Every accumulator tile is still produced by one wave in the same stage and k order: the slab is bitwise the
 // four-wave kernel's.
 template <int NIT, int NJT, int NJW, bool COLSUM>
-static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restrict__ A, const float* __restrict__ B, int nrows,
+static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int nrows,
                                                      int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
                                                      float* __restrict__ slab, float* __restrict__ colsum) {
     static_assert(2 * NJW > NJT, "the second half of the j-tiles needs a spare slot for the ones-tile");
@@ -1059,7 +1059,7 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
             if (piece < npieces) {
                 const bool isA = piece * 64 < UA;
                 const float* base = isA ? A : B;
-                const int ld = isA ? Mi : Nj;
+                const int ld = isA ? lda : ldb;        // row strides of the two operands (Mi / Nj when they are plain matrices)
                 const float* src = base + (size_t)(r0 + min(p_rr[k], rmax)) * ld + p_off[k];
                 __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
             }
