@@ -478,19 +478,34 @@ __global__ __launch_bounds__(256) void level_project(const float* __restrict__ W
         if (row < ncell) st4(P + crow_of(row) * ldp + col, v);
     }
     if (cb == 0 && H) {                       // chart output of the level: wave w writes rows w, w+4, ...
+        // all of the wave's rows are fetched before the first is written: one row after the other (fetch, divide, store, next) made
+        // these blocks -- one in ncolblocks -- a chain of eight dependent round trips, and the launch waits for its slowest block
         const int nv = K >> 2;
-        for (int rr = wave; rr < 16; rr += 4) {
-            const int r = rg * 16 + rr;
+        float4 a[4][2];
+        size_t crow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = rg * 16 + wave + 4 * k;
+            crow[k] = crow_of(r);
+            const float* src = HP + crow[k] * K;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int v4 = lane + 64 * it;
+                a[k][it] = (r < ncell && v4 < nv) ? sum_parts<SP>(src, hp_stride, 4 * v4) : f4zero();
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rr = wave + 4 * k, r = rg * 16 + rr;
             if (r >= ncell) break;
             float nr;
             const float d = den_of(rr, &nr);
-            const size_t crow = crow_of(r);
-            const float* src = HP + crow * K;
-            for (int v4 = lane; v4 < nv; v4 += 64) {
-                const float4 a = sum_parts<SP>(src, hp_stride, 4 * v4);
-                st4(H + crow * K + 4 * v4, make_float4(a.x / d, a.y / d, a.z / d, a.w / d));
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int v4 = lane + 64 * it;
+                if (v4 < nv) st4(H + crow[k] * K + 4 * v4, make_float4(a[k][it].x / d, a[k][it].y / d, a[k][it].z / d, a[k][it].w / d));
             }
-            if (lane == 0) nrm[crow] = nr;
+            if (lane == 0) nrm[crow[k]] = nr;
         }
     }
 }
