@@ -309,17 +309,20 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
         nsl = (nrows + rps - 1) / rps;
         csl = slab + (size_t)nsl * Dp * Dp;
         static const bool eight = [] { const char* e = getenv("CLIORA_WGRAD_WAVES"); return !e || atoi(e) != 4; }();
+        bool launched = false;
         if constexpr (NIT == 7 && NJT == 9) {              // d = 400: two waves per SIMD, each with half of the block's j-tiles
             if (eight) {                                   // (the second half has at most NJT - 5 = 4 of its 5 slots taken: the spare one holds the ones-tile)
                 OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3x<NIT, NJT, 5, true>));
                 hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, DZ, ldz, X, ldx, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
                 LAUNCHOK("tn_gemm_dma3x");
-                goto reduce;
+                launched = true;
             }
         }
-        if (strided) return fail(CLIORA_EINVAL, "strided operands need the eight-wave weight-gradient kernel (tn_pairs_strided_ok)");
-        hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(256), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
-        LAUNCHOK("tn_gemm_dma3");
+        if (!launched) {
+            if (strided) return fail(CLIORA_EINVAL, "strided operands need the eight-wave weight-gradient kernel (tn_pairs_strided_ok)");
+            hipLaunchKernelGGL((tn_gemm_dma3<NIT, NJT, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(256), lds3, st, DZ, X, nrows, rps, nsl, Dp, Dp, nkb, slab, csl);
+            LAUNCHOK("tn_gemm_dma3");
+        }
     } else {
         if (strided) return fail(CLIORA_EINVAL, "strided operands need the eight-wave weight-gradient kernel (tn_pairs_strided_ok)");
         const size_t lds = (size_t)2 * TN_RS * (Dp + NJT * 16) * sizeof(float);
@@ -327,7 +330,6 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
         hipLaunchKernelGGL((tn_gemm_dma<NIT, NJT, true>), dim3(nkb * nsl), dim3(256), lds, st, DZ, X, nrows, rps, Dp, Dp, nkb, slab, csl);
         LAUNCHOK("tn_gemm_dma");
     }
-reduce:
     const size_t n = (size_t)Dp * Dp;
     hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, accumulate);
     LAUNCHOK("slab_reduce");
