@@ -263,6 +263,9 @@ def _dist(a, ref64):
     return dict(q50=float(sub.median()) / sc, q99=float(torch.quantile(sub, 0.99)) / sc, max=float(d.max()) / sc)
 
 
+_FP64_CASE = {}
+
+
 def test_c2_full_size_gradients_vs_fp64(mfma_mode):
     """B = 64, L = 20, D = 400: gradients of the HIP path and of the fp32 oracle, both measured against the fp64 oracle."""
     from cliora_amd.diora import DioraMLP
@@ -283,11 +286,13 @@ def test_c2_full_size_gradients_vs_fp64(mfma_mode):
     torch.cuda.synchronize()
 
     def oracle(dt):
-        Pd = {k: v.detach().to(dt).requires_grad_(True) for k, v in P.items()}
-        xd = x.detach().to(dt).requires_grad_(True)
-        o = R.diora_forward(Pd, xd, xd, training=True)
-        sum((o[k] * cot[k].to(dt)).sum() for k in keys).backward()
-        return Pd, xd, o
+        if dt not in _FP64_CASE:                 # the same two CPU runs serve both arithmetic modes of the GPU path (25 s each)
+            Pd = {k: v.detach().to(dt).requires_grad_(True) for k, v in P.items()}
+            xd = x.detach().to(dt).requires_grad_(True)
+            o = R.diora_forward(Pd, xd, xd, training=True)
+            sum((o[k] * cot[k].to(dt)).sum() for k in keys).backward()
+            _FP64_CASE[dt] = (Pd, xd, {k: o[k].detach() for k in keys})
+        return _FP64_CASE[dt]
     P64, x64, o64 = oracle(torch.float64)
     P32, x32, o32 = oracle(torch.float32)
     named = dict(m.named_parameters())
