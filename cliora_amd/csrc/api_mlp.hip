@@ -745,6 +745,12 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                       (float*)nullptr));
     }
     HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[1], 0));
+    if (vl && d_obj_span) {      // d obj: independent of the weight gradients, so beside the pair rows' tail on the GEMM stream
+        float* dO = padded ? wb + bw.dobjp : d_obj_span;
+        hipLaunchKernelGGL(obj_grad_reduce, dim3(B, (p.R + 3) / 4), dim3(256), 0, sw, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo,
+                           wb + bw.dsc, dO);
+        LAUNCHOK("obj_grad_reduce");
+    }
     OKR(launch_tn(sw, B * tail_cells, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, 0, tail_cells}, LevelRowsA{IH, Dp, C, 0, tail_cells},
                   wb + bw.slab2, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat, tail_cells < C));
     OKR(launch_tn(sw, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
@@ -773,12 +779,6 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     HIPOK(hipStreamWaitEvent(st, plan->ev_join[1], 0));
     fork_guard.disarm();                                   // both side streams have been joined above
 
-    if (vl && d_obj_span) {
-        float* dO = padded ? wb + bw.dobjp : d_obj_span;
-        hipLaunchKernelGGL(obj_grad_reduce, dim3(B, (p.R + 3) / 4), dim3(256), 0, st, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo,
-                           wb + bw.dsc, dO);
-        LAUNCHOK("obj_grad_reduce");
-    }
     // ---- scatter packed gradients back to the reference parameter shapes ----
     {
         CopyTable t; t.n = 0;
