@@ -489,3 +489,26 @@ def test_two_host_threads_make_their_first_call_on_one_cold_plan():
         for i in range(2):
             for k in CHARTS:
                 assert torch.equal(res[i][k], warm[k]), (arch, i, k)
+
+
+@pytest.mark.parametrize('D,B,L', [(64, 3, 17), (96, 2, 20), (400, 1, 16), (33, 5, 18), (256, 2, 16), (400, 7, 23)])
+def test_early_weight_gradient_ranges(D, B, L, mfma_mode):
+    """L >= 16 with shared weights: the pair rows' weight gradient is taken in three pieces -- the finished middle of the rows on the GEMM
+    stream after backward step (L-1)/2, the two end ranges in the tail (api_mlp.hip).  Every width class of the weight-gradient kernels,
+    odd batch sizes, and CLIORA_WGRAD_EARLY_STEP's default against the oracle; the pieces must add up to the reference's dW2 / db2."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    P, x, cot = synth.diora_case(D, B, L, 2024)
+    m = _module_from_params(P, D, True, 'unit')
+    outs, xg = _run_gpu(m, x, cot)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, training=True)
+    sum((ref[k] * cot[k]).sum() for k in CHARTS).backward()
+    for k in CHARTS:
+        assert _err(outs[k], ref[k]) <= OUT_TOL * _scale(ref[k].detach().numpy()), k
+    named = dict(m.named_parameters())
+    for k, p in P.items():
+        _grad_ok(named[k].grad, p.grad, k, mfma_mode)
+    _grad_ok(xg.grad, xc.grad, 'x_span', mfma_mode)
