@@ -737,7 +737,9 @@ static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb
     const float pn = an ? Pp[row0 + lane] : 0.f;
     const float sn = an ? Sp[row0 + lane] : 0.f;
     const float mean = wave_sum(pn * dp);
-    const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + sn - Schart[crow]));
+    // 1 + (s_n - S), in that order: the scores reach 1e8 without unit normalisation, where (1 + s_n) - S loses the 1 (found by
+    // tools/fuzz_parity.py: every gradient through outside_s of a cell with |S| > 2^24 vanished)
+    const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + (sn - Schart[crow])));
     if (an) DS[row0 + lane] = ds;
 }
 

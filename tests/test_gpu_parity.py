@@ -512,3 +512,34 @@ def test_early_weight_gradient_ranges(D, B, L, mfma_mode):
     for k, p in P.items():
         _grad_ok(named[k].grad, p.grad, k, mfma_mode)
     _grad_ok(xg.grad, xc.grad, 'x_span', mfma_mode)
+
+
+@pytest.mark.parametrize('D,B,L', [(64, 2, 8), (24, 3, 7), (96, 1, 12)])
+def test_no_normalization_scores_beyond_2_to_24(D, B, L):
+    """normalize='none': the vectors grow by an order of magnitude per level and the scores pass 1e8.  The softmax backward's factor
+    1 + (s_n - S) must be formed in that order -- as (1 + s_n) - S it loses the 1 beyond 2^24 and every gradient through the score of
+    such a cell vanishes (found by tools/fuzz_parity.py in round 3; the reference's own fixture diora_nonorm.npz stays below 2^24).
+    Exact-fp32 mode, every output and gradient against the oracle, relative to each tensor's scale."""
+    from cliora_amd import _lib
+    from oracle import diora_ref as R
+    from oracle import synth
+    prev = _lib.set_mfma_mode('f32')
+    try:
+        P, x, cot = synth.diora_case(D, B, L, 5)
+        m = _module_from_params(P, D, True, 'none')
+        outs, xg = _run_gpu(m, x, cot)
+        for v in P.values():
+            v.requires_grad_(True)
+        xc = x.clone().requires_grad_(True)
+        ref = R.diora_forward(P, xc, xc, normalize='none', training=True)
+        assert float(ref['outside_s'].abs().max()) > 2.0 ** 24 or L < 8       # the regime the test is about (the small shape is the fixture's)
+        sum((ref[k] * cot[k]).sum() for k in CHARTS).backward()
+        rel = lambda a, b: float((a.detach().double().cpu() - b.detach().double()).abs().max() / (b.detach().double().abs().max() + 1e-30))
+        for k in CHARTS:
+            assert rel(outs[k], ref[k]) <= 2e-5, k
+        named = dict(m.named_parameters())
+        for k, p in P.items():
+            assert rel(named[k].grad, p.grad) <= 2e-5, (k, rel(named[k].grad, p.grad))
+        assert rel(xg.grad, xc.grad) <= 2e-5
+    finally:
+        _lib.set_mfma_mode(prev)
