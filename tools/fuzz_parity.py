@@ -133,6 +133,26 @@ for case in range(n_cases):
             mx, med = rel(gg, gr)
             if med > gtol_med or mx > 0.1:
                 worst.append(('grad ' + k, mx, med))
+        # trees of the evaluation forward (scripts/parse.py: eval mode, no grad) against the oracle's CKY over its own scores; a tree that
+        # differs must be a tie under the REFERENCE's scores (within 1e-4 of the score scale)
+        if L >= 2 and arch != 'cliora':
+            m.eval()
+            with torch.no_grad():
+                xe = x.clone().cuda()
+                m(xe, xe)
+            trees = m.cky()
+            with torch.no_grad():
+                if arch == 'treelstm':
+                    pe = R.diora_forward({k: v.detach() for k, v in P.items()}, x, x, arch='treelstm', share=share, normalize=normalize, keep_pairs=True)
+                else:
+                    pe = R.diora_forward({k: v.detach() for k, v in P.items()}, x, x, share=share, normalize=normalize, keep_pairs=True)
+            want = R.cky_trees(pe['pair_s_in'], B, L)
+            for b in range(B):
+                if str(trees[b]) != str(want[b]):
+                    sc = max(1.0, max(float(v.abs().max()) for v in pe['pair_s_in'].values()))
+                    gap = abs(R.tree_score(pe['pair_s_in'], b, trees[b]) - R.tree_score(pe['pair_s_in'], b, want[b]))
+                    if gap > 1e-4 * sc:
+                        worst.append(('tree of sentence %d' % b, gap / sc))
         if worst:
             bad += 1
             print('MISMATCH', desc, worst[:4], flush=True)
