@@ -72,8 +72,15 @@ class Proj(torch.autograd.Function):
         return d_x, None, d_w, d_b
 
 
+def _pad16(t):
+    """Zero-pad the last dimension to a multiple of 16 (differentiable).  The kernels reduce over 16-wide chunks; the reference's own
+    embedding widths include 300 (GloVe, scripts/train.py:320) and 1324 (w2v + ELMo, data/embeddings.py:141), which are not."""
+    k = t.shape[-1]
+    return t if k % 16 == 0 else torch.nn.functional.pad(t, (0, 16 - k % 16))
+
+
 def proj(x, index, w, bias=None):
-    return Proj.apply(x, index, w, bias)
+    return Proj.apply(_pad16(x), index, _pad16(w), bias)
 
 
 class ReconLoss(torch.autograd.Function):
@@ -121,7 +128,8 @@ class ReconLoss(torch.autograd.Function):
 
 
 def recon_loss(emb, mat, outside_h, tokens, neg):
-    return ReconLoss.apply(emb, mat, outside_h, tokens, neg)
+    # emb (V, E), mat (D, E): the embedding width E is the reduction of the lookup projection
+    return ReconLoss.apply(_pad16(emb), _pad16(mat), outside_h, tokens, neg)
 
 
 class VGLossFn(torch.autograd.Function):

@@ -51,12 +51,21 @@ def test_net_losses_grads_and_three_adam_steps(name, vl, mfma_mode):
     for k, p in net.named_parameters():
         if not p.requires_grad:
             continue
-        want = g['after3__' + k.replace('.', '__')]
+        want = torch.from_numpy(g['after3__' + k.replace('.', '__')])
         # Adam divides every gradient element by its own running magnitude: an element whose gradient is at the rounding-noise
         # level moves by up to lr per step whatever its size, so three steps of the split-bf16 mode (operands rounded to 16 bits)
-        # are held to one lr (1e-3) and the exact-fp32 mode to half of it
+        # are held to half an lr (lr = 2e-3 in the fixtures) and the exact-fp32 mode to a quarter of it
         tol = 5e-4 if mfma_mode == 'f32' else 1e-3
-        assert float((p.detach().cpu() - torch.from_numpy(want)).abs().max()) <= tol * max(1.0, float(np.abs(want).max())), k
+        have = p.detach().cpu()
+        # ... and an element whose TRUE gradient is zero (img_encoder.fc_vis.bias: the same vector added to every region cancels in
+        # the attention softmax; the reference's own value there is 1e-9 of rounding residue) takes a random walk of +-lr per step in
+        # the reference as much as here: such elements are only held to the walk's bound from the starting value
+        g0 = torch.from_numpy(g['grad__' + k.replace('.', '__')]) if 'grad__' + k.replace('.', '__') in g else None
+        noise = (g0.abs() < 1e-7) if g0 is not None else torch.zeros_like(have, dtype=torch.bool)
+        start = torch.from_numpy(g['param__' + k.replace('.', '__')])
+        assert float((have - start)[noise].abs().max() if noise.any() else 0.0) <= 3.2 * g['meta']['lr'], k
+        err = (have - want).abs()[~noise]
+        assert float(err.max() if err.numel() else 0.0) <= tol * max(1.0, float(want.abs().max())), k
 
 
 @pytest.mark.parametrize('B,L,margin', [(64, 20, 1.0), (7, 5, 0.2), (128, 6, 0.5), (2, 3, 1.0)])

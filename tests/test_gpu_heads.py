@@ -1,6 +1,7 @@
 """The callers either side of the chart on this library's kernels (cliora_amd/heads.py, csrc/api_heads.hip) against the torch
 formulas of the oracle (oracle/diora_ref.py restates cliora/net/trainer.py:25-224 and net/utils.py:37-55): values and every
-gradient, at sizes with and without padding (D a multiple of 16 or not, negatives / regions not a multiple of 16 / 64).
+gradient, at sizes with and without padding (D a multiple of 16 or not, negatives / regions not a multiple of 16 / 64, and the
+reference's embedding widths that are not multiples of 16: 300 = GloVe, 1324 = w2v + ELMo).
 Tolerance: 1e-4 of the tensor's scale (fp32 products, other summation order than ATen)."""
 import pytest
 import torch
@@ -14,7 +15,7 @@ def _close(a, b, what, tol=1e-4):
     assert float((a - b).abs().max()) <= tol * sc, (what, float((a - b).abs().max()), sc)
 
 
-@pytest.mark.parametrize('B,L,V,E,D', [(5, 7, 50, 32, 48), (64, 20, 2000, 1024, 400), (3, 4, 20, 16, 50)])
+@pytest.mark.parametrize('B,L,V,E,D', [(5, 7, 50, 32, 48), (64, 20, 2000, 1024, 400), (3, 4, 20, 16, 50), (4, 6, 80, 300, 400), (2, 5, 40, 1324, 64)])
 def test_embed_projection(B, L, V, E, D):
     from cliora_amd import heads
     from oracle import diora_ref as R
@@ -55,7 +56,7 @@ def test_image_encoder_projection(B, R, K, D):
         _close(a.grad, b.grad, n)
 
 
-@pytest.mark.parametrize('B,L,V,E,D,K', [(4, 6, 60, 32, 48, 7), (64, 20, 2000, 1024, 400, 100), (2, 5, 40, 16, 50, 20)])
+@pytest.mark.parametrize('B,L,V,E,D,K', [(4, 6, 60, 32, 48, 7), (64, 20, 2000, 1024, 400, 100), (2, 5, 40, 16, 50, 20), (3, 7, 90, 300, 400, 25)])
 def test_reconstruction_loss(B, L, V, E, D, K):
     from cliora_amd import heads
     from oracle import diora_ref as R
