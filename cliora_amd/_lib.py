@@ -123,6 +123,8 @@ def lib():
     L.cliora_set_wavefront.restype = i32
     L.cliora_set_rows_stationary.argtypes = [i32]
     L.cliora_set_rows_stationary.restype = i32
+    L.cliora_set_resident.argtypes = [i32]
+    L.cliora_set_resident.restype = i32
     L.cliora_set_persistent.argtypes = [i32]
     L.cliora_set_persistent.restype = i32
     L.cliora_persistent_status.argtypes = [vp, C.POINTER(C.c_uint), vp]
@@ -234,6 +236,13 @@ def set_wavefront(mode):
     reference's order on the caller's stream alone) or 'on'.  Results are bitwise identical.  Returns the previous mode."""
     prev = lib().cliora_set_wavefront(WAVEFRONT_MODES[mode])
     return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
+
+
+def set_resident(mode):
+    """One workgroup per sentence for the level loops of a small-D DioraMLP plan (include/cliora_chart.h: cliora_set_resident):
+    'auto' (default), 'off', 'on'.  Returns the previous mode's name."""
+    prev = lib().cliora_set_resident(WAVEFRONT_MODES[mode])
+    return {v: k for k, v in WAVEFRONT_MODES.items()}[prev]
 
 
 def set_persistent(mode):

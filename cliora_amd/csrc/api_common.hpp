@@ -103,6 +103,8 @@ extern int g_cliora_wavefront;      // -1 auto, 0 off, 1 on (include/cliora_char
 extern int g_cliora_rows_stationary; // -1 auto, 0 off, 1 every eligible level, 2 the rows-stationary geometry on the weight-stationary kernel (tests)
 extern int g_cliora_rs_min_rows;      // auto: levels with at least this many pair rows (CLIORA_RS_MIN_ROWS)
 extern int g_cliora_persistent;     // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_persistent)
+extern int g_cliora_resident;       // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_resident)
+extern int g_cliora_resident_max_pairs;   // auto: span pairs per sentence (both passes) up to which the sentence-resident kernels are taken
 extern int g_cliora_split_bf16;
 static inline bool split_bf16() {
     if (g_cliora_split_bf16 < 0) {

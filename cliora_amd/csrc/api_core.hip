@@ -341,6 +341,13 @@ extern "C" int cliora_set_rows_stationary(int mode) {
     g_cliora_rows_stationary = mode < 0 ? -1 : std::min(mode, 2);
     return prev;
 }
+int g_cliora_resident = [] { const char* e = getenv("CLIORA_RESIDENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+int g_cliora_resident_max_pairs = [] { const char* e = getenv("CLIORA_RESIDENT_MAX_PAIRS"); return e ? atoi(e) : 1000; }();
+extern "C" int cliora_set_resident(int mode) {
+    const int prev = g_cliora_resident;
+    g_cliora_resident = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
+    return prev;
+}
 extern "C" int cliora_set_persistent(int mode) {
     const int prev = g_cliora_persistent;
     g_cliora_persistent = mode < 0 ? -1 : (mode != 0 ? 1 : 0);

@@ -4,6 +4,7 @@
 #include "level_kernels.hpp"
 #include "compose_rs_kernels.hpp"
 #include "persist_kernels.hpp"
+#include "resident_kernels.hpp"
 #include "vl_kernels.hpp"
 
 // the attention kernels keep a wave's regions in registers: 9 per wave cover R <= 36 (the reference's 36 boxes), 16 cover R <= 64
@@ -214,6 +215,48 @@ static bool persist_pays(const cliora_plan* plan, bool vl) {
     return true;
 }
 
+// One workgroup per sentence for every level of both passes (resident_kernels.hpp) when a row fits a wavefront: text-only DioraMLP,
+// Dp <= 64, no per-pair hook states.  Measured on MI355X (tools/resident_ab.py, profiles/r03_resident_ab.txt), ms launches -> resident:
+//   backward  D 50 / B 8 / L 10  0.63 -> 0.38,  D 32 / B 64 / L 12  0.85 -> 0.67,  D 16 / B 128 / L 8  0.59 -> 0.42;  D 64 / B 64 / L 16  1.11 -> 1.33
+//   forward   D 50 / B 8 / L 10  0.197 -> 0.210 (the persistent forward is as good there), D 50 / B 256 / L 10  0.31 -> 0.24,
+//             D 16 / B 128 / L 8  0.157 -> 0.093;  D 64 / B 64 / L 16  0.37 -> 0.51
+// so AUTO takes it while a sentence's chart is short (span pairs per sentence, both passes, <= g_cliora_resident_max_pairs = 1000:
+// L <= 12) -- the backward always, the forward where one workgroup per sentence fills the chip or the rows are narrow (B >= 128 or
+// Dp <= 32).  The two directions share every buffer format, so each is chosen on its own.
+// cliora_set_resident / CLIORA_RESIDENT=0|1 force it off / on (on is still refused for shapes the kernels do not cover).
+static size_t resident_lds_bytes(const Plan& p) {
+    return ((size_t)(p.share ? 6 : 8) * p.Dp * p.Dp + (size_t)RES_WAVES * RES_SCR) * sizeof(float);
+}
+static bool resident_pays(const cliora_plan* plan, bool vl, bool compress, bool backward) {
+    const Plan& p = plan->p;
+    if (g_cliora_resident == 0 || vl || compress || p.arch != 0 || p.L < 2 || p.Dp > 64) return false;
+    if (resident_lds_bytes(p) > 160 * 1024) return false;
+    if (g_cliora_resident < 0) {
+        if (p.P_in + p.P_out > g_cliora_resident_max_pairs) return false;
+        if (!backward && !(p.B >= 128 || p.Dp <= 32)) return false;
+    }
+    return true;
+}
+static ResArgs resident_args(const cliora_plan* plan, float* ws, float* IH, float* OH, float* IS, float* OS, int run_outside) {
+    const Plan& p = plan->p;
+    const FwdLayout& f = p.fwd;
+    const Dev dv = dev_views(p);
+    ResArgs a{};
+    a.tabs = p.d_tables;
+    a.pa_in = (uint32_t)p.dev.pair_a_in; a.pb_in = (uint32_t)p.dev.pair_b_in; a.pa_out = (uint32_t)p.dev.pair_a_out; a.pb_out = (uint32_t)p.dev.pair_b_out;
+    a.lvl_in = (uint32_t)p.dev.lvl_base_in; a.lvl_out = (uint32_t)p.dev.lvl_base_out;
+    a.use_ina = dv.use[ROLE_INA]; a.use_inb = dv.use[ROLE_INB]; a.use_outa = dv.use[ROLE_OUTA]; a.use_outb = dv.use[ROLE_OUTB];
+    a.B = p.B; a.L = p.L; a.C = p.C; a.D = p.D; a.Dp = p.Dp; a.ldpi = p.nblk * p.Dp; a.nblk = p.nblk; a.blk_plo = p.blk_plo; a.blk_qlo = p.blk_qlo;
+    a.share = p.share; a.normalize = p.normalize; a.run_outside = run_outside; a.ct = f.ct3; a.gy = f.ncb3; a.R_in = p.R_in;
+    a.IH = IH; a.OH = OH; a.IS = IS; a.OS = OS; a.PI = ws + f.pi; a.PO = ws + f.po; a.nrmi = ws + f.nrmi; a.nrmo = ws + f.nrmo;
+    a.Sp = ws + f.sp; a.Pp = ws + f.pp; a.ymask = reinterpret_cast<uint32_t*>(ws + f.ymask);
+    a.wcatT = ws + f.wcatT; a.bcat = ws + f.bcat; a.w2iT = ws + f.w2iT; a.b2i = ws + f.b2i; a.w2oT = ws + f.w2oT; a.b2o = ws + f.b2o;
+    a.w1roT = ws + f.w1roT; a.rootp = ws + f.rootp;
+    a.wcat = ws + f.wcat; a.w2i = ws + f.w2i; a.w2o = ws + f.w2o; a.w1ro = ws + f.w1ro;
+    a.T = ws + f.t;
+    return a;
+}
+
 // ------------------------------------------------------------------ forward
 extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
                                     const float* drop_mask, float* inside_h, float* inside_s, float* outside_h,
@@ -382,8 +425,9 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
-    const bool persist = !compress && persist_pays(plan, vl);
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress;
+    const bool resident = !PH && resident_pays(plan, vl, compress, false);
+    const bool persist = !resident && !compress && persist_pays(plan, vl);
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress && !resident;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
     auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
@@ -440,7 +484,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         return CLIORA_OK;
     };
 
-    if (L > 1) {
+    if (L > 1 && !resident) {
         // QR = M h of the leaves: the partner of a newest-level LEFT child is always a leaf (see level_project)
         OKR(launch_rows_direct(st, ws + f.matp, PROJ_IMG(f.matq3), Dp, Dp, B * L, LevelRowsA{IH, Dp, C, 0, L},
                                StoreRowsE{ws + f.qrleaf, Dp, nullptr, 0, Dp}));
@@ -454,6 +498,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // root of the outside chart (diora.py:337-356) and the scores of the level below it: parents = the root only.  compress = True:
     // the root of sentence b is unit(inside_h[b, root] @ root_mat_out) -- one row per sentence, after the inside pass.
     auto init_root = [&]() -> int {
+        if (run_outside && resident) return CLIORA_OK;      // the sentence's workgroup forms its own root row
         if (run_outside) {
             if (compress)
                 OKR(launch_rows_direct(sb, ws + f.rootw, PROJ_IMG(f.rootw3), Dp, Dp, B, LevelRowsA{IH, Dp, C, C - 1, 1},
@@ -503,7 +548,18 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         }
         HIPOK(hipEventRecord(plan->ev_persist, st));
     }
-    for (int k = 1; k <= L && !persist; ++k) {
+    if (resident) {
+        // ---- one workgroup per sentence, every level of both passes (resident_kernels.hpp) ----
+        ResArgs a = resident_args(plan, ws, IH, OH, IS, OS, run_outside);
+        if (!keep) a.ymask = nullptr;
+        static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
+        a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
+        OKR(cliora_ensure_max_lds((const void*)resident_fwd));
+        ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+        hipLaunchKernelGGL(resident_fwd, dim3(std::min(B, std::max(1, plan->ncu))), dim3(RES_THREADS), resident_lds_bytes(p), st, a);
+        LAUNCHOK("resident_fwd");
+    }
+    for (int k = 1; k <= L && !persist && !resident; ++k) {
         if (k <= L - 1) {
             OKR(inside_step(k));
             if (two_streams) HIPOK(hipEventRecord(plan->ev_level[k], sa));
@@ -593,7 +649,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // inside level L-1-j on the caller's stream, which waits for the event of outside step j-1 (see cliora_chart_forward).
     // compress = True: the outside root's gradient flows into the inside root, so the outside backward ends before the inside one starts
     const bool compress = P && P->root_mat;
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside && !compress;
+    const bool resident = resident_pays(plan, vl, compress, true);
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside && !compress && !resident;
     hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
     float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
 
@@ -704,9 +761,25 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     static const int early_slices = [] { const char* e = getenv("CLIORA_WGRAD_EARLY_SLICES"); return e ? atoi(e) : 32; }();
     const int early_auto = L >= 16 ? (L - 1) / 2 : -1;
     const int early_pick = early_env == -2 ? early_auto : early_env;
-    const int J_early = (p.share && ran_outside && !compress && early_pick >= 0 && early_pick <= L - 3) ? early_pick : -1;
+    const int J_early = (p.share && ran_outside && !compress && !resident && early_pick >= 0 && early_pick <= L - 3) ? early_pick : -1;
     long long early_r0 = 0, early_r1 = 0;
-    for (int j = 0; j <= L - 1 && !compress; ++j) {
+    if (resident) {
+        // ---- both chains and the leaves' pre-activation gradient: one workgroup per sentence (resident_kernels.hpp) ----
+        ResArgs a = resident_args(plan, ws, const_cast<float*>(IH), const_cast<float*>(OH), const_cast<float*>(IS), const_cast<float*>(OS), ran_outside);
+        a.dIH = d_inside_h; a.dIS = d_inside_s; a.dOH = d_outside_h; a.dOS = d_outside_s;
+        a.VHo = VHo; a.dPI = dPI; a.dPO = dPO; a.DA = DA; a.DS = DS; a.DZ = DZ; a.X = Xp; a.dU = dU;
+        OKR(cliora_ensure_max_lds((const void*)resident_bwd));
+        {
+            ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);
+            hipLaunchKernelGGL(resident_bwd, dim3(std::min(B, std::max(1, plan->ncu))), dim3(RES_THREADS), resident_lds_bytes(p), st, a);
+            LAUNCHOK("resident_bwd");
+        }
+        if (ran_outside) {
+            hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, st, B, C, Dp, VHo, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+            LAUNCHOK("root_bwd");
+        }
+    }
+    for (int j = 0; j <= L - 1 && !compress && !resident; ++j) {
         if (ran_outside) {
             OKR(outside_bwd_step(j));
             if (two_streams) HIPOK(hipEventRecord(plan->ev_level[j], sb));
@@ -725,8 +798,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         }
     }
     // leaves
-    hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
-    LAUNCHOK("leaf_bwd_pre");
+    if (!resident) {
+        hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
+        LAUNCHOK("leaf_bwd_pre");
+    }
     if (d_x_span)
         OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
 

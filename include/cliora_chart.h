@@ -318,6 +318,18 @@ int cliora_set_wavefront(int mode);
 int cliora_set_persistent(int mode);
 int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
 
+/* One workgroup per sentence.  For a text-only DioraMLP plan whose rows fit a wavefront (D <= 64; BASELINE configs[0]) the level
+ * loops of the forward (cliora/net/diora.py:312-331, 378-398) and of the backward run inside ONE launch each, a workgroup walking
+ * every level of one sentence's chart with workgroup barriers between them (csrc/resident_kernels.hpp): sentences exchange nothing
+ * inside the recursion.  AUTO (the default; CLIORA_RESIDENT=0|1 sets the initial value) takes it for short sentences
+ * (CLIORA_RESIDENT_MAX_PAIRS span pairs per sentence, both passes), OFF never, ON for every shape the kernels cover.  Same buffers
+ * and formats as the launch-per-level path, exact fp32 FMA arithmetic, results equal to fp32 rounding.  Process-wide; returns the
+ * previous mode. */
+#define CLIORA_RESIDENT_AUTO (-1)
+#define CLIORA_RESIDENT_OFF 0
+#define CLIORA_RESIDENT_ON 1
+int cliora_set_resident(int mode);
+
 /* Rows-stationary forward compose (csrc/compose_rs_kernels.hpp) for the big levels of a d = 400 DioraMLP / CLIORA plan: the two
  * operand rows of a span pair (cliora/net/diora.py:112-118, get_inside_states) are gathered ONCE and kept in registers while the
  * second compose layer's weight (diora.py:65-72) streams through LDS, instead of once per block of 80 output columns.  AUTO
