@@ -216,24 +216,24 @@ static bool persist_pays(const cliora_plan* plan, bool vl) {
 }
 
 // One workgroup per sentence for every level of both passes (resident_kernels.hpp) when a row fits a wavefront: text-only DioraMLP,
-// Dp <= 64, no per-pair hook states.  Measured on MI355X (tools/resident_ab.py, profiles/r03_resident_ab.txt), ms launches -> resident:
-//   backward  D 50 / B 8 / L 10  0.63 -> 0.38,  D 32 / B 64 / L 12  0.85 -> 0.67,  D 16 / B 128 / L 8  0.59 -> 0.42;  D 64 / B 64 / L 16  1.11 -> 1.33
-//   forward   D 50 / B 8 / L 10  0.197 -> 0.210 (the persistent forward is as good there), D 50 / B 256 / L 10  0.31 -> 0.24,
-//             D 16 / B 128 / L 8  0.157 -> 0.093;  D 64 / B 64 / L 16  0.37 -> 0.51
-// so AUTO takes it while a sentence's chart is short (span pairs per sentence, both passes, <= g_cliora_resident_max_pairs = 1000:
-// L <= 12) -- the backward always, the forward where one workgroup per sentence fills the chip or the rows are narrow (B >= 128 or
-// Dp <= 32).  The two directions share every buffer format, so each is chosen on its own.
+// Dp <= 64, no per-pair hook states.  Measured on MI355X (tools/resident_ab.py, profiles/r03_resident_ab.txt), forward / forward +
+// backward ms, launches (persistent forward where AUTO takes it) -> resident:
+//   D 50 / B 8 / L 10 (configs[0])   0.198 -> 0.196 / 0.80 -> 0.56        D 50 / B 256 / L 10   0.31 -> 0.23 / 1.59 -> 1.25
+//   D 32 / B 64 / L 12               0.246 -> 0.211 / 1.07 -> 0.86        D 16 / B 128 / L 8    0.159 -> 0.094 / 0.75 -> 0.51
+//   D 64 / B 64 / L 16               0.36 -> 0.46 / 1.40 -> 1.81          D 64 / B 8 / L 40     1.19 -> 3.84 / 3.0 -> 11.7
+// one workgroup (8 waves) per sentence is a chain of 2 (L - 1) levels of 7-8 us each whatever the batch, so AUTO takes it while a
+// sentence's chart is short: span pairs per sentence, both passes, <= g_cliora_resident_max_pairs = 1000 (L <= 12).  The two
+// directions share every buffer format with the launch path, so either can run on either (tests/test_gpu_resident.py).
 // cliora_set_resident / CLIORA_RESIDENT=0|1 force it off / on (on is still refused for shapes the kernels do not cover).
 static size_t resident_lds_bytes(const Plan& p) {
     return ((size_t)(p.share ? 6 : 8) * p.Dp * p.Dp + (size_t)RES_WAVES * RES_SCR) * sizeof(float);
 }
-static bool resident_pays(const cliora_plan* plan, bool vl, bool compress, bool backward) {
+static bool resident_pays(const cliora_plan* plan, bool vl, bool compress, bool /*backward*/) {
     const Plan& p = plan->p;
     if (g_cliora_resident == 0 || vl || compress || p.arch != 0 || p.L < 2 || p.Dp > 64) return false;
     if (resident_lds_bytes(p) > 160 * 1024) return false;
     if (g_cliora_resident < 0) {
         if (p.P_in + p.P_out > g_cliora_resident_max_pairs) return false;
-        if (!backward && !(p.B >= 128 || p.Dp <= 32)) return false;
     }
     return true;
 }
@@ -768,6 +768,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         ResArgs a = resident_args(plan, ws, const_cast<float*>(IH), const_cast<float*>(OH), const_cast<float*>(IS), const_cast<float*>(OS), ran_outside);
         a.dIH = d_inside_h; a.dIS = d_inside_s; a.dOH = d_outside_h; a.dOS = d_outside_s;
         a.VHo = VHo; a.dPI = dPI; a.dPO = dPO; a.DA = DA; a.DS = DS; a.DZ = DZ; a.X = Xp; a.dU = dU;
+        static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
+        a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
         OKR(cliora_ensure_max_lds((const void*)resident_bwd));
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);

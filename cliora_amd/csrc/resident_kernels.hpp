@@ -26,9 +26,9 @@
 
 namespace cliora {
 
-constexpr int RES_WAVES = 8;
+constexpr int RES_WAVES = 12;
 constexpr int RES_THREADS = RES_WAVES * 64;
-constexpr int RES_R = 4;                     // pair rows per pass over a weight matrix
+constexpr int RES_R = 8;                     // pair rows per pass over a weight matrix
 
 struct ResArgs {
     const int32_t* tabs;                     // the plan's int32 tables
@@ -50,6 +50,7 @@ struct ResArgs {
     unsigned long long* trace;               // diagnostics (CLIORA_RES_TRACE=1): wall-clock stamps of workgroup 0, wave 0
 };
 
+#define RES_STAMPW(i) do { if (a.trace && blockIdx.x == 0 && lane == 0) a.trace[(i)] = wall_clock64(); } while (0)
 #define RES_STAMP(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[(i)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ float res_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
@@ -87,13 +88,13 @@ __device__ __forceinline__ float res_wave_max(float v) {
 // blocks of eight k, double-buffered, with scheduling barriers that keep each block where it is written.
 // One wave's LDS instructions execute in order: the broadcast reads see the parked values.
 typedef float res_f2 __attribute__((ext_vector_type(2)));
-constexpr int RES_SCR = 320;                 // floats of LDS scratch per wave: four parked rows [k][4] + one more row [k]
+constexpr int RES_SCR = 576;                 // floats of LDS scratch per wave: eight parked rows [k][8] (or four [k][4] + one more row [k] at 256)
 
 __device__ __forceinline__ void res_park_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void res_park4(float* xs, int lane, bool act, const float (&x)[RES_R]) {
+__device__ __forceinline__ void res_park4(float* xs, int lane, bool act, const float (&x)[4]) {
     if (act) *reinterpret_cast<float4*>(xs + 4 * lane) = make_float4(x[0], x[1], x[2], x[3]);
     res_park_sync();
 }
@@ -102,38 +103,52 @@ __device__ __forceinline__ void res_park1(float* xs, int lane, bool act, float x
     res_park_sync();
 }
 
-// four rows at once: out[r][lane] += sum_k Wt[k][lane] * xs[k][r]
-__device__ __forceinline__ void res_matvec4(const float* Wt, int ld, int Dp, int lc, const float* xs, float (&out)[RES_R]) {
-    res_f2 o01 = {out[0], out[1]}, o23 = {out[2], out[3]};
-    float wA[8], wB[8];
-    float4 xA[8], xB[8];
-    auto load = [&](float (&w)[8], float4 (&x)[8], int k0) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            w[kk] = Wt[(k0 + kk) * ld + lc];
-            x[kk] = *reinterpret_cast<const float4*>(xs + 4 * (k0 + kk));
-        }
-    };
-    auto mac = [&](const float (&w)[8], const float4 (&x)[8]) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const res_f2 ww = {w[kk], w[kk]};
-            o01 = __builtin_elementwise_fma(ww, res_f2{x[kk].x, x[kk].y}, o01);
-            o23 = __builtin_elementwise_fma(ww, res_f2{x[kk].z, x[kk].w}, o23);
-        }
-    };
-    load(wA, xA, 0);
-    for (int k0 = 0; k0 < Dp; k0 += 16) {
-        load(wB, xB, k0 + 8);
-        __builtin_amdgcn_sched_barrier(0);
-        mac(wA, xA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 16 < Dp) load(wA, xA, k0 + 16);
-        __builtin_amdgcn_sched_barrier(0);
-        mac(wB, xB);
-        __builtin_amdgcn_sched_barrier(0);
+// eight rows at once: out[r][lane] += sum_k W[k][lane] * xs[k][r].  The weight sits in LDS interleaved by four k
+// (Wq[((k >> 2) * Dp + lane) * 4 + (k & 3)]): one 16-byte read gives a lane its weights of four k, eight broadcast reads the operands.
+__device__ __forceinline__ void res_park8(float* xs, int lane, bool act, const float (&x)[RES_R]) {
+    if (act) {
+        *reinterpret_cast<float4*>(xs + 8 * lane) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(xs + 8 * lane + 4) = make_float4(x[4], x[5], x[6], x[7]);
     }
-    out[0] = o01.x; out[1] = o01.y; out[2] = o23.x; out[3] = o23.y;
+    res_park_sync();
+}
+__device__ __forceinline__ void res_matvec8(const float* Wq, int Dp, int lc, const float* xs, float (&out)[RES_R]) {
+    res_f2 o0 = {out[0], out[1]}, o1 = {out[2], out[3]}, o2 = {out[4], out[5]}, o3 = {out[6], out[7]};
+    // phases of two k (four broadcast reads, eight packed FMAs), double-buffered; the lane's weights of four k arrive as one read
+    float4 w, wn, xA[4], xB[4];
+    auto load = [&](float4 (&x)[4], int k0) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            x[2 * kk] = *reinterpret_cast<const float4*>(xs + 8 * (k0 + kk));
+            x[2 * kk + 1] = *reinterpret_cast<const float4*>(xs + 8 * (k0 + kk) + 4);
+        }
+    };
+    auto mac = [&](float w0, float w1, const float4 (&x)[4]) {
+        const float wv[2] = {w0, w1};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const res_f2 ww = {wv[kk], wv[kk]};
+            o0 = __builtin_elementwise_fma(ww, res_f2{x[2 * kk].x, x[2 * kk].y}, o0);
+            o1 = __builtin_elementwise_fma(ww, res_f2{x[2 * kk].z, x[2 * kk].w}, o1);
+            o2 = __builtin_elementwise_fma(ww, res_f2{x[2 * kk + 1].x, x[2 * kk + 1].y}, o2);
+            o3 = __builtin_elementwise_fma(ww, res_f2{x[2 * kk + 1].z, x[2 * kk + 1].w}, o3);
+        }
+    };
+    w = *reinterpret_cast<const float4*>(Wq + (size_t)lc * 4);
+    load(xA, 0);
+    for (int k0 = 0; k0 < Dp; k0 += 4) {
+        load(xB, k0 + 2);
+        wn = *reinterpret_cast<const float4*>(Wq + ((size_t)(min(k0 + 4, Dp - 4) >> 2) * Dp + lc) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(w.x, w.y, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 4 < Dp) load(xA, k0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(w.z, w.w, xB);
+        __builtin_amdgcn_sched_barrier(0);
+        w = wn;
+    }
+    out[0] = o0.x; out[1] = o0.y; out[2] = o1.x; out[3] = o1.y; out[4] = o2.x; out[5] = o2.y; out[6] = o3.x; out[7] = o3.y;
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -171,7 +186,8 @@ __device__ __forceinline__ float res_matvec1(const float* Wt, int ld, int Dp, in
 // k gives a lane its four block weights) and W5[k * Dp + lane] for the fifth block of an unshared plan.
 //   forward   o[blk][lane] = bias + sum_k Wcat[blk*Dp + lane][k] h[k]          W4 indexed (k, lane): h parked as one row
 //   backward  v[lane]     += sum_col sum_blk dP[blk][col] Wcat[blk*Dp + col][lane]   W4 indexed (col, lane): dP parked [col][4] (+ [col])
-__device__ __forceinline__ void res_project_fwd(const float* W4, const float* W5, int nblk, int Dp, int lc, const float* xs, float (&o)[5]) {
+template <bool FIVE>
+__device__ __forceinline__ void res_project_fwd(const float* W4, const float* W5, int Dp, int lc, const float* xs, float (&o)[5]) {
     res_f2 o01 = {o[0], o[1]}, o23 = {o[2], o[3]};
     float o4 = o[4];
     float4 wA[4], wB[4], xA, xB;
@@ -180,7 +196,7 @@ __device__ __forceinline__ void res_project_fwd(const float* W4, const float* W5
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             w[kk] = *reinterpret_cast<const float4*>(W4 + ((size_t)(k0 + kk) * Dp + lc) * 4);
-            v[kk] = nblk > 4 ? W5[(k0 + kk) * Dp + lc] : 0.f;
+            v[kk] = FIVE ? W5[(k0 + kk) * Dp + lc] : 0.f;
         }
         x = *reinterpret_cast<const float4*>(xs + k0);
     };
@@ -191,7 +207,7 @@ __device__ __forceinline__ void res_project_fwd(const float* W4, const float* W5
             const res_f2 xx = {xv[kk], xv[kk]};
             o01 = __builtin_elementwise_fma(res_f2{w[kk].x, w[kk].y}, xx, o01);
             o23 = __builtin_elementwise_fma(res_f2{w[kk].z, w[kk].w}, xx, o23);
-            o4 = fmaf(v[kk], xv[kk], o4);
+            if (FIVE) o4 = fmaf(v[kk], xv[kk], o4);
         }
     };
     load(wA, vA, xA, 0);
@@ -208,7 +224,8 @@ __device__ __forceinline__ void res_project_fwd(const float* W4, const float* W5
     o[0] = o01.x; o[1] = o01.y; o[2] = o23.x; o[3] = o23.y; o[4] = o4;
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ float res_project_bwd(const float* W4, const float* W5, int nblk, int Dp, int lc, const float* xs4, const float* xs5) {
+template <bool FIVE>
+__device__ __forceinline__ float res_project_bwd(const float* W4, const float* W5, int Dp, int lc, const float* xs4, const float* xs5) {
     res_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
     float a4 = 0.f;
     float4 wA[4], wB[4], xA[4], xB[4], yA, yB;
@@ -217,10 +234,10 @@ __device__ __forceinline__ float res_project_bwd(const float* W4, const float* W
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             w[kk] = *reinterpret_cast<const float4*>(W4 + ((size_t)(c0 + kk) * Dp + lc) * 4);
-            v[kk] = nblk > 4 ? W5[(c0 + kk) * Dp + lc] : 0.f;
+            v[kk] = FIVE ? W5[(c0 + kk) * Dp + lc] : 0.f;
             x[kk] = *reinterpret_cast<const float4*>(xs4 + 4 * (c0 + kk));
         }
-        y = *reinterpret_cast<const float4*>(xs5 + c0);
+        y = FIVE ? *reinterpret_cast<const float4*>(xs5 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto mac = [&](const float4 (&w)[4], const float (&v)[4], const float4 (&x)[4], const float4& y) {
         const float yv[4] = {y.x, y.y, y.z, y.w};
@@ -228,7 +245,7 @@ __device__ __forceinline__ float res_project_bwd(const float* W4, const float* W
         for (int kk = 0; kk < 4; ++kk) {
             a01 = __builtin_elementwise_fma(res_f2{w[kk].x, w[kk].y}, res_f2{x[kk].x, x[kk].y}, a01);
             a23 = __builtin_elementwise_fma(res_f2{w[kk].z, w[kk].w}, res_f2{x[kk].z, x[kk].w}, a23);
-            a4 = fmaf(v[kk], yv[kk], a4);
+            if (FIVE) a4 = fmaf(v[kk], yv[kk], a4);
         }
     };
     load(wA, vA, xA, yA, 0);
@@ -284,17 +301,17 @@ __device__ __forceinline__ float res_cell_fwd(const ResArgs& a, const ResPass& q
     load_x(0, xa, xb);
     const float sa = q.SA[bC + ca], sb = q.SB[bC + cb];
     float my_s = -INFINITY;
-    for (int n0 = 0; n0 < N; n0 += 2 * RES_R) {            // eight splits' operand rows in flight
-        float d[2 * RES_R];
+    for (int n0 = 0; n0 < N; n0 += RES_R) {                // eight splits' operand rows in flight
+        float d[RES_R];
 #pragma unroll
-        for (int r = 0; r < 2 * RES_R; ++r) {
+        for (int r = 0; r < RES_R; ++r) {
             const int n = min(n0 + r, N - 1);
             const int can = res_bcast_i(ca, n), cbn = res_bcast_i(cb, n);
             d[r] = act ? q.QA[(bC + can) * q.ldq + lane] * q.HB[(bC + cbn) * Dp + lane] : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 2 * RES_R; ++r) {
+        for (int r = 0; r < RES_R; ++r) {
             if (n0 + r >= N) break;                            // wave-uniform
             const float s = res_wave_sum(d[r]);
             if (lane == n0 + r) my_s = (s + sa) + sb;
@@ -317,10 +334,10 @@ __device__ __forceinline__ float res_cell_fwd(const ResArgs& a, const ResPass& q
             x[r] = fmaxf(xa[r] + xb[r], 0.f);
             z[r] = q.b2;
         }
-        res_park4(xs, lane, act, x);
+        res_park8(xs, lane, act, x);
         if (n0 + RES_R < N) load_x(n0 + RES_R, xa, xb);      // the next chunk's rows travel under this chunk's layer
         __builtin_amdgcn_sched_barrier(0);
-        res_matvec4(q.W2, Dp, Dp, lc, xs, z);
+        res_matvec8(q.W2, Dp, lc, xs, z);
 #pragma unroll
         for (int r = 0; r < RES_R; ++r) {
             const int n = n0 + r;
@@ -368,10 +385,11 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
         sW4[i] = blk < a.nblk ? a.wcatT[(size_t)k * ldpi + blk * Dp + col] : 0.f;
     }
     for (int i = threadIdx.x; i < Dp * Dp; i += RES_THREADS) {
-        sW2i[i] = a.w2iT[i];
+        const int qi = (((i / Dp) >> 2) * Dp + i % Dp) * 4 + ((i / Dp) & 3);      // interleaved by four k (res_matvec8)
+        sW2i[qi] = a.w2iT[i];
         sW1ro[i] = a.w1roT[i];
         if (!a.share) {
-            sW2o[i] = a.w2oT[i];
+            sW2o[qi] = a.w2oT[i];
             const int k = i / Dp, col = i - k * Dp;
             sW5[i] = a.wcatT[(size_t)k * ldpi + 4 * Dp + col];
         }
@@ -386,37 +404,45 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t bC = (size_t)b * C;
-        // ---- inside pass (diora.py:295-331); the leaves' rows and projections are there already
-        for (int level = 1; level < L; ++level) {
+        auto inside_cell = [&](int level, int p) {           // diora.py:295-331 for one cell; the leaves' rows and projections are there already
             ResPass q;
             q.Lc = L - level; q.N = level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = (long long)a.B * lvl_in[level];
             q.pa = a.tabs + a.pa_in + lvl_in[level]; q.pb = a.tabs + a.pb_in + lvl_in[level];
             q.QA = a.PI + 2 * Dp; q.ldq = ldpi; q.XA = a.PI; q.ldxa = ldpi; q.XB = a.PI + Dp; q.ldxb = ldpi;
             q.HB = a.IH; q.SA = a.IS; q.SB = a.IS; q.W2 = sW2i; q.b2 = b2i; q.H = a.IH; q.nrm = a.nrmi; q.S = a.IS;
-            RES_STAMP(4 * level + 0);
-            for (int p = wave; p < q.Lc; p += RES_WAVES) {
-                const float h = res_cell_fwd(a, q, b, p, lane, act, lc, xs, 256 + 8 * level);
-                RES_STAMP(4 * level + 1);
-                if (level < L - 1) {                          // [PL | PR | QL | (PLo | QLo)] = h Wcat^T + bias
-                    float o[5];
+            const float h = res_cell_fwd(a, q, b, p, lane, act, lc, xs, 256 + 8 * level);
+            RES_STAMP(4 * level + 1);
+            if (level < L - 1) {                              // [PL | PR | QL | (PLo | QLo)] = h Wcat^T + bias
+                float o[5];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) o[k] = bc[k];
-                    res_park1(xs, lane, act, h);
-                    res_project_fwd(sW4, sW5, a.nblk, Dp, lc, xs, o);
-                    float* dst = a.PI + (bC + q.off + p) * ldpi + lane;
+                for (int k = 0; k < 5; ++k) o[k] = bc[k];
+                res_park1(xs, lane, act, h);
+                if (a.nblk > 4) res_project_fwd<true>(sW4, sW5, Dp, lc, xs, o);
+                else res_project_fwd<false>(sW4, sW5, Dp, lc, xs, o);
+                float* dst = a.PI + (bC + q.off + p) * ldpi + lane;
 #pragma unroll
-                    for (int k = 0; k < 5; ++k)
-                        if (act && k < a.nblk) dst[k * Dp] = o[k];
-                }
-                RES_STAMP(4 * level + 2);
+                for (int k = 0; k < 5; ++k)
+                    if (act && k < a.nblk) dst[k * Dp] = o[k];
             }
-            __syncthreads();
-            RES_STAMP(4 * level + 3);
-        }
-        if (!a.run_outside) continue;
-        // ---- outside pass (diora.py:337-398): root, then the levels top-down
-        if (wave == 0) {
+            RES_STAMP(4 * level + 2);
+        };
+        auto outside_cell = [&](int level, int p) {          // diora.py:358-398 for one cell
+            ResPass q;
+            q.Lc = L - level; q.N = L - 1 - level; q.off = C - (L - level) * (L - level + 1) / 2;
+            q.rowbase = a.R_in + (long long)a.B * lvl_out[level];
+            q.pa = a.tabs + a.pa_out + lvl_out[level]; q.pb = a.tabs + a.pb_out + lvl_out[level];
+            q.QA = a.PI + (size_t)a.blk_qlo * Dp; q.ldq = ldpi; q.XA = a.PI + (size_t)a.blk_plo * Dp; q.ldxa = ldpi; q.XB = a.PO; q.ldxb = Dp;
+            q.HB = a.OH; q.SA = a.IS; q.SB = a.OS; q.W2 = sW2o; q.b2 = b2o; q.H = a.OH; q.nrm = a.nrmo; q.S = a.OS;
+            const float h = res_cell_fwd(a, q, b, p, lane, act, lc, xs);
+            if (level >= 1) {                                 // PRo of the new parents
+                res_park1(xs, lane, act, h);
+                const float o = res_matvec1(sW1ro, Dp, Dp, lc, xs, 0.f);
+                if (act) a.PO[(bC + q.off + p) * Dp + lane] = o;
+            }
+        };
+        // root of the outside chart (diora.py:337-356): the last wave, beside the first inside level
+        if (a.run_outside && wave == RES_WAVES - 1) {
             const float v = act ? a.rootp[lane] : 0.f;
             const float nr = sqrtf(res_wave_sum(v * v));
             const float den = a.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
@@ -428,23 +454,19 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             const float o = res_matvec1(sW1ro, Dp, Dp, lc, xs, 0.f);
             if (act) a.PO[crow * Dp + lane] = o;
         }
-        __syncthreads();
-        for (int level = L - 2; level >= 0; --level) {
-            ResPass q;
-            q.Lc = L - level; q.N = L - 1 - level; q.off = C - (L - level) * (L - level + 1) / 2;
-            q.rowbase = a.R_in + (long long)a.B * lvl_out[level];
-            q.pa = a.tabs + a.pa_out + lvl_out[level]; q.pb = a.tabs + a.pb_out + lvl_out[level];
-            q.QA = a.PI + (size_t)a.blk_qlo * Dp; q.ldq = ldpi; q.XA = a.PI + (size_t)a.blk_plo * Dp; q.ldxa = ldpi; q.XB = a.PO; q.ldxb = Dp;
-            q.HB = a.OH; q.SA = a.IS; q.SB = a.OS; q.W2 = sW2o; q.b2 = b2o; q.H = a.OH; q.nrm = a.nrmo; q.S = a.OS;
-            for (int p = wave; p < q.Lc; p += RES_WAVES) {
-                const float h = res_cell_fwd(a, q, b, p, lane, act, lc, xs);
-                if (level >= 1) {                             // PRo of the new parents
-                    res_park1(xs, lane, act, h);
-                    const float o = res_matvec1(sW1ro, Dp, Dp, lc, xs, 0.f);
-                    if (act) a.PO[(bC + q.off + p) * Dp + lane] = o;
-                }
+        // The two passes as a wavefront (cliora_chart_forward): outside level t composes parents of the outside
+        // levels above it with siblings of the inside levels <= L-2-t, so step k runs inside level k AND outside level L-k: L steps
+        // instead of 2 (L-1), and the cells of a step are (L-k) + k = L whatever k -- every step fills the same number of waves.
+        for (int k = 1; k <= L; ++k) {
+            const int nin = k <= L - 1 ? L - k : 0;
+            const int nout = (a.run_outside && k >= 2) ? k : 0;
+            RES_STAMP(4 * k + 0);
+            for (int t = wave; t < nin + nout; t += RES_WAVES) {
+                if (t < nin) inside_cell(k, t);
+                else outside_cell(L - k, t - nin);
             }
             __syncthreads();
+            RES_STAMP(4 * k + 3);
         }
     }
 }
@@ -509,30 +531,19 @@ __device__ __forceinline__ void res_cell_pairs_bwd(const ResArgs& a, const ResPa
     const int by = lc / cw, cc = (lc % cw) >> 4, g = (lc & 15) >> 2, e = lc & 3;
     const int nw = a.gy * 4;
     float dp_l = 0.f;
-    uint32_t wd[RES_R];
-    float xsum[RES_R];
-    auto load_ops = [&](int n0, uint32_t (&w)[RES_R], float (&xv)[RES_R]) {
-#pragma unroll
-        for (int r = 0; r < RES_R; ++r) {
-            const int n = min(n0 + r, N - 1);
-            w[r] = a.ymask[(row0 + n) * nw + by * 4 + g];
-            const int can = res_bcast_i(ca, n), cbn = res_bcast_i(cb, n);
-            xv[r] = act ? q.XA[(bC + can) * q.ldxa + lane] + q.XB[(bC + cbn) * q.ldxb + lane] : 0.f;
-        }
-    };
-    load_ops(0, wd, xsum);
     for (int n0 = 0; n0 < N; n0 += RES_R) {
         float dzu[RES_R], u[RES_R], xs[RES_R];
 #pragma unroll
         for (int r = 0; r < RES_R; ++r) {
-            dzu[r] = (act && ((wd[r] >> (4 * cc + e)) & 1u)) ? dG : 0.f;
+            const int n = min(n0 + r, N - 1);
+            const uint32_t word = a.ymask[(row0 + n) * nw + by * 4 + g];
+            const int can = res_bcast_i(ca, n), cbn = res_bcast_i(cb, n);
+            xs[r] = act ? q.XA[(bC + can) * q.ldxa + lane] + q.XB[(bC + cbn) * q.ldxb + lane] : 0.f;
+            dzu[r] = (act && ((word >> (4 * cc + e)) & 1u)) ? dG : 0.f;
             u[r] = 0.f;
-            xs[r] = xsum[r];
         }
-        res_park4(scr, lane, act, dzu);
-        if (n0 + RES_R < N) load_ops(n0 + RES_R, wd, xsum);  // the next chunk's operands travel under this chunk's layer
-        __builtin_amdgcn_sched_barrier(0);
-        res_matvec4(q.W2, Dp, Dp, lc, scr, u);
+        res_park8(scr, lane, act, dzu);
+        res_matvec8(q.W2, Dp, lc, scr, u);
 #pragma unroll
         for (int r = 0; r < RES_R; ++r) {
             const int n = n0 + r;
@@ -574,10 +585,11 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
         sW4[i] = blk < a.nblk ? a.wcat[((size_t)blk * Dp + col) * Dp + k] : 0.f;
     }
     for (int i = threadIdx.x; i < Dp * Dp; i += RES_THREADS) {
-        sW2i[i] = a.w2i[i];
+        const int qi = (((i / Dp) >> 2) * Dp + i % Dp) * 4 + ((i / Dp) & 3);      // interleaved by four z (res_matvec8)
+        sW2i[qi] = a.w2i[i];
         sW1ro[i] = a.w1ro[i];
         if (!a.share) {
-            sW2o[i] = a.w2o[i];
+            sW2o[qi] = a.w2o[i];
             sW5[i] = a.wcat[(size_t)4 * Dp * Dp + i];
         }
     }
@@ -589,77 +601,94 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t bC = (size_t)b * C;
-        // ---- outside chain, leaves first (a parent's uses are the pairs of the levels below it)
-        for (int level = 0; level < L && a.run_outside; ++level) {
+        auto outside_cell = [&](int level, int p) {          // a parent's uses are the pairs of the outside levels below it
             ResPass q;
             q.Lc = L - level; q.N = L - 1 - level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = a.R_in + (long long)a.B * lvl_out[level];          // (the root level has no pairs: N = 0)
             q.pa = a.tabs + a.pa_out + lvl_out[level]; q.pb = a.tabs + a.pb_out + lvl_out[level];
             q.XA = a.PI + (size_t)a.blk_plo * Dp; q.ldxa = ldpi; q.XB = a.PO; q.ldxb = Dp;
             q.W2 = sW2o; q.b2 = b2o; q.S = a.OS;
-            for (int p = wave; p < q.Lc; p += RES_WAVES) {
-                const int c = q.off + p;
-                const size_t crow = bC + c;
-                float dpo = 0.f, v = 0.f, vS = 0.f;
-                res_gather(a.use_outb, c, b, bC, a.DA, a.DS, Dp, a.PI + (size_t)a.blk_qlo * Dp, ldpi, lane, act, dpo, v, vS);
-                v += (ext && a.dOH) ? a.dOH[crow * D + lane] : 0.f;
-                if (level < L - 1 && a.dOS) vS += a.dOS[crow];
-                if (act) a.dPO[crow * Dp + lane] = dpo;
-                if (level >= 1) {                              // vH += dPRo . W1R_out
-                    res_park1(scr, lane, act, dpo);
-                    const float o = res_matvec1(sW1ro, Dp, Dp, lc, scr, 0.f);
-                    v += act ? o : 0.f;
-                }
-                if (level == L - 1) {                          // the root: root_bwd sums its unit-norm backward over the batch
-                    if (act) a.VHo[crow * Dp + lane] = v;
-                    continue;
-                }
-                const float h = act ? a.OH[crow * Dp + lane] : 0.f;
-                const float dG = res_dnorm(v, h, a.nrmo[crow], a.normalize);
-                res_cell_pairs_bwd(a, q, b, p, lane, act, lc, dG, vS, scr);
+            const int c = q.off + p;
+            const size_t crow = bC + c;
+            const int tb = 512 + 16 * level;
+            if (p == 0) RES_STAMPW(tb + 0);
+            float dpo = 0.f, v = 0.f, vS = 0.f;
+            res_gather(a.use_outb, c, b, bC, a.DA, a.DS, Dp, a.PI + (size_t)a.blk_qlo * Dp, ldpi, lane, act, dpo, v, vS);
+            v += (ext && a.dOH) ? a.dOH[crow * D + lane] : 0.f;
+            if (level < L - 1 && a.dOS) vS += a.dOS[crow];
+            if (p == 0) RES_STAMPW(tb + 1);
+            if (act) a.dPO[crow * Dp + lane] = dpo;
+            if (level >= 1) {                                  // vH += dPRo . W1R_out
+                res_park1(scr, lane, act, dpo);
+                const float o = res_matvec1(sW1ro, Dp, Dp, lc, scr, 0.f);
+                v += act ? o : 0.f;
             }
-            __syncthreads();
-        }
-        // ---- inside chain, root first
-        for (int level = L - 1; level >= 0; --level) {
+            if (level == L - 1) {                              // the root: root_bwd sums its unit-norm backward over the batch
+                if (act) a.VHo[crow * Dp + lane] = v;
+                return;
+            }
+            if (p == 0) RES_STAMPW(tb + 2);
+            const float h = act ? a.OH[crow * Dp + lane] : 0.f;
+            const float dG = res_dnorm(v, h, a.nrmo[crow], a.normalize);
+            if (p == 0) RES_STAMPW(tb + 3);
+            res_cell_pairs_bwd(a, q, b, p, lane, act, lc, dG, vS, scr);
+            if (p == 0) RES_STAMPW(tb + 4);
+        };
+        auto inside_cell = [&](int level, int p) {
             ResPass q;
             q.Lc = L - level; q.N = level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = (long long)a.B * lvl_in[level];
             q.pa = a.tabs + a.pa_in + lvl_in[level]; q.pb = a.tabs + a.pb_in + lvl_in[level];
             q.XA = a.PI; q.ldxa = ldpi; q.XB = a.PI + Dp; q.ldxb = ldpi;
             q.W2 = sW2i; q.b2 = b2i; q.S = a.IS;
-            for (int p = wave; p < q.Lc; p += RES_WAVES) {
-                const int c = q.off + p;
-                const size_t crow = bC + c;
-                float dPL = 0.f, dPR = 0.f, dQL = 0.f, dPLo = 0.f, dQLo = 0.f, v = 0.f, vS = 0.f;
-                res_gather(a.use_inb, c, b, bC, a.DA, a.DS, Dp, a.PI + 2 * Dp, ldpi, lane, act, dPR, v, vS);      // right-child uses
-                res_gather(a.use_ina, c, b, bC, a.DA, a.DS, Dp, a.IH, Dp, lane, act, dPL, dQL, vS);                // left-child uses
-                if (a.run_outside) res_gather(a.use_outa, c, b, bC, a.DA, a.DS, Dp, a.OH, Dp, lane, act, dPLo, dQLo, vS);   // sibling uses
-                if (a.share) { dPL += dPLo; dQL += dQLo; }
-                float blk[5] = {dPL, dPR, dQL, dPLo, dQLo};
-                float* o = a.dPI + crow * ldpi + lane;
+            const int c = q.off + p;
+            const size_t crow = bC + c;
+            const int tb = 512 + 16 * (L - 1 - level) + 8;
+            if (p == 0) RES_STAMPW(tb + 0);
+            float dPL = 0.f, dPR = 0.f, dQL = 0.f, dPLo = 0.f, dQLo = 0.f, v = 0.f, vS = 0.f;
+            res_gather(a.use_inb, c, b, bC, a.DA, a.DS, Dp, a.PI + 2 * Dp, ldpi, lane, act, dPR, v, vS);      // right-child uses
+            res_gather(a.use_ina, c, b, bC, a.DA, a.DS, Dp, a.IH, Dp, lane, act, dPL, dQL, vS);                // left-child uses
+            if (a.run_outside) res_gather(a.use_outa, c, b, bC, a.DA, a.DS, Dp, a.OH, Dp, lane, act, dPLo, dQLo, vS);   // sibling uses
+            if (p == 0) RES_STAMPW(tb + 1);
+            if (a.share) { dPL += dPLo; dQL += dQLo; }
+            float blk[5] = {dPL, dPR, dQL, dPLo, dQLo};
+            float* o = a.dPI + crow * ldpi + lane;
 #pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    if (act && k < a.nblk) o[k * Dp] = blk[k];
-                v += (ext && a.dIH) ? a.dIH[crow * D + lane] : 0.f;
-                if (level >= 1 && a.dIS) vS += a.dIS[crow];
-                if (level <= L - 2) {                          // vH += dP . Wcat
-                    const float b4[RES_R] = {blk[0], blk[1], blk[2], a.nblk > 3 ? blk[3] : 0.f};
-                    if (act) scr[256 + lane] = a.nblk > 4 ? blk[4] : 0.f;
-                    res_park4(scr, lane, act, b4);
-                    const float acc = res_project_bwd(sW4, sW5, a.nblk, Dp, lc, scr, scr + 256);
-                    v += act ? acc : 0.f;
-                }
-                const float h = act ? a.IH[crow * Dp + lane] : 0.f;
-                const float dG = res_dnorm(v, h, a.nrmi[crow], a.normalize);
-                if (level == 0) {                              // leaves: H = unit(T), T = tanh(U)  (leaf_bwd_pre)
-                    const size_t r = (size_t)b * L + p;
-                    if (act) { const float t = a.T[r * Dp + lane]; a.dU[r * Dp + lane] = dG * (1.f - t * t); }
-                    continue;
-                }
-                res_cell_pairs_bwd(a, q, b, p, lane, act, lc, dG, vS, scr);
+            for (int k = 0; k < 5; ++k)
+                if (act && k < a.nblk) o[k * Dp] = blk[k];
+            v += (ext && a.dIH) ? a.dIH[crow * D + lane] : 0.f;
+            if (level >= 1 && a.dIS) vS += a.dIS[crow];
+            if (level <= L - 2) {                              // vH += dP . Wcat
+                const float b4[4] = {blk[0], blk[1], blk[2], a.nblk > 3 ? blk[3] : 0.f};
+                if (act) scr[256 + lane] = a.nblk > 4 ? blk[4] : 0.f;
+                res_park4(scr, lane, act, b4);
+                const float acc = a.nblk > 4 ? res_project_bwd<true>(sW4, sW5, Dp, lc, scr, scr + 256) : res_project_bwd<false>(sW4, sW5, Dp, lc, scr, scr + 256);
+                v += act ? acc : 0.f;
+            }
+            if (p == 0) RES_STAMPW(tb + 2);
+            const float h = act ? a.IH[crow * Dp + lane] : 0.f;
+            const float dG = res_dnorm(v, h, a.nrmi[crow], a.normalize);
+            if (p == 0) RES_STAMPW(tb + 3);
+            if (level == 0) {                                  // leaves: H = unit(T), T = tanh(U)  (leaf_bwd_pre)
+                const size_t r = (size_t)b * L + p;
+                if (act) { const float t = a.T[r * Dp + lane]; a.dU[r * Dp + lane] = dG * (1.f - t * t); }
+                return;
+            }
+            res_cell_pairs_bwd(a, q, b, p, lane, act, lc, dG, vS, scr);
+            if (p == 0) RES_STAMPW(tb + 4);
+        };
+        // The two chains as a wavefront (cliora_chart_backward): the backward of outside level t only feeds inside cells of the levels
+        // <= L-2-t (its siblings), so step j runs outside level j AND inside level L-1-j -- whose gathers read the outside pair rows
+        // of the levels <= j-1, written in earlier steps: L steps of (L-j) + (j+1) = L+1 cells each.
+        for (int j = 0; j <= L - 1; ++j) {
+            const int nout = a.run_outside ? L - j : 0;
+            const int nin = j + 1;
+            for (int t = wave; t < nout + nin; t += RES_WAVES) {
+                if (t < nout) outside_cell(j, t);
+                else inside_cell(L - 1 - j, t - nout);
             }
             __syncthreads();
+            RES_STAMP(512 + 16 * j + 7);
         }
     }
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Random-shape parity sweep of the HIP path against the CPU oracle (outputs and gradients), over the module variants and the schedule
-switches: DioraMLP / CLIORA / DioraTreeLSTM, share, normalize, compress, arithmetic mode, wavefront, persistent, rows-stationary.
-Not a test (the committed tests pin chosen cases): a tool for hunting shape-dependent bugs.   python tools/fuzz_parity.py [n] [seed]"""
+switches: DioraMLP / CLIORA / DioraTreeLSTM, share, normalize, compress, arithmetic mode, wavefront, persistent, rows-stationary, sentence-resident.
+Not a test (the committed tests pin chosen cases): a tool for hunting shape-dependent bugs.   python tools/fuzz_parity.py [n] [seed] [small]
+('small': text-only DioraMLP at D <= 64 only -- the shapes of the sentence-resident kernels)"""
 import os
 import random
 import sys
@@ -17,6 +18,7 @@ from oracle import diora_ref as R                            # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 KEYS = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
+SMALL = len(sys.argv) > 3 and sys.argv[3] == 'small'
 
 
 def load(m, P, share):
@@ -39,6 +41,8 @@ t0 = time.time()
 for case in range(n_cases):
     arch = rnd.choice(['mlp', 'mlp', 'cliora', 'treelstm'])
     D = rnd.choice([16, 33, 48, 64, 96, 128, 200, 256, 400, 400])
+    if SMALL:
+        arch, D = 'mlp', rnd.choice([5, 16, 20, 33, 48, 50, 64])
     L = rnd.randint(1, 22 if D <= 128 else 18)
     B = rnd.randint(1, 5)
     share = rnd.random() < 0.6
@@ -50,10 +54,11 @@ for case in range(n_cases):
     mode = rnd.choice(['f32', 'bf16x3'])
     wf, ps = rnd.choice(['auto', 'off', 'on']), rnd.choice(['auto', 'off', 'on'])
     rs = rnd.choice(['auto', 'on', 'geometry']) if D == 400 else 'auto'
+    rd = rnd.choice(['auto', 'off', 'on']) if D <= 64 else 'auto'
     seed = rnd.randint(0, 10 ** 6)
     desc = dict(arch=arch, D=D, L=L, B=B, share=share, normalize=normalize, compress=compress, R=Rr if arch == 'cliora' else 0, mode=mode,
-                wavefront=wf, persistent=ps, rows_stationary=rs, seed=seed)
-    _lib.set_mfma_mode(mode); _lib.set_wavefront(wf); _lib.set_persistent(ps); _lib.set_rows_stationary(rs)
+                wavefront=wf, persistent=ps, rows_stationary=rs, resident=rd, seed=seed)
+    _lib.set_mfma_mode(mode); _lib.set_wavefront(wf); _lib.set_persistent(ps); _lib.set_rows_stationary(rs); _lib.set_resident(rd)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, L, D, generator=g)
     C = L * (L + 1) // 2
