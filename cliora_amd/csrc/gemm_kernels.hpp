@@ -31,16 +31,35 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Wave-wide sum / max, the butterfly lane ^ 32, ^ 16, ... ^ 1.  Rounds 1-2 ran it on __shfl_xor (ds_bpermute: six dependent
+// LDS-crossbar round trips, 180 ns per reduction on MI355X); the same pairs in the same order on gfx950's v_permlane32_swap /
+// v_permlane16_swap (the halves / the odd and even rows of the wave exchanged) and DPP row moves take 69 ns and give the SAME BITS
+// (tools/ubench/wave_reduce_bench.hip, profiles/r03_ubench_wave_reduce.txt: 0 mismatches in 262 144 waves) -- every score, norm and
+// softmax kernel is a chain of these.  All 64 lanes must be active (true at every call site: the callers branch per wave).
+template <int CTRL, int BANK>
+__device__ __forceinline__ float wave_dpp(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK, false));
+}
+template <class Op>
+__device__ __forceinline__ float wave_butterfly(float v, Op op) {
+    {   // lane ^ 32
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {   // lane ^ 16
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    v = op(v, wave_dpp<0x128, 0xf>(v, v));                                                   // row_ror:8 = lane ^ 8
+    { float t = wave_dpp<0x104, 0x5>(v, v); t = wave_dpp<0x114, 0xA>(t, v); v = op(v, t); }   // row_shl:4 | row_shr:4 by bank = lane ^ 4
+    v = op(v, wave_dpp<0x4E, 0xf>(v, v));                                                    // quad_perm [2,3,0,1] = lane ^ 2
+    v = op(v, wave_dpp<0xB1, 0xf>(v, v));                                                    // quad_perm [1,0,3,2] = lane ^ 1
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+struct WaveAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct WaveMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+__device__ __forceinline__ float wave_sum(float v) { return wave_butterfly(v, WaveAdd()); }
+__device__ __forceinline__ float wave_max(float v) { return wave_butterfly(v, WaveMax()); }
 
 // Lane maps of a 16-row operand tile.  The MFMA wants lane l to hold row (l & 15), k-piece (l >> 4) -- but gfx950 coalesces
 // the addresses of CONSECUTIVE lanes, so a gather issued in that map is 64 separate 16-byte requests per instruction and runs at
