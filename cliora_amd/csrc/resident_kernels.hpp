@@ -405,6 +405,10 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t bC = (size_t)b * C;
         auto inside_cell = [&](int level, int p) {           // diora.py:295-331 for one cell; the leaves' rows and projections are there already
+            // the lane index made opaque per cell: hipcc otherwise hoists one 64-bit per-lane address per array out of the whole level loop
+            // (~50 VGPRs of kernel-invariant pointers) and spills them at the 168-VGPR cap of twelve waves
+            int lane_o = lane; asm volatile("" : "+v"(lane_o));
+            const int lane = lane_o; const bool act = lane < Dp; const int lc = min(lane, Dp - 1);
             ResPass q;
             q.Lc = L - level; q.N = level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = (long long)a.B * lvl_in[level];
@@ -428,6 +432,8 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             RES_STAMP(4 * level + 2);
         };
         auto outside_cell = [&](int level, int p) {          // diora.py:358-398 for one cell
+            int lane_o = lane; asm volatile("" : "+v"(lane_o));
+            const int lane = lane_o; const bool act = lane < Dp; const int lc = min(lane, Dp - 1);
             ResPass q;
             q.Lc = L - level; q.N = L - 1 - level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = a.R_in + (long long)a.B * lvl_out[level];
@@ -573,7 +579,6 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Dp = a.Dp, ldpi = a.ldpi, L = a.L, C = a.C, D = a.D;
     const bool act = lane < Dp;
-    const int lc = min(lane, Dp - 1);
     float* sW4 = res_lds;                                     // [col][k][4]: projection blocks 0..3, interleaved
     float* sW2i = sW4 + 4 * Dp * Dp;                          // [z][x]
     float* sW1ro = sW2i + Dp * Dp;                            // [col][k]
@@ -597,11 +602,13 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
     __syncthreads();
     const int32_t* lvl_in = a.tabs + a.lvl_in;
     const int32_t* lvl_out = a.tabs + a.lvl_out;
-    const bool ext = lane < D;
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t bC = (size_t)b * C;
         auto outside_cell = [&](int level, int p) {          // a parent's uses are the pairs of the outside levels below it
+            int lane_o = lane; asm volatile("" : "+v"(lane_o));
+            const int lane = lane_o; const bool act = lane < Dp; const int lc = min(lane, Dp - 1);
+            const bool ext = lane < D;
             ResPass q;
             q.Lc = L - level; q.N = L - 1 - level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = a.R_in + (long long)a.B * lvl_out[level];          // (the root level has no pairs: N = 0)
@@ -635,6 +642,9 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
             if (p == 0) RES_STAMPW(tb + 4);
         };
         auto inside_cell = [&](int level, int p) {
+            int lane_o = lane; asm volatile("" : "+v"(lane_o));
+            const int lane = lane_o; const bool act = lane < Dp; const int lc = min(lane, Dp - 1);
+            const bool ext = lane < D;
             ResPass q;
             q.Lc = L - level; q.N = level; q.off = C - (L - level) * (L - level + 1) / 2;
             q.rowbase = (long long)a.B * lvl_in[level];
