@@ -226,7 +226,7 @@ static bool persist_pays(const cliora_plan* plan, bool vl) {
 // directions share every buffer format with the launch path, so either can run on either (tests/test_gpu_resident.py).
 // cliora_set_resident / CLIORA_RESIDENT=0|1 force it off / on (on is still refused for shapes the kernels do not cover).
 static size_t resident_lds_bytes(const Plan& p) {
-    return ((size_t)(p.share ? 6 : 8) * p.Dp * p.Dp + (size_t)RES_WAVES * RES_SCR) * sizeof(float);
+    return ((size_t)(p.share ? 7 : 8) * p.Dp * p.Dp + (size_t)RES_WAVES * RES_SCR) * sizeof(float);      // shared plans: + the leaf weight
 }
 static bool resident_pays(const cliora_plan* plan, bool vl, bool compress, bool /*backward*/) {
     const Plan& p = plan->p;
@@ -253,7 +253,7 @@ static ResArgs resident_args(const cliora_plan* plan, float* ws, float* IH, floa
     a.wcatT = ws + f.wcatT; a.bcat = ws + f.bcat; a.w2iT = ws + f.w2iT; a.b2i = ws + f.b2i; a.w2oT = ws + f.w2oT; a.b2o = ws + f.b2o;
     a.w1roT = ws + f.w1roT; a.rootp = ws + f.rootp;
     a.wcat = ws + f.wcat; a.w2i = ws + f.w2i; a.w2o = ws + f.w2o; a.w1ro = ws + f.w1ro;
-    a.T = ws + f.t;
+    a.T = ws + f.t; a.wlT = ws + f.wlT; a.wl = ws + f.wl; a.bl = ws + f.bl;
     return a;
 }
 
@@ -349,8 +349,10 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
-    OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
-    if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
+    const bool resident = !(run_outside & CLIORA_FWD_PAIR_STATES) && resident_pays(plan, vl, compress, false);     // its workgroups do the leaves too
+    if (!resident) OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
+    if (resident) {
+    } else if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
         LevelArgs g0 = level_args(p, 0, false);
         ATTEND_LAUNCH(cell_attend_fwd, p.R, dim3(B * L), st, g0, L, (const float*)nullptr, (size_t)0, 0,
                            ws + f.t, OBJ, p.R, drop_mask, p.normalize, IH, ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk,
@@ -361,7 +363,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                            IH, ws + f.nrmi, IS);
         LAUNCHOK("unit_norm_rows");
     }
-    if (L > 1)
+    if (L > 1 && !resident)
         OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L},
                         StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
 
@@ -425,7 +427,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
-    const bool resident = !PH && resident_pays(plan, vl, compress, false);
     const bool persist = !resident && !compress && persist_pays(plan, vl);
     const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress && !resident;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
@@ -551,6 +552,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     if (resident) {
         // ---- one workgroup per sentence, every level of both passes (resident_kernels.hpp) ----
         ResArgs a = resident_args(plan, ws, IH, OH, IS, OS, run_outside);
+        a.X = X;
         if (!keep) a.ymask = nullptr;
         static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
         a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
@@ -767,7 +769,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         // ---- both chains and the leaves' pre-activation gradient: one workgroup per sentence (resident_kernels.hpp) ----
         ResArgs a = resident_args(plan, ws, const_cast<float*>(IH), const_cast<float*>(OH), const_cast<float*>(IS), const_cast<float*>(OS), ran_outside);
         a.dIH = d_inside_h; a.dIS = d_inside_s; a.dOH = d_outside_h; a.dOS = d_outside_s;
-        a.VHo = VHo; a.dPI = dPI; a.dPO = dPO; a.DA = DA; a.DS = DS; a.DZ = DZ; a.X = Xp; a.dU = dU;
+        a.VHo = VHo; a.dPI = dPI; a.dPO = dPO; a.DA = DA; a.DS = DS; a.DZ = DZ; a.Xrows = Xp; a.dU = dU; a.dX = d_x_span;
         static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
         a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
         OKR(cliora_ensure_max_lds((const void*)resident_bwd));
@@ -804,7 +806,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         hipLaunchKernelGGL(leaf_bwd_pre, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, VH, IHn, nrmIn, p.normalize, ws + f.t, dU);
         LAUNCHOK("leaf_bwd_pre");
     }
-    if (d_x_span)
+    if (d_x_span && !resident)
         OKR(launch_rows_direct(st, ws + f.wlT, PROJ_IMG(f.wlT3), Dp, Dp, B * L, PlainRowsA{dU, Dp}, StoreRowsE{d_x_span, D, nullptr, 0, D}));
 
     // ---- weight gradients: the cell projections' and the leaf layer's on the GEMM stream, the pair rows' dW2 (tn_gemm_dma3 fills

@@ -45,8 +45,10 @@ struct ResArgs {
     const float *wcat, *w2i, *w2o, *w1ro;                                      // backward: the weights as they are ([col][k])
     // backward
     const float *dIH, *dIS, *dOH, *dOS;      // cotangents of the four outputs (row stride D)
-    const float* T;                          // tanh output of the leaf layer (B*L x Dp)
-    float *VHo, *dPI, *dPO, *DA, *DS, *DZ, *X, *dU;
+    float* T;                                // tanh output of the leaf layer (B*L x Dp): written by the forward, read by the backward
+    const float *X, *wlT, *bl, *wl;          // leaf layer (diora.py:58-63): input rows (B*L x Dp), Wl^T ([k][col]), bias, Wl ([col][k])
+    float* dX;                               // d x_span (row stride D) or nullptr
+    float *VHo, *dPI, *dPO, *DA, *DS, *DZ, *Xrows, *dU;
     unsigned long long* trace;               // diagnostics (CLIORA_RES_TRACE=1): wall-clock stamps of workgroup 0, wave 0
 };
 
@@ -380,6 +382,14 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
     float* sW2o = a.share ? sW2i : sW1ro + Dp * Dp;
     float* sW5 = sW1ro + 2 * Dp * Dp;                         // [k][col]: the fifth block (unshared plans only)
     float* xs = sW1ro + (a.share ? 1 : 3) * Dp * Dp + wave * RES_SCR;            // this wave's operand scratch
+    // the leaf layer's weight: beside the scratch when there is room (shared plans: 139 KB in all), from global memory otherwise
+    const float* sWl = a.wlT;
+    if (a.share) {
+        float* dst = sW1ro + Dp * Dp + RES_WAVES * RES_SCR;
+        for (int i = threadIdx.x; i < Dp * Dp; i += RES_THREADS) dst[i] = a.wlT[i];
+        sWl = dst;
+    }
+    const float bl = act ? a.bl[lane] : 0.f;
     for (int i = threadIdx.x; i < 4 * Dp * Dp; i += RES_THREADS) {
         const int blk = i & 3, kc = i >> 2, k = kc / Dp, col = kc - k * Dp;
         sW4[i] = blk < a.nblk ? a.wcatT[(size_t)k * ldpi + blk * Dp + col] : 0.f;
@@ -447,7 +457,32 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
                 if (act) a.PO[(bC + q.off + p) * Dp + lane] = o;
             }
         };
-        // root of the outside chart (diora.py:337-356): the last wave, beside the first inside level
+        // leaves (diora.py:58-63, 283-292): h = unit(tanh(x Wl^T + bl)), score 0, and their projections
+        for (int p = wave; p < L; p += RES_WAVES) {
+            const size_t r = (size_t)b * L + p, crow = bC + p;
+            res_park1(xs, lane, act, act ? a.X[r * Dp + lane] : 0.f);
+            const float u = res_matvec1(sWl, Dp, Dp, lc, xs, bl);
+            const float t = act ? tanhf(u) : 0.f;
+            if (act) a.T[r * Dp + lane] = t;
+            const float nr = sqrtf(res_wave_sum(t * t));
+            const float den = a.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+            const float h = t / den;
+            if (act) a.IH[crow * Dp + lane] = h;
+            if (lane == 0) { a.nrmi[crow] = nr; a.IS[crow] = 0.f; }
+            if (L > 1) {
+                float o[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) o[k] = bc[k];
+                res_park1(xs, lane, act, h);
+                if (a.nblk > 4) res_project_fwd<true>(sW4, sW5, Dp, lc, xs, o);
+                else res_project_fwd<false>(sW4, sW5, Dp, lc, xs, o);
+                float* dst = a.PI + crow * ldpi + lane;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (act && k < a.nblk) dst[k * Dp] = o[k];
+            }
+        }
+        // root of the outside chart (diora.py:337-356): the last wave, beside the leaves
         if (a.run_outside && wave == RES_WAVES - 1) {
             const float v = act ? a.rootp[lane] : 0.f;
             const float nr = sqrtf(res_wave_sum(v * v));
@@ -460,6 +495,7 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             const float o = res_matvec1(sW1ro, Dp, Dp, lc, xs, 0.f);
             if (act) a.PO[crow * Dp + lane] = o;
         }
+        __syncthreads();
         // The two passes as a wavefront (cliora_chart_forward): outside level t composes parents of the outside
         // levels above it with siblings of the inside levels <= L-2-t, so step k runs inside level k AND outside level L-k: L steps
         // instead of 2 (L-1), and the cells of a step are (L-k) + k = L whatever k -- every step fills the same number of waves.
@@ -563,7 +599,7 @@ __device__ __forceinline__ void res_cell_pairs_bwd(const ResArgs& a, const ResPa
             if (act) {
                 const size_t o = (row0 + n) * Dp + lane;
                 a.DZ[o] = pr * dzu[r];
-                a.X[o] = x;
+                a.Xrows[o] = x;
                 a.DA[o] = xs[r] > 0.f ? pr * uu : 0.f;
             }
         }
@@ -585,6 +621,12 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
     float* sW2o = a.share ? sW2i : sW1ro + Dp * Dp;
     float* sW5 = sW1ro + 2 * Dp * Dp;                         // [col][k]: the fifth block (unshared plans only)
     float* scr = sW1ro + (a.share ? 1 : 3) * Dp * Dp + wave * RES_SCR;           // this wave's operand scratch
+    const float* sWl = a.wl;                                  // leaf weight [col][k]: in LDS when there is room (shared plans)
+    if (a.share) {
+        float* dst = sW1ro + Dp * Dp + RES_WAVES * RES_SCR;
+        for (int i = threadIdx.x; i < Dp * Dp; i += RES_THREADS) dst[i] = a.wl[i];
+        sWl = dst;
+    }
     for (int i = threadIdx.x; i < 4 * Dp * Dp; i += RES_THREADS) {
         const int blk = i & 3, ck = i >> 2, col = ck / Dp, k = ck - col * Dp;
         sW4[i] = blk < a.nblk ? a.wcat[((size_t)blk * Dp + col) * Dp + k] : 0.f;
@@ -681,7 +723,13 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_bwd(ResArgs a) {
             if (p == 0) RES_STAMPW(tb + 3);
             if (level == 0) {                                  // leaves: H = unit(T), T = tanh(U)  (leaf_bwd_pre)
                 const size_t r = (size_t)b * L + p;
-                if (act) { const float t = a.T[r * Dp + lane]; a.dU[r * Dp + lane] = dG * (1.f - t * t); }
+                float du = 0.f;
+                if (act) { const float t = a.T[r * Dp + lane]; du = dG * (1.f - t * t); a.dU[r * Dp + lane] = du; }
+                if (a.dX) {                                    // d x = dU Wl
+                    res_park1(scr, lane, act, du);
+                    const float dx = res_matvec1(sWl, Dp, Dp, lc, scr, 0.f);
+                    if (ext) a.dX[r * D + lane] = dx;
+                }
                 return;
             }
             res_cell_pairs_bwd(a, q, b, p, lane, act, lc, dG, vS, scr);
