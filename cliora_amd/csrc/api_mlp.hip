@@ -221,9 +221,11 @@ static bool persist_pays(const cliora_plan* plan, bool vl) {
 //   D 50 / B 8 / L 10 (configs[0])   0.198 -> 0.196 / 0.80 -> 0.56        D 50 / B 256 / L 10   0.31 -> 0.23 / 1.59 -> 1.25
 //   D 32 / B 64 / L 12               0.246 -> 0.211 / 1.07 -> 0.86        D 16 / B 128 / L 8    0.159 -> 0.094 / 0.75 -> 0.51
 //   D 64 / B 64 / L 16               0.36 -> 0.46 / 1.40 -> 1.81          D 64 / B 8 / L 40     1.19 -> 3.84 / 3.0 -> 11.7
-// one workgroup (8 waves) per sentence is a chain of 2 (L - 1) levels of 7-8 us each whatever the batch, so AUTO takes it while a
-// sentence's chart is short: span pairs per sentence, both passes, <= g_cliora_resident_max_pairs = 1000 (L <= 12).  The two
-// directions share every buffer format with the launch path, so either can run on either (tests/test_gpu_resident.py).
+//   D 64 / B 256 / L 16              0.54 -> 0.39 / 3.02 -> 2.35          D 64 / B 256 / L 40   4.29 -> 3.49 / 20.8 -> 13.4
+// one workgroup (12 waves) per sentence is a chain of L steps of 10-16 us each whatever the batch, so AUTO takes it while a
+// sentence's chart is short (span pairs per sentence, both passes, <= g_cliora_resident_max_pairs = 1000: L <= 12) or when the
+// batch gives at least every other CU a sentence (B >= CUs / 2 = 128).  The two directions share every buffer format with the
+// launch path, so either can run on either (tests/test_gpu_resident.py).
 // cliora_set_resident / CLIORA_RESIDENT=0|1 force it off / on (on is still refused for shapes the kernels do not cover).
 static size_t resident_lds_bytes(const Plan& p) {
     return ((size_t)(p.share ? 7 : 8) * p.Dp * p.Dp + (size_t)RES_WAVES * RES_SCR) * sizeof(float);      // shared plans: + the leaf weight
@@ -233,7 +235,9 @@ static bool resident_pays(const cliora_plan* plan, bool vl, bool compress, bool 
     if (g_cliora_resident == 0 || vl || compress || p.arch != 0 || p.L < 2 || p.Dp > 64) return false;
     if (resident_lds_bytes(p) > 160 * 1024) return false;
     if (g_cliora_resident < 0) {
-        if (p.P_in + p.P_out > g_cliora_resident_max_pairs) return false;
+        // short sentences (the chain of L steps beats the launch boundaries), or enough sentences to give every other CU its own
+        // (the kernels are then throughput-bound and win at every length: D 64 / B 256 / L 40 20.8 -> 13.4 ms)
+        if (p.P_in + p.P_out > g_cliora_resident_max_pairs && p.B * 2 < plan->ncu) return false;
     }
     return true;
 }

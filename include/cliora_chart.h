@@ -322,7 +322,8 @@ int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream
  * loops of the forward (cliora/net/diora.py:312-331, 378-398) and of the backward run inside ONE launch each, a workgroup walking
  * every level of one sentence's chart with workgroup barriers between them (csrc/resident_kernels.hpp): sentences exchange nothing
  * inside the recursion.  AUTO (the default; CLIORA_RESIDENT=0|1 sets the initial value) takes it for short sentences
- * (CLIORA_RESIDENT_MAX_PAIRS span pairs per sentence, both passes), OFF never, ON for every shape the kernels cover.  Same buffers
+ * (CLIORA_RESIDENT_MAX_PAIRS span pairs per sentence, both passes) or batches of at least half as many sentences as the device has
+ * compute units, OFF never, ON for every shape the kernels cover.  Same buffers
  * and formats as the launch-per-level path, exact fp32 FMA arithmetic, results equal to fp32 rounding.  Process-wide; returns the
  * previous mode. */
 #define CLIORA_RESIDENT_AUTO (-1)

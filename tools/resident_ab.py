@@ -10,7 +10,9 @@ import torch                                  # noqa: E402
 from cliora_amd import _lib                   # noqa: E402
 from cliora_amd.diora import DioraMLP         # noqa: E402
 
-SHAPES = [(50, 8, 10), (50, 1, 10), (50, 64, 10), (50, 256, 10), (64, 16, 16), (64, 64, 16), (64, 64, 20), (64, 256, 20), (64, 8, 30), (64, 64, 30), (64, 8, 40), (32, 64, 12), (16, 128, 8)]
+import ast
+SHAPES_ENV = os.environ.get('RESIDENT_AB_SHAPES')
+SHAPES = ast.literal_eval(SHAPES_ENV) if SHAPES_ENV else [(50, 8, 10), (50, 1, 10), (50, 64, 10), (50, 256, 10), (64, 16, 16), (64, 64, 16), (64, 64, 20), (64, 256, 20), (64, 8, 30), (64, 64, 30), (64, 8, 40), (32, 64, 12), (16, 128, 8)]
 keys = ('inside_h', 'inside_s', 'outside_h', 'outside_s')
 
 
