@@ -241,6 +241,8 @@ static int launch_rows(hipStream_t st, const float* W, int Kseg, int nseg, int n
     return fail(CLIORA_EINVAL, "weight block does not fit LDS");
 }
 
+constexpr int TN_DIRECT_ROWS = 4096;       // weight-gradient GEMMs of at most this many rows run as one launch (tn_gemm_direct)
+
 template <int T, class AP, class BP>
 static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats,
                        float* out, float* colsum_out, int accumulate) {
@@ -276,6 +278,15 @@ static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, B
         if (accumulate) return CLIORA_OK;
         HIPOK(hipMemsetAsync(out, 0, (size_t)Mi * Nj * sizeof(float), st));
         if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Mi * sizeof(float), st));
+        return CLIORA_OK;
+    }
+    if (nrows <= TN_DIRECT_ROWS) {            // small plans: one launch, no slab (tn_gemm_direct)
+        const int blocks = (Mi / 16) * (Nj / 16);
+        if (colsum_out)
+            hipLaunchKernelGGL((tn_gemm_direct<true, AP, BP>), dim3(blocks), dim3(TND_WAVES * 64), 0, st, nrows, Mi, Nj, ap, bp, out, colsum_out, accumulate);
+        else
+            hipLaunchKernelGGL((tn_gemm_direct<false, AP, BP>), dim3(blocks), dim3(TND_WAVES * 64), 0, st, nrows, Mi, Nj, ap, bp, out, colsum_out, accumulate);
+        LAUNCHOK("tn_gemm_direct");
         return CLIORA_OK;
     }
     switch (pick_tiles(Dp / 16)) {
@@ -359,6 +370,8 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
         if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
         return CLIORA_OK;
     }
+    if (nrows <= TN_DIRECT_ROWS && slices_cap == 0)
+        return launch_tn(st, nrows, Dp, Dp, Dp, PlainRowsA{DZ, ldz}, PlainRowsA{X, ldx}, slab, slab_floats, out, colsum_out, accumulate);
     // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
     // nkb column blocks of NJT = ceil(NT/nkb) j-tiles
     const int NT = Dp / 16;

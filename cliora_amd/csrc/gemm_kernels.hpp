@@ -657,6 +657,67 @@ static __global__ __launch_bounds__(WS_THREADS) void tn_gemm(int nrows, int rows
 }
 
 // ---------------------------------------------------------------------------------
+// tn_gemm_direct: the same product for SMALL row counts (configs[0]-sized plans: a few hundred to a few thousand rows) in ONE
+// launch: a workgroup of eight waves owns one 16 x 16 block of C, the waves split the rows, their partial blocks meet in LDS in wave
+// order and wave 0 writes (or accumulates into) the result -- no slab, no slab_reduce launches (tn_gemm + two reductions were three
+// launches per weight gradient, and a step of such a plan is bound by the host's launch rate).  Exact fp32 MFMA.
+// ---------------------------------------------------------------------------------
+constexpr int TND_WAVES = 8;
+template <bool COLSUM, class AProd, class BProd>
+static __global__ __launch_bounds__(TND_WAVES * 64) void tn_gemm_direct(int nrows, int Mi, int Nj, AProd ap, BProd bp, float* __restrict__ out,
+                                                                    float* __restrict__ colsum_out, int accumulate) {
+    __shared__ float red[TND_WAVES - 1][4][64];
+    __shared__ float redc[TND_WAVES - 1][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int njb = Nj / 16;
+    const int ib = blockIdx.x / njb, jb = blockIdx.x - ib * njb;
+    const int i0 = ib * 16, j0 = jb * 16;
+    const int rps = ((nrows + TND_WAVES - 1) / TND_WAVES + 3) / 4 * 4;
+    const int rbeg = wave * rps;
+    const int rend = min(rbeg + rps, nrows);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+#pragma unroll 8
+    for (int r0 = rbeg; r0 < rend; r0 += 4) {
+        const int r = r0 + q;
+        const bool ok = r < rend;
+        const int rc = ok ? r : rend - 1;
+        const float a = ap.val(ap.row(rc), i0 + i);
+        const float b = bp.val(bp.row(rc), j0 + i);
+        const float av = ok ? a : 0.f;
+        if (COLSUM) csum += av;
+        acc = mfma16(av, b, acc);
+    }
+    if (COLSUM) {
+        csum += __shfl_xor(csum, 16);
+        csum += __shfl_xor(csum, 32);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[wave - 1][reg][lane] = acc[reg];
+        if (COLSUM && q == 0) redc[wave - 1][i] = csum;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < TND_WAVES - 1; ++w) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[reg] += red[w][reg][lane];
+        if (COLSUM && q == 0) csum += redc[w][i];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        float* o = out + (size_t)(i0 + q * 4 + reg) * Nj + j0 + i;
+        *o = accumulate ? *o + acc[reg] : acc[reg];
+    }
+    if (COLSUM && jb == 0 && q == 0) {
+        float* o = colsum_out + i0 + i;
+        *o = accumulate ? *o + csum : csum;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // tn_gemm_dma:  C[i][j] = sum_r A[r][i] B[r][j]  for the big weight gradient (rows = span pairs).
 //   A (dz) and B (x) are dense row-major matrices the compose kernels materialised.  One
 //   workgroup (4 waves, one per SIMD) owns ALL Mi rows of C x one block of up to NJT*16 columns
