@@ -26,19 +26,38 @@ def _stream():
 
 
 def _param_struct(tensors):
-    st = _lib.Params()
-    for name in _lib.PARAM_FIELDS:
-        t = tensors.get(name)
-        setattr(st, name, t.data_ptr() if t is not None else None)
-    return st
+    return _lib.Params(*[(t.data_ptr() if t is not None else None) for t in map(tensors.get, _lib.PARAM_FIELDS)])
+
+
+class _OnDevice(object):
+    """`with torch.cuda.device(dev)` only when `dev` is not the current device already (the context manager costs ~10 us of host
+    time per use, and a configs[0]-sized step is bound by the host: tools/host_bench.py)."""
+    __slots__ = ('ctx',)
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*a)
 
 
 def _grad_out(t):
     """Output tensor for the gradient of the parameter that `t` (its detached view) belongs to: the parameter's slice of a live
     flat all-reduce buffer (cliora_amd.parallel: the backward then writes straight into what RCCL reduces), else a fresh tensor."""
-    from .parallel import grad_buffer_for
-    v = grad_buffer_for(t)
+    global _grad_buffer_for
+    if _grad_buffer_for is None:
+        from .parallel import grad_buffer_for as _g
+        _grad_buffer_for = _g
+    v = _grad_buffer_for(t)
     return v if v is not None else torch.empty_like(t)
+
+
+_grad_buffer_for = None
 
 
 class ChartFunction(torch.autograd.Function):
@@ -59,7 +78,7 @@ class ChartFunction(torch.autograd.Function):
         x_span = x_span.contiguous().float()
         ptens = {n: (p.detach().contiguous() if p is not None else None) for n, p in zip(_lib.PARAM_FIELDS, params)}
         dev = x_span.device
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             inside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
             inside_s = torch.empty((B, Cc, 1), device=dev, dtype=torch.float32)
             outside_h = torch.empty((B, Cc, D), device=dev, dtype=torch.float32)
@@ -85,7 +104,7 @@ class ChartFunction(torch.autograd.Function):
         dev = x_span.device
         cont = lambda g: g.contiguous().float() if g is not None else None
         d_ih, d_is, d_oh, d_os = cont(d_ih), cont(d_is), cont(d_oh), cont(d_os)
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             d_x = torch.empty_like(x_span)
             pst = _param_struct(ctx.ptens)
             g = {n: (_grad_out(t) if t is not None else None) for n, t in ctx.ptens.items()}
@@ -121,8 +140,33 @@ class Bilinear(nn.Module):
 
 
 class Chart(object):
-    """Attribute bag with the six chart tensors (diora.py:7-23)."""
-    __slots__ = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+    """Attribute bag with the six chart tensors (diora.py:7-23).  DioraMLP's cell states are identically zero (diora.py:60-61, 70):
+    they are created when first read (two fill launches and ~20 us of host time per step otherwise, for tensors nothing on the
+    training path reads)."""
+    __slots__ = ('inside_h', 'inside_s', 'outside_h', 'outside_s', '_ic', '_oc')
+
+    def __init__(self):
+        self._ic = self._oc = None
+
+    @property
+    def inside_c(self):
+        if self._ic is None:
+            self._ic = torch.zeros_like(self.inside_h)
+        return self._ic
+
+    @inside_c.setter
+    def inside_c(self, v):
+        self._ic = v
+
+    @property
+    def outside_c(self):
+        if self._oc is None:
+            self._oc = torch.zeros_like(self.outside_h)
+        return self._oc
+
+    @outside_c.setter
+    def outside_c(self, v):
+        self._oc = v
 
 
 class DioraBase(nn.Module):
@@ -189,34 +233,35 @@ class DioraBase(nn.Module):
     def init_with_batch(self, h, c):
         # the native forward has already filled the chart; kept as an overridable method because
         # analysis/utils.py:67-76 wraps it with types.MethodType to attach its score store
-        self.batch_size, self.length = h.shape[0], h.shape[1]
+        d = self.__dict__
+        d['batch_size'], d['length'] = h.shape[0], h.shape[1]
 
     def reset(self):
-        self.batch_size = None
-        self.length = None
-        self.chart = None
-        self.atten_score = None
-        self.all_atten_score = None
-        self.vg_atten_score = None
-        self._wss = None
-        self._plan = None
+        # plain attributes, written straight into the instance dict: nn.Module.__setattr__ walks its parameter / buffer / module
+        # registries for every assignment (~3.5 us each; a configs[0]-sized step is bound by the host)
+        self.__dict__.update(batch_size=None, length=None, chart=None, atten_score=None, all_atten_score=None, vg_atten_score=None,
+                             _wss=None, _plan=None)
 
     def _hook_overridden(self, name):
         return name in self.__dict__ or getattr(type(self), name) is not getattr(DioraBase, name)
 
     def _param_tensors(self):
-        ic, isf = self.inside_compose_func, self.inside_score_func
-        t = dict(leaf_w=ic.leaf_fc.weight, leaf_b=ic.leaf_fc.bias,
-                 in_w1=ic.h_fcs[0].weight, in_b1=ic.h_fcs[0].bias, in_w2=ic.h_fcs[2].weight, in_b2=ic.h_fcs[2].bias,
-                 in_mat=isf.mat)
+        # through the module / parameter registries directly: attribute access on an nn.Module falls back to __getattr__ for every
+        # submodule and parameter (always the live objects: nothing is cached)
+        mods, pars = self._modules, self._parameters
+        ic = mods['inside_compose_func']._modules
+        fc, h0, h2 = ic['leaf_fc']._parameters, ic['h_fcs']._modules['0']._parameters, ic['h_fcs']._modules['2']._parameters
+        t = dict(leaf_w=fc['weight'], leaf_b=fc['bias'], in_w1=h0['weight'], in_b1=h0['bias'], in_w2=h2['weight'], in_b2=h2['bias'],
+                 in_mat=mods['inside_score_func']._parameters['mat'])
         if self.compress:           # diora.py:342-343, 466-467: the outside root is inside_h[root] @ root_mat_out
-            t['root_mat'] = self.root_mat_out
+            t['root_mat'] = pars['root_mat_out']
         else:
-            t['root_h'] = self.root_vector_out_h
+            t['root_h'] = pars['root_vector_out_h']
         if not self.share:
-            oc, osf = self.outside_compose_func, self.outside_score_func
-            t.update(out_w1=oc.h_fcs[0].weight, out_b1=oc.h_fcs[0].bias, out_w2=oc.h_fcs[2].weight,
-                     out_b2=oc.h_fcs[2].bias, out_mat=osf.mat)
+            oc = mods['outside_compose_func']._modules['h_fcs']._modules
+            o0, o2 = oc['0']._parameters, oc['2']._parameters
+            t.update(out_w1=o0['weight'], out_b1=o0['bias'], out_w2=o2['weight'], out_b2=o2['bias'],
+                     out_mat=mods['outside_score_func']._parameters['mat'])
         return [t.get(n) for n in _lib.PARAM_FIELDS]
 
     def forward(self, x_span, x_word=None, obj_embed_span=None, obj_embed_word=None):
@@ -238,14 +283,15 @@ class DioraBase(nn.Module):
         flags = int(bool(self.outside)) | (0 if needs_grad else _lib.FWD_NO_BACKWARD) | (_lib.FWD_PAIR_STATES if hooks else 0)
         ih, is_, oh, os_ = ChartFunction.apply(plan, holder, flags, x_span, *params)
         ch = Chart()
-        ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s = ih, is_, oh, os_
-        # DioraMLP's cell state is identically zero (diora.py:60-61, 70)
-        ch.inside_c = torch.zeros_like(ih)
-        ch.outside_c = torch.zeros_like(oh)
-        self.chart = ch
-        self._wss, self._plan = holder, plan
-        self.init_with_batch(ih[:, :L], ch.inside_c[:, :L])
-        self._serve_hooks(L)
+        ch.inside_h, ch.inside_s, ch.outside_h, ch.outside_s = ih, is_, oh, os_       # the zero cell states: on first read (Chart)
+        d = self.__dict__
+        d['chart'], d['_wss'], d['_plan'] = ch, holder, plan
+        if self._hook_overridden('init_with_batch'):      # analysis/utils.py:67-76 wraps it: then it gets the reference's arguments
+            self.init_with_batch(ih[:, :L], ch.inside_c[:, :L])
+        else:
+            d['batch_size'], d['length'] = B, L
+        if hooks:
+            self._serve_hooks(L)
         return None
 
     # ---- un-aggregated per-split tensors the hooks receive (diora.py:295-334)
