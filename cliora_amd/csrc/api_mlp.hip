@@ -854,10 +854,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                 wb + bw.gw2i, wb + bw.gb2i, 1, tail_slices));
         } else
         OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
-        if (p.share && J_early < 0) {
-            HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
-            HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
-        }
+        // shared weights without the early part: gw2o / gb2o hold nothing of this call -- the scatter below leaves them out (two memset
+        // launches before)
     }
     HIPOK(hipStreamWaitEvent(st, plan->ev_join[1], 0));
     fork_guard.disarm();                                   // both side streams have been joined above
@@ -878,8 +876,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             }
             if (G->in_b1) add_copy(t, G->in_b1, D, 1, D, wb + bw.gbcat, Dp, 1, D, 0, 0, 0);
             if (G->in_mat) add_copy(t, G->in_mat, D, D, D, wb + bw.gwcat + 2 * DD, Dp, D, D, 0, 0, 1);
-            if (G->in_w2) add_copy(t, G->in_w2, D, D, D, wb + bw.gw2i, Dp, D, D, 0, 0, 0, wb + bw.gw2o, Dp, D, D, 0, 0, 0);
-            if (G->in_b2) add_copy(t, G->in_b2, D, 1, D, wb + bw.gb2i, Dp, 1, D, 0, 0, 0, wb + bw.gb2o, Dp, 1, D, 0, 0, 0);
+            const float* gw2o_part = J_early >= 0 ? wb + bw.gw2o : nullptr;      // the early middle range's share (else: not written)
+            const float* gb2o_part = J_early >= 0 ? wb + bw.gb2o : nullptr;
+            if (G->in_w2) add_copy(t, G->in_w2, D, D, D, wb + bw.gw2i, Dp, D, D, 0, 0, 0, gw2o_part, Dp, D, D, 0, 0, 0);
+            if (G->in_b2) add_copy(t, G->in_b2, D, 1, D, wb + bw.gb2i, Dp, 1, D, 0, 0, 0, gb2o_part, Dp, 1, D, 0, 0, 0);
         } else {
             if (G->in_w1) {
                 add_copy(t, G->in_w1, 2 * D, D, D, wb + bw.gwcat, Dp, D, D, 0, 0, 0);
