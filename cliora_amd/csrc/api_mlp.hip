@@ -557,6 +557,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         // ---- one workgroup per sentence, every level of both passes (resident_kernels.hpp) ----
         ResArgs a = resident_args(plan, ws, IH, OH, IS, OS, run_outside);
         a.X = X;
+        if (padded) { a.outIH = inside_h; a.outOH = run_outside ? outside_h : nullptr; }     // the un-padded charts straight from the kernel
         if (!keep) a.ymask = nullptr;
         static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
         a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
@@ -587,10 +588,10 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
         fork_guard.disarm();
     }
-    if (padded) {
+    if (padded && !(resident && run_outside)) {
         CopyTable t; t.n = 0;
-        add_copy(t, inside_h, D, B * C, D, IH, Dp, B * C, D, 0, 0, 0);
-        add_copy(t, outside_h, D, B * C, D, OH, Dp, B * C, D, 0, 0, 0);
+        if (!resident) add_copy(t, inside_h, D, B * C, D, IH, Dp, B * C, D, 0, 0, 0);
+        add_copy(t, outside_h, D, B * C, D, OH, Dp, B * C, D, 0, 0, 0);      // (inside-only resident call: the zeroed outside chart)
         OKR(run_copies(st, t));
     }
     return CLIORA_OK;

@@ -48,6 +48,7 @@ struct ResArgs {
     float* T;                                // tanh output of the leaf layer (B*L x Dp): written by the forward, read by the backward
     const float *X, *wlT, *bl, *wl;          // leaf layer (diora.py:58-63): input rows (B*L x Dp), Wl^T ([k][col]), bias, Wl ([col][k])
     float* dX;                               // d x_span (row stride D) or nullptr
+    float *outIH, *outOH;                    // forward, D != Dp only: the caller's (B, C, D) charts, written beside the padded working copies
     float *VHo, *dPI, *dPO, *DA, *DS, *DZ, *Xrows, *dU;
     unsigned long long* trace;               // diagnostics (CLIORA_RES_TRACE=1): wall-clock stamps of workgroup 0, wave 0
 };
@@ -276,6 +277,7 @@ struct ResPass {
     const float* W2;                         // LDS: forward W2^T ([k][col]); backward W2 ([z][x])
     float b2;                                // this lane's element of the second bias
     float *H, *nrm, *S;                      // the target chart, its norms and scores
+    float* Hout;                             // forward: the caller's un-padded chart (or nullptr)
     int Lc, N, off; long long rowbase;
 };
 
@@ -364,6 +366,7 @@ __device__ __forceinline__ float res_cell_fwd(const ResArgs& a, const ResPass& q
     const float den = a.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
     const float h = hagg / den;
     if (act) q.H[crow * Dp + lane] = h;
+    if (q.Hout && lane < a.D) q.Hout[crow * a.D + lane] = h;
     if (lane == 0) q.nrm[crow] = nr;
     RES_STAMP(tr + 4);
     return h;
@@ -424,7 +427,7 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             q.rowbase = (long long)a.B * lvl_in[level];
             q.pa = a.tabs + a.pa_in + lvl_in[level]; q.pb = a.tabs + a.pb_in + lvl_in[level];
             q.QA = a.PI + 2 * Dp; q.ldq = ldpi; q.XA = a.PI; q.ldxa = ldpi; q.XB = a.PI + Dp; q.ldxb = ldpi;
-            q.HB = a.IH; q.SA = a.IS; q.SB = a.IS; q.W2 = sW2i; q.b2 = b2i; q.H = a.IH; q.nrm = a.nrmi; q.S = a.IS;
+            q.HB = a.IH; q.SA = a.IS; q.SB = a.IS; q.W2 = sW2i; q.b2 = b2i; q.H = a.IH; q.nrm = a.nrmi; q.S = a.IS; q.Hout = a.outIH;
             const float h = res_cell_fwd(a, q, b, p, lane, act, lc, xs, 256 + 8 * level);
             RES_STAMP(4 * level + 1);
             if (level < L - 1) {                              // [PL | PR | QL | (PLo | QLo)] = h Wcat^T + bias
@@ -449,7 +452,7 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             q.rowbase = a.R_in + (long long)a.B * lvl_out[level];
             q.pa = a.tabs + a.pa_out + lvl_out[level]; q.pb = a.tabs + a.pb_out + lvl_out[level];
             q.QA = a.PI + (size_t)a.blk_qlo * Dp; q.ldq = ldpi; q.XA = a.PI + (size_t)a.blk_plo * Dp; q.ldxa = ldpi; q.XB = a.PO; q.ldxb = Dp;
-            q.HB = a.OH; q.SA = a.IS; q.SB = a.OS; q.W2 = sW2o; q.b2 = b2o; q.H = a.OH; q.nrm = a.nrmo; q.S = a.OS;
+            q.HB = a.OH; q.SA = a.IS; q.SB = a.OS; q.W2 = sW2o; q.b2 = b2o; q.H = a.OH; q.nrm = a.nrmo; q.S = a.OS; q.Hout = a.outOH;
             const float h = res_cell_fwd(a, q, b, p, lane, act, lc, xs);
             if (level >= 1) {                                 // PRo of the new parents
                 res_park1(xs, lane, act, h);
@@ -468,6 +471,7 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             const float den = a.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
             const float h = t / den;
             if (act) a.IH[crow * Dp + lane] = h;
+            if (a.outIH && lane < a.D) a.outIH[crow * a.D + lane] = h;
             if (lane == 0) { a.nrmi[crow] = nr; a.IS[crow] = 0.f; }
             if (L > 1) {
                 float o[5];
@@ -490,6 +494,7 @@ static __global__ __launch_bounds__(RES_THREADS) void resident_fwd(ResArgs a) {
             const float h = v / den;
             const size_t crow = bC + C - 1;
             if (act) a.OH[crow * Dp + lane] = h;
+            if (a.outOH && lane < a.D) a.outOH[crow * a.D + lane] = h;
             if (lane == 0) { a.nrmo[crow] = nr; a.OS[crow] = 0.f; }
             res_park1(xs, lane, act, h);
             const float o = res_matvec1(sW1ro, Dp, Dp, lc, xs, 0.f);
