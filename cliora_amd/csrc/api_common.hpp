@@ -37,6 +37,18 @@ struct cliora_plan {
     // must never share the device: every such launch waits for the previous one's event (device-wide chain, under lanes_mu)
     int ncu = 0;
     hipEvent_t ev_persist = nullptr;
+    // forward workspaces whose weight images were NOT built (resident forward; the last eight): a launch-path backward on one of them
+    // builds them first.  Only a mode switch between a forward and its backward gets there (tests do that).
+    const void* imageless_ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int imageless_next = 0;
+    void note_imageless(const void* ws) {
+        for (const void* w : imageless_ws) if (w == ws) return;
+        imageless_ws[imageless_next] = ws; imageless_next = (imageless_next + 1) % 8;
+    }
+    bool take_imageless(const void* ws) {          // true (and forgotten) if `ws` is one of them
+        for (const void*& w : imageless_ws) if (w == ws && ws) { w = nullptr; return true; }
+        return false;
+    }
     unsigned* persist_status = nullptr;     // device words: [0] barrier timeouts since the process started
     std::mutex upload_mu;                   // first-use upload of the tables (plans are shared between host threads)
 };

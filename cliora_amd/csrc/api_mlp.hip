@@ -261,6 +261,26 @@ static ResArgs resident_args(const cliora_plan* plan, float* ws, float* IH, floa
     return a;
 }
 
+// split-bf16 / fragment images of the packed weights, built in either arithmetic mode (two small launches): the backward call may run
+// under the other one
+static int build_chart_images(const cliora_plan* plan, float* ws, bool compress, hipStream_t st) {
+    const Plan& p = plan->p;
+    const FwdLayout& f = p.fwd;
+    const int Dp = p.Dp, ldpi = p.nblk * p.Dp;
+    ImageList im;
+    im.add(ws + f.w2i, ws + f.w2i3, Dp, Dp, Dp); im.add(ws + f.w2iT, ws + f.w2iT3, Dp, Dp, Dp);
+    if (!p.share) { im.add(ws + f.w2o, ws + f.w2o3, Dp, Dp, Dp); im.add(ws + f.w2oT, ws + f.w2oT3, Dp, Dp, Dp); }
+    ImageList pj;
+    pj.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
+    pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
+    pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
+    pj.add(ws + f.matp, ws + f.matq3, Dp, Dp, Dp);
+    if (compress) { pj.add(ws + f.rootw, ws + f.rootw3, Dp, Dp, Dp); pj.add(ws + f.rootwT, ws + f.rootwT3, Dp, Dp, Dp); }
+    OKR(build_weight_images(st, im));
+    OKR(build_frag_images(st, pj));
+    return CLIORA_OK;
+}
+
 // ------------------------------------------------------------------ forward
 extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, const float* x_span, const float* obj_span,
                                     const float* drop_mask, float* inside_h, float* inside_s, float* outside_h,
@@ -296,6 +316,8 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     const float* X = padded ? ws + f.xp : x_span;
     const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
     const float* w1o = p.share ? P->in_w1 : P->out_w1;
+
+    const bool resident = !(run_outside & CLIORA_FWD_PAIR_STATES) && resident_pays(plan, vl, compress, false);     // its workgroups do the leaves too
 
     // ---- pack parameters into padded / concatenated / transposed layouts ----
     {
@@ -337,23 +359,14 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         if (padded) add_copy(t, ws + f.xp, Dp, B * L, Dp, x_span, D, B * L, D, 0, 0, 0);
         if (padded && vl) add_copy(t, ws + f.objp, Dp, B * p.R, Dp, obj_span, D, B * p.R, D, 0, 0, 0);
         OKR(run_copies(st, t));
-        {   // built in either arithmetic mode (one small launch): the backward call may run under the other one
-            ImageList im;
-            im.add(ws + f.w2i, ws + f.w2i3, Dp, Dp, Dp); im.add(ws + f.w2iT, ws + f.w2iT3, Dp, Dp, Dp);
-            if (!p.share) { im.add(ws + f.w2o, ws + f.w2o3, Dp, Dp, Dp); im.add(ws + f.w2oT, ws + f.w2oT3, Dp, Dp, Dp); }
-            ImageList pj;
-            pj.add(ws + f.wl, ws + f.wl3, Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, Dp, Dp);
-            pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
-            pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
-            pj.add(ws + f.matp, ws + f.matq3, Dp, Dp, Dp);
-            if (compress) { pj.add(ws + f.rootw, ws + f.rootw3, Dp, Dp, Dp); pj.add(ws + f.rootwT, ws + f.rootwT3, Dp, Dp, Dp); }
-            OKR(build_weight_images(st, im));
-            OKR(build_frag_images(st, pj));
-        }
+        // the weight images (split-bf16 / fragment layouts of the packed weights) feed the launch path's GEMMs only: a resident forward
+        // leaves them out, and a launch-path backward on such a workspace builds them first (cliora_chart_backward)
+        if (!resident) OKR(build_chart_images(plan, ws, compress, st));
+        if (resident) plan->note_imageless(fwd_ws);
+        else (void)plan->take_imageless(fwd_ws);
     }
 
     // ---- leaves: h = unit(tanh(x Wl^T + bl))  (diora.py:58-63, 283-292) ----
-    const bool resident = !(run_outside & CLIORA_FWD_PAIR_STATES) && resident_pays(plan, vl, compress, false);     // its workgroups do the leaves too
     if (!resident) OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, Dp, ws + f.bl, 1, Dp}));
     if (resident) {
     } else if (vl) {   // h = unit(unit(tanh) + attention(...)), c = unit(context)   (cliora.py:71-80, 290-301)
@@ -657,6 +670,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // compress = True: the outside root's gradient flows into the inside root, so the outside backward ends before the inside one starts
     const bool compress = P && P->root_mat;
     const bool resident = resident_pays(plan, vl, compress, true);
+    if (!resident && plan->take_imageless(fwd_ws))            // the forward ran on the resident kernels and left the weight images out
+        OKR(build_chart_images(plan, ws, compress, st));
     const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside && !compress && !resident;
     hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
     float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
