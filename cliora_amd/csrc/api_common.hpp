@@ -50,6 +50,9 @@ struct cliora_plan {
         return false;
     }
     unsigned* persist_status = nullptr;     // device words: [0] barrier timeouts since the process started
+    // the timeout word as the host last saw it: after every persistent launch it is copied (async) to pinned host memory, and the next
+    // library call on the device looks at it (cliora_persist_check): a launch that gave up on a barrier left its chart partly written
+    struct PersistWatch* watch = nullptr;
     std::mutex upload_mu;                   // first-use upload of the tables (plans are shared between host threads)
 };
 
@@ -76,6 +79,10 @@ int cliora_ensure_max_lds(const void* fn);
 int cliora_plan_ready(cliora_plan* plan, hipStream_t st);
 
 constexpr size_t PERSIST_TRACE_BYTES = (size_t)256 * 4 * (CLIORA_MAX_L + 1) * 10 * 8;   // [workgroup][phase][2] stamps behind the status words
+// device-wide watch of the persistent kernels' timeout word (api_core.hip)
+struct PersistWatch { unsigned* host = nullptr; hipEvent_t ev = nullptr; unsigned seen = 0; bool pending = false; };
+int cliora_persist_note(cliora_plan* plan, hipStream_t st);      // after a persistent launch on st
+int cliora_persist_check(cliora_plan* plan, bool wait = false);  // entry of a library call; wait: block until the last copy has landed
 // persistent level-loop kernels (api_persist.hip)
 namespace cliora { struct PersistFwd; }
 int cliora_launch_persist_fwd(hipStream_t st, const cliora::PersistFwd& a, int ct, int nwg);
@@ -253,7 +260,11 @@ static int launch_rows(hipStream_t st, const float* W, int Kseg, int nseg, int n
     return fail(CLIORA_EINVAL, "weight block does not fit LDS");
 }
 
-constexpr int TN_DIRECT_ROWS = 4096;       // weight-gradient GEMMs of at most this many rows run as one launch (tn_gemm_direct)
+// weight-gradient GEMMs of at most this many rows AND at most this many 16 x 16 output blocks run as one launch (tn_gemm_direct: a
+// workgroup per block walks every row with element loads -- the shape of the configs[0]-sized plans; at d = 400 the 1 875 blocks of the
+// low levels' projection gradient took 190 us that way, beside and slowing the pair rows' tail, against 35 us through the slab)
+constexpr int TN_DIRECT_ROWS = 4096;
+constexpr int TN_DIRECT_BLOCKS = 256;
 
 template <int T, class AP, class BP>
 static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, float* slab, size_t slab_floats,
@@ -273,12 +284,8 @@ static int launch_tn_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp, 
         hipLaunchKernelGGL((tn_gemm<T, T, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
     LAUNCHOK("tn_gemm");
     const size_t n = (size_t)Mi * Nj;
-    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, accumulate);
+    launch_slab_reduce(st, slab, nsl, n, out, accumulate, csl, (size_t)Mi, colsum_out);
     LAUNCHOK("slab_reduce");
-    if (colsum_out) {
-        hipLaunchKernelGGL(slab_reduce, dim3((Mi + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Mi, colsum_out, accumulate);
-        LAUNCHOK("slab_reduce(colsum)");
-    }
     return CLIORA_OK;
 }
 
@@ -292,7 +299,7 @@ static int launch_tn(hipStream_t st, int nrows, int Mi, int Nj, int Dp, AP ap, B
         if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Mi * sizeof(float), st));
         return CLIORA_OK;
     }
-    if (nrows <= TN_DIRECT_ROWS) {            // small plans: one launch, no slab (tn_gemm_direct)
+    if (nrows <= TN_DIRECT_ROWS && (Mi / 16) * (Nj / 16) <= TN_DIRECT_BLOCKS) {            // small plans: one launch, no slab (tn_gemm_direct)
         const int blocks = (Mi / 16) * (Nj / 16);
         if (colsum_out)
             hipLaunchKernelGGL((tn_gemm_direct<true, AP, BP>), dim3(blocks), dim3(TND_WAVES * 64), 0, st, nrows, Mi, Nj, ap, bp, out, colsum_out, accumulate);
@@ -356,12 +363,38 @@ static int launch_tn_pairs_inst(hipStream_t st, const float* DZ, const float* X,
         LAUNCHOK("tn_gemm_dma");
     }
     const size_t n = (size_t)Dp * Dp;
-    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, accumulate);
+    launch_slab_reduce(st, slab, nsl, n, out, accumulate, csl, (size_t)Dp, colsum_out);
     LAUNCHOK("slab_reduce");
-    if (colsum_out) {
-        hipLaunchKernelGGL(slab_reduce, dim3((Dp + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Dp, colsum_out, accumulate);
-        LAUNCHOK("slab_reduce(colsum)");
-    }
+    return CLIORA_OK;
+}
+
+// The eight-wave d = 400 kernel over TWO row ranges of the pair rows in one launch (rows [0, n1) and n2 rows from row `start2`): one
+// slab and one reduction.  false: this shape has no such kernel (the caller launches the ranges one after the other).
+static bool tn_pairs_two_ranges_ok(int Dp) {
+    static const bool eight = [] { const char* e = getenv("CLIORA_WGRAD_WAVES"); return !e || atoi(e) != 4; }();
+    static const bool off = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_MERGED"); return e && atoi(e) == 0; }();
+    const int NT = Dp / 16;
+    return split_bf16() && eight && !off && NT > 20 && NT <= 27;
+}
+static int launch_tn_pairs_two_ranges(hipStream_t st, const float* DZ, const float* X, int n1, long long start2, int n2, int Dp, float* slab,
+                                      size_t slab_floats, float* out, float* colsum_out, int slices_cap) {
+    constexpr int NIT = 7, NJT = 9, nkb = 3;
+    const size_t per_slice = (size_t)Dp * Dp + Dp;
+    const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float) + (size_t)NJT * 2048;
+    int cap = std::min<int>((int)(slab_floats / per_slice), slices_cap > 0 ? slices_cap : std::max(1, 230 / (8 * nkb)) * 8);
+    cap = std::max(2, cap);
+    int rps = (n1 + n2 + cap - 1) / cap;
+    rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
+    int s1 = (n1 + rps - 1) / rps, s2 = (n2 + rps - 1) / rps;
+    while (s1 + s2 > cap) { rps += TN3_RS; s1 = (n1 + rps - 1) / rps; s2 = (n2 + rps - 1) / rps; }
+    const int nsl = s1 + s2;
+    float* csl = slab + (size_t)nsl * Dp * Dp;
+    OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3x<NIT, NJT, 5, true>));
+    hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, DZ, Dp, X, Dp, n1, rps, nsl, Dp, Dp, nkb,
+                       slab, csl, s1, n2, start2);
+    LAUNCHOK("tn_gemm_dma3x(two ranges)");
+    launch_slab_reduce(st, slab, nsl, (size_t)Dp * Dp, out, 0, csl, (size_t)Dp, colsum_out);
+    LAUNCHOK("slab_reduce");
     return CLIORA_OK;
 }
 
@@ -382,7 +415,7 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
         if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
         return CLIORA_OK;
     }
-    if (nrows <= TN_DIRECT_ROWS && slices_cap == 0)
+    if (nrows <= TN_DIRECT_ROWS && (Dp / 16) * (Dp / 16) <= TN_DIRECT_BLOCKS && slices_cap == 0)
         return launch_tn(st, nrows, Dp, Dp, Dp, PlainRowsA{DZ, ldz}, PlainRowsA{X, ldx}, slab, slab_floats, out, colsum_out, accumulate);
     // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
     // nkb column blocks of NJT = ceil(NT/nkb) j-tiles

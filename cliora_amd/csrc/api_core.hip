@@ -127,6 +127,7 @@ struct DeviceLanes {
     unsigned* status = nullptr;         // 16 device words, zeroed once
     int ncu = 0;
     std::mutex mu;
+    PersistWatch watch;
 };
 // Holds one workgroup for `ticks` of the 100 MHz wall clock: the probe of pick_concurrent_stream.
 static __global__ void lane_probe(long long ticks) {
@@ -195,16 +196,27 @@ static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
         OKR(pick_concurrent_stream(busy, 1, &ln->side));
         busy[1] = ln->side;
         OKR(pick_concurrent_stream(busy, 2, &ln->side2));
+        // The fork / join / level events order kernels of ONE device against each other, so a device-scope release at the record
+        // would do (CLIORA_EVENT_SCOPE=device: hipEventReleaseToDevice instead of the default system-scope release).  Measured on
+        // MI355X at c2 (round 4, tools/ab/env_ab.sh, three alternations): 3.512 / 3.547 / 3.528 ms (system) against 3.526 / 3.549 /
+        // 3.567 (device) -- no gain, so the default stays.
+        static const unsigned ev_flags = [] {
+            const char* e = getenv("CLIORA_EVENT_SCOPE");
+            return (unsigned)hipEventDisableTiming | ((e && !strcmp(e, "device")) ? (unsigned)hipEventReleaseToDevice : 0u);
+        }();
         for (int k = 0; k < 3; ++k) {
-            HIPOK(hipEventCreateWithFlags(&ln->fork[k], hipEventDisableTiming));
-            HIPOK(hipEventCreateWithFlags(&ln->join[k], hipEventDisableTiming));
+            HIPOK(hipEventCreateWithFlags(&ln->fork[k], ev_flags));
+            HIPOK(hipEventCreateWithFlags(&ln->join[k], ev_flags));
         }
-        for (int k = 0; k <= CLIORA_MAX_L; ++k) HIPOK(hipEventCreateWithFlags(&ln->level[k], hipEventDisableTiming));
+        for (int k = 0; k <= CLIORA_MAX_L; ++k) HIPOK(hipEventCreateWithFlags(&ln->level[k], ev_flags));
         HIPOK(hipEventCreateWithFlags(&ln->persist, hipEventDisableTiming));
         HIPOK(hipEventRecord(ln->persist, st));
         HIPOK(hipMalloc((void**)&ln->status, 64 + PERSIST_TRACE_BYTES));
         HIPOK(hipMemsetAsync(ln->status, 0, 64 + PERSIST_TRACE_BYTES, st));
         HIPOK(hipDeviceGetAttribute(&ln->ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        HIPOK(hipHostMalloc((void**)&ln->watch.host, 64, hipHostMallocDefault));
+        ln->watch.host[0] = 0;
+        HIPOK(hipEventCreateWithFlags(&ln->watch.ev, hipEventDisableTiming));
         g_lanes[dev] = ln;
     }
     *out = g_lanes[dev];
@@ -236,7 +248,7 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     for (int k = 0; k < 3; ++k) { plan->ev_fork[k] = ln->fork[k]; plan->ev_join[k] = ln->join[k]; }
     plan->ev_level = ln->level;
     plan->lanes_mu = &ln->mu;
-    plan->ncu = ln->ncu; plan->ev_persist = ln->persist; plan->persist_status = ln->status;
+    plan->ncu = ln->ncu; plan->ev_persist = ln->persist; plan->persist_status = ln->status; plan->watch = &ln->watch;
     plan->device = dev;
     __atomic_store_n(&plan->uploaded, true, __ATOMIC_RELEASE);
     return CLIORA_OK;
@@ -353,11 +365,56 @@ extern "C" int cliora_set_persistent(int mode) {
     g_cliora_persistent = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
     return prev;
 }
+// A persistent launch that gives up on a grid barrier (another process held CUs for seconds) returns early with its chart partly
+// written and counts that in a device word.  The word follows every such launch to pinned host memory; the next call into the
+// library on that device -- normally the backward of the same step -- looks at it and fails loudly instead of training on garbage.
+// Both run under the device's lanes mutex (the callers hold it).
+int cliora_persist_note(cliora_plan* plan, hipStream_t st) {
+    PersistWatch* w = plan->watch;
+    if (!w || !w->host) return CLIORA_OK;
+    HIPOK(hipMemcpyAsync(w->host, plan->persist_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPOK(hipEventRecord(w->ev, st));
+    w->pending = true;
+    return CLIORA_OK;
+}
+int cliora_persist_check(cliora_plan* plan, bool wait) {
+    PersistWatch* w = plan->watch;
+    if (!w || !w->host) return CLIORA_OK;
+    if (w->pending) {
+        if (wait) HIPOK(hipEventSynchronize(w->ev));
+        else {
+            const hipError_t q = hipEventQuery(w->ev);
+            if (q == hipErrorNotReady) return CLIORA_OK;      // still in flight: the next call looks again
+            if (q != hipSuccess) return fail(CLIORA_EHIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
+        w->pending = false;
+    }
+    const unsigned now = __atomic_load_n(w->host, __ATOMIC_RELAXED);
+    if (now != w->seen) {
+        const unsigned n = now - w->seen;
+        w->seen = now;
+        return fail(CLIORA_EHIP, "a persistent level-loop launch gave up on " + std::to_string(n) + " grid barrier wait(s) (the device was shared): "
+                                 "the charts of that forward are incomplete; rerun the step, or set CLIORA_PERSISTENT=0");
+    }
+    return CLIORA_OK;
+}
+
 extern "C" int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream) {
     if (!plan || !timeouts) return fail(CLIORA_EINVAL, "NULL argument");
     if (!plan->uploaded) { *timeouts = 0; return CLIORA_OK; }
     HIPOK(hipMemcpyAsync(timeouts, plan->persist_status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPOK(hipStreamSynchronize((hipStream_t)stream));
+    return CLIORA_OK;
+}
+
+// diagnostics / tests: count one more given-up barrier wait in the device word, as a persistent launch that timed out would -- the
+// next persistent launch carries the word to the host and the library call after it fails (cliora_persist_check)
+static __global__ void persist_bump_status(unsigned* status) { atomicAdd(status, 1u); }
+extern "C" int cliora_persistent_inject_timeout(cliora_plan* plan, void* stream) {
+    if (!plan) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, "no forward has run on this plan");
+    hipLaunchKernelGGL(persist_bump_status, dim3(1), dim3(1), 0, (hipStream_t)stream, plan->persist_status);
+    LAUNCHOK("persist_bump_status");
     return CLIORA_OK;
 }
 

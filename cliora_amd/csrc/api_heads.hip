@@ -23,12 +23,8 @@ static int launch_tn_rect_t(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP
     else hipLaunchKernelGGL((tn_gemm<TI, TJ, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab, csl);
     LAUNCHOK("tn_gemm(rect)");
     const size_t n = (size_t)Mi * Nj;
-    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, nsl, n, out, 0);
+    launch_slab_reduce(st, slab, nsl, n, out, 0, csl, (size_t)Mi, colsum_out);
     LAUNCHOK("slab_reduce");
-    if (colsum_out) {
-        hipLaunchKernelGGL(slab_reduce, dim3((Mi + 255) / 256), dim3(256), 0, st, csl, nsl, (size_t)Mi, colsum_out, 0);
-        LAUNCHOK("slab_reduce(colsum)");
-    }
     return CLIORA_OK;
 }
 template <class AP, class BP>

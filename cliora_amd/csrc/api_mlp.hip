@@ -304,6 +304,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
+    OKR(cliora_persist_check(plan));
     ForkGuard fork_guard(st);                          // declared after the lock: runs (joins the side streams) before it is released
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
@@ -565,6 +566,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             OKR(cliora_launch_persist_fwd(st, a, f.ct3, plan->ncu));
         }
         HIPOK(hipEventRecord(plan->ev_persist, st));
+        OKR(cliora_persist_note(plan, st));
     }
     if (resident) {
         // ---- one workgroup per sentence, every level of both passes (resident_kernels.hpp) ----
@@ -629,6 +631,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
+    OKR(cliora_persist_check(plan));                   // the forward of this step may have run as one persistent launch
     ForkGuard fork_guard(st);
     fork_guard.arm(1, plan->side2, plan->ev_join[1]);     // the weight-gradient stream takes work at several points of the call
     const Dev dv = dev_views(p);
@@ -865,9 +868,15 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             // the two end ranges are short and run beside the side stream's small GEMMs: two thirds of the chip each (c2: 72 / 56 / 40 / 24
             // slices: 3.497 / 3.484 / 3.481 / 3.547 ms)
             static const int tail_slices = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES"); return e ? atoi(e) : 48; }();
+            static const int tail_slices2 = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES2"); return e ? atoi(e) : 72; }();
+            if (tn_pairs_two_ranges_ok(Dp))          // both ends in one launch (round 4): one slab, one reduction
+                OKR(launch_tn_pairs_two_ranges(st, DZ, Xp, (int)early_r0, early_r1, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
+                                               wb + bw.gw2i, wb + bw.gb2i, tail_slices2));
+            else {
             OKR(launch_tn_pairs(st, DZ, Xp, (int)early_r0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0, tail_slices));
             OKR(launch_tn_pairs(st, DZ + (size_t)early_r1 * Dp, Xp + (size_t)early_r1 * Dp, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
                                 wb + bw.gw2i, wb + bw.gb2i, 1, tail_slices));
+            }
         } else
         OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
         // shared weights without the early part: gw2o / gb2o hold nothing of this call -- the scatter below leaves them out (two memset

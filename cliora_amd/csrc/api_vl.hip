@@ -19,7 +19,7 @@ static int launch_tn_ij(hipStream_t st, int nrows, int Mi, int Nj, AP ap, BP bp,
     hipLaunchKernelGGL((tn_gemm<TI, TJ, false, AP, BP>), dim3(blocks, nsl / 4), dim3(WS_THREADS), 0, st, nrows, rps, Mi, Nj, ap, bp, slab,
                        (float*)nullptr);
     LAUNCHOK("tn_gemm(ij)");
-    hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((per_slice + 255) / 256)), dim3(256), 0, st, slab, nsl, per_slice, out);
+    launch_slab_reduce(st, slab, nsl, per_slice, out, 0);
     LAUNCHOK("slab_reduce");
     return CLIORA_OK;
 }
@@ -165,7 +165,7 @@ extern "C" int cliora_vl_scores_max_backward(cliora_plan* plan, const float* ins
         }
         hipLaunchKernelGGL(region_max_bwd_obj, dim3(B * R, nchunk), dim3(256), 0, st, B, C, R, Dp, a_per_chunk, d_all_max, all_arg, v.sump, v.slab);
         LAUNCHOK("region_max_bwd_obj");
-        hipLaunchKernelGGL(slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v.slab, nchunk, n, v.gobj, 0);
+        launch_slab_reduce(st, v.slab, nchunk, n, v.gobj, 0);
         LAUNCHOK("slab_reduce");
         CopyTable t; t.n = 0;
         add_copy(t, d_obj_span, D, B * R, D, v.gobj, Dp, B * R, D, 0, 0, 0);

@@ -1076,7 +1076,10 @@ static __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restri
 template <int NIT, int NJT, int NJW, bool COLSUM>
 static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int nrows,
                                                      int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
-                                                     float* __restrict__ slab, float* __restrict__ colsum) {
+                                                     float* __restrict__ slab, float* __restrict__ colsum,
+                                                     int slice2 = 0x7fffffff, int nrows2 = 0, long long shift2 = 0) {
+    // slices >= slice2 walk a SECOND row range of the same matrices: nrows2 rows starting shift2 rows further down (the two ends of the
+    // pair rows around the part whose weight gradient started early: one launch, one slab, one reduction for both)
     static_assert(2 * NJW > NJT, "the second half of the j-tiles needs a spare slot for the ones-tile");
     extern __shared__ __attribute__((aligned(16))) float lds_t[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1101,8 +1104,10 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
     const int bufsz = TN3_RS * (ldA + ldX);
     const int x4 = ldX >> 2, xv4 = njt * 4;
 
-    const int rbeg = slice * rows_per_slice;
-    const int rend = min(nrows, rbeg + rows_per_slice);
+    const bool second = slice >= slice2;
+    if (second) { A += shift2 * lda; B += shift2 * ldb; }
+    const int rbeg = (second ? slice - slice2 : slice) * rows_per_slice;
+    const int rend = min(second ? nrows2 : nrows, rbeg + rows_per_slice);
     const int nstages = rend > rbeg ? (rend - rbeg + TN3_RS - 1) / TN3_RS : 0;
 
     f32x4 acc[NIT][NJW];
@@ -1247,13 +1252,72 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
     }
 }
 
-// out[e] (+)= sum_s slab[s][e], fixed order.
-static __global__ void slab_reduce(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out, int accumulate = 0) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float v = 0.f;
-    for (int s = 0; s < nslices; ++s) v += slab[(size_t)s * n + e];
-    out[e] = accumulate ? out[e] + v : v;
+// out[e] (+)= sum_s slab[s][e] and -- the blocks past the matrix, same launch -- cs_out[i] (+)= sum_s csl[s][i].  Fixed order: a
+// workgroup owns 64 * V consecutive elements (V = 4: one float4 per thread); its four waves take the slices s = w, w + 4, ... in
+// order, eight loads in flight each (the first form of this kernel was one thread per element walking the slices one dependent
+// 4-byte load after the other: 56 us for the 48 slices of a d = 400 pair-row weight gradient, 30 us for its 400-element bias
+// gradient, both on the step's critical tail), and the four partial sums meet in LDS as (w0 + w1) + (w2 + w3).
+template <int V>
+static __global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ slab, int nslices, size_t n, float* __restrict__ out,
+                                                            int accumulate, const float* __restrict__ csl, size_t ncs,
+                                                            float* __restrict__ cs_out, unsigned nblk_main) {
+    __shared__ float sh[3][64 * V];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool main = blockIdx.x < nblk_main;
+    const float* src = main ? slab : csl;
+    float* dst = main ? out : cs_out;
+    const size_t len = main ? n : ncs;
+    const size_t e = ((size_t)(main ? blockIdx.x : blockIdx.x - nblk_main) * 64 + lane) * V;
+    const bool ok = e < len;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (ok) {
+        for (int s0 = w; s0 < nslices; s0 += 32) {
+            float t[8][V];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s = s0 + 4 * j;
+                const float* p = src + (size_t)min(s, nslices - 1) * len + e;
+                if constexpr (V == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    t[j][0] = q.x; t[j][1] = q.y; t[j][2] = q.z; t[j][3] = q.w;
+                } else {
+                    t[j][0] = p[0];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + 4 * j < nslices)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v] += t[j][v];
+        }
+    }
+    if (w > 0)
+#pragma unroll
+        for (int v = 0; v < V; ++v) sh[w - 1][lane * V + v] = acc[v];
+    __syncthreads();
+    if (w != 0 || !ok) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float r = (acc[v] + sh[0][lane * V + v]) + (sh[1][lane * V + v] + sh[2][lane * V + v]);
+        if (accumulate) r += dst[e + v];
+        acc[v] = r;
+    }
+    if constexpr (V == 4) *reinterpret_cast<float4*>(dst + e) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else dst[e] = acc[0];
+}
+
+// one launch for a slab and (optionally) its column-sum slab; false on a launch error (hipGetLastError holds it)
+static inline void launch_slab_reduce(hipStream_t st, const float* slab, int nslices, size_t n, float* out, int accumulate,
+                                      const float* csl = nullptr, size_t ncs = 0, float* cs_out = nullptr) {
+    if (!cs_out) ncs = 0;
+    const bool vec = (n % 4 == 0) && (ncs % 4 == 0) && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) |
+                                                        reinterpret_cast<uintptr_t>(csl) | reinterpret_cast<uintptr_t>(cs_out)) % 16 == 0);
+    const int per = vec ? 256 : 64;
+    const unsigned nb = (unsigned)((n + per - 1) / per), nc = (unsigned)((ncs + per - 1) / per);
+    if (vec) hipLaunchKernelGGL(slab_reduce_k<4>, dim3(nb + nc), dim3(256), 0, st, slab, nslices, n, out, accumulate, csl, ncs, cs_out, nb);
+    else hipLaunchKernelGGL(slab_reduce_k<1>, dim3(nb + nc), dim3(256), 0, st, slab, nslices, n, out, accumulate, csl, ncs, cs_out, nb);
 }
 
 }  // namespace cliora

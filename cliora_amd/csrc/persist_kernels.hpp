@@ -445,12 +445,15 @@ __global__ __launch_bounds__(512) void chart_fwd_persist(PersistFwd a) {
     };
     if (threadIdx.x == 0) {
         sh_flag[0] = 0;
+        // census word first, then the top counter as a RELEASE; the census reads follow the spin as ACQUIRES: a workgroup that has
+        // seen all NW arrivals sees every census add (two relaxed adds to different words could be reordered by the compiler or land
+        // out of order, and an under-counted nx releases every later barrier of this workgroup's XCD early)
         __hip_atomic_fetch_add((pk_gu32*)(a.sync + 64 * 17 + xcc), 1u, PK_RLX);
-        __hip_atomic_fetch_add((pk_gu32*)a.sync, 1u, PK_RLX);
+        __hip_atomic_fetch_add((pk_gu32*)a.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (!spin_ge(a.sync, (unsigned)NW)) { atomicAdd(a.status, 1u); sh_flag[0] = 1; }
         unsigned nx = 0, nlive = 0;
         for (unsigned x = 0; x < 8; ++x) {
-            const unsigned c = __hip_atomic_load((pk_gu32*)(a.sync + 64 * 17 + x), PK_RLX);
+            const unsigned c = __hip_atomic_load((pk_gu32*)(a.sync + 64 * 17 + x), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             if (x == xcc) nx = c;
             nlive += c ? 1u : 0u;
         }

@@ -192,14 +192,28 @@ class FusedClipAdam(object):
     def step(self, gathered=False):
         """gathered=True: the reducer has just brought every gradient into the flat buffer (all_reduce_mean)."""
         ar = self.grads
+        skipped = []              # parameters without a gradient this step: torch.optim.Adam leaves them (and their moments) untouched
         if not gathered:
+            o = 0
             for p, v in zip(ar.params, ar.views):
                 if p.grad is None:
                     v.zero_()
+                    skipped.append((o, p.numel()))
                 elif p.grad.data_ptr() != v.data_ptr():
                     v.copy_(p.grad)
+                o += p.numel()
+        # a zero gradient is not "no gradient" to Adam (the moments decay and the parameter keeps moving on its momentum): the
+        # skipped segments are put back after the launch.  (Their bias-correction step count still advances with the rest: a
+        # parameter that receives gradients only on SOME steps is corrected with the global count here, with its own in torch.)
+        saved = [(o, n, self.flat_p[o:o + n].clone(), self.m[o:o + n].clone(), self.v[o:o + n].clone()) for o, n in skipped]
         self.t += 1
         with torch.cuda.device(self.flat_p.device):
             _lib.check(_lib.lib().cliora_clip_adam(_p(self.flat_p), _p(ar.flat), _p(self.m), _p(self.v), self.flat_p.numel(), float(self.max_norm),
                                                   float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.t, _p(self.ws),
                                                   self.ws.numel(), _st()), 'cliora_clip_adam')
+        for o, n, p0, m0, v0 in saved:
+            self.flat_p[o:o + n].copy_(p0); self.m[o:o + n].copy_(m0); self.v[o:o + n].copy_(v0)
+        # the clipped values are what the kernel applied; gradients that live outside the arena (torch-produced, copied in above)
+        # keep their unclipped values in p.grad -- callers that read p.grad after step() see the arena's clipped copy only for the
+        # in-place ones
+

@@ -317,6 +317,11 @@ int cliora_set_wavefront(int mode);
 #define CLIORA_PERSISTENT_ON 1
 int cliora_set_persistent(int mode);
 int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
+/* A persistent launch that gives up on a barrier leaves its charts partly written.  The library does not let that pass silently:
+ * the timeout word follows every persistent launch to pinned host memory, and the next cliora_chart_forward /
+ * cliora_chart_backward on the device (normally the backward of the same step) returns CLIORA_EHIP once the word has moved.
+ * cliora_persistent_inject_timeout (diagnostics, tests) counts one such give-up in the device word without any launch failing. */
+int cliora_persistent_inject_timeout(cliora_plan* plan, void* stream);
 
 /* One workgroup per sentence.  For a text-only DioraMLP plan whose rows fit a wavefront (D <= 64; BASELINE configs[0]) the level
  * loops of the forward (cliora/net/diora.py:312-331, 378-398) and of the backward run inside ONE launch each, a workgroup walking

@@ -85,11 +85,62 @@ def test_c5_treelstm_length_40():
     assert [str(t) for t in m.cky()] == [str(t) for t in R.cky_trees(ref['pair_s_in'], B, L)]
 
 
+def test_c5_treelstm_full_batch_properties():
+    """BASELINE configs[4] at the bench's own size -- DioraTreeLSTM d = 400, B = 64, L = 40 (2.05 M pair rows) -- through the
+    size-independent properties (the CPU oracle needs minutes per sentence pair at this length; it checks B = 2 above):
+    unit-length chart vectors, zero leaf / root scores, sentences independent of their batch (the first two against the oracle run on them
+    alone), bitwise equality of two runs, linearity of the backward in the cotangent.  [TreeLSTM parity is unpinned: treelstm.py]"""
+    from cliora_amd.treelstm import DioraTreeLSTM
+    from oracle import diora_ref as R
+    D, B, L = 400, 64, 40
+    C = L * (L + 1) // 2
+    keys = ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s')
+    P = R.init_params_treelstm(D, seed=41)
+    m = DioraTreeLSTM(D)
+    sd = m.state_dict()
+    for k in sd:
+        sd[k] = P[k if k in P else 'inside_' + k[len('outside_'):]].detach().clone()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    gen = torch.Generator().manual_seed(42)
+    x = torch.randn(B, L, D, generator=gen)
+    cot = {k: torch.randn(B, C, 1 if k.endswith('_s') else D, generator=gen).cuda() for k in keys}
+
+    def run(scale=1.0):
+        for p_ in m.parameters():
+            p_.grad = None
+        xg = x.clone().cuda().requires_grad_(True)
+        m(xg, xg)
+        outs = {k: getattr(m, k).detach().clone() for k in keys}
+        torch.autograd.backward([getattr(m, k) for k in keys], [scale * cot[k] for k in keys])
+        torch.cuda.synchronize()
+        return outs, {n: p_.grad.clone() for n, p_ in m.named_parameters()}, xg.grad.clone()
+    o1, g1, dx1 = run()
+    assert float((o1['inside_h'].norm(dim=-1) - 1).abs().max()) < 1e-5 and float((o1['outside_h'].norm(dim=-1) - 1).abs().max()) < 1e-5
+    assert float(o1['inside_s'][:, :L].abs().max()) == 0.0 and float(o1['outside_s'][:, -1].abs().max()) == 0.0
+    for k in keys:
+        assert bool(torch.isfinite(o1[k]).all()), k
+    with torch.no_grad():
+        ref = R.diora_forward(P, x[:2], x[:2], arch='treelstm')
+    for k in keys:
+        assert _err(o1[k][:2], ref[k]) <= 1e-4 * _scale(ref[k]), k
+    o2, g2, dx2 = run()
+    for k in keys:
+        assert torch.equal(o1[k], o2[k]), k
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+    assert torch.equal(dx1, dx2)
+    _, g3, dx3 = run(2.0)
+    for n in g1:
+        assert _err(g3[n], 2.0 * g1[n]) <= 1e-4 * _scale(g1[n]), n
+    assert _err(dx3, 2.0 * dx1) <= 1e-4 * _scale(dx1)
+
+
 def test_c3_cliora_full_size(mfma_mode):
     """BASELINE configs[2]: CLIORA d=400, batch 64, length 20, 36 regions x 2048-d features, all three losses."""
     from cliora_amd import harness as H
     from oracle import diora_ref as R
-    B, L, D, Rg, V, E, K = 64, 20, 400, 36, 2000, 64, 20
+    B, L, D, Rg, V, E, K = 64, 20, 400, 36, 10000, 1024, 100      # BASELINE's own sizes: 1024-d embeddings, V 10 000, k_neg 100
     torch.manual_seed(21)
     net = H.build_net(D, torch.nn.Embedding(V, E), obj_feats=True, img_dim=2048, k_neg=K, vg_loss=True, use_contr=True,
                       vl_margin=0.2, alpha_contr=1.0, alpha_vg=1.0)
@@ -145,7 +196,7 @@ def test_c3_cliora_full_size_training_mode(mfma_mode):
     batch with the mask replayed."""
     from cliora_amd import harness as H
     from oracle import diora_ref as R
-    B, L, D, Rg, V, E, K = 64, 20, 400, 36, 2000, 64, 20
+    B, L, D, Rg, V, E, K = 64, 20, 400, 36, 10000, 1024, 100
     C = L * (L + 1) // 2
     torch.manual_seed(31)
     net = H.build_net(D, torch.nn.Embedding(V, E), obj_feats=True, img_dim=2048, k_neg=K, vg_loss=True, use_contr=True,
@@ -304,6 +355,8 @@ def test_c2_full_size_gradients_vs_fp64(mfma_mode):
         report[k] = dict(hip=hip, fp32_oracle=ref, ratio={q: hip[q] / max(ref[q], 1e-12) for q in hip})
     for k in keys:
         report['out.' + k] = dict(hip=_dist(getattr(m, k), o64[k].detach()), fp32_oracle=_dist(o32[k], o64[k].detach()))
+        # every chart of all 64 sentences against the fp32 oracle (the reference's arithmetic): the north-star 1e-4
+        assert _err(getattr(m, k), o32[k]) <= 1e-4 * _scale(o32[k]), (k, _err(getattr(m, k), o32[k]))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'accuracy_fp64_%s.json' % mfma_mode), 'w') as f:
         json.dump(dict(mode=mfma_mode, D=D, B=B, L=L, unit='error / max|fp64 value| of the tensor', tensors=report), f, indent=1)

@@ -110,3 +110,44 @@ def test_device_feed_on_the_gpu():
         assert float(a['obj_feats'].sum()) == float(i) * b['batch_size'] * 36 * 64
         n += 1
     assert n == len(want)
+
+
+def test_trainer_with_a_reducer_writes_chart_gradients_in_place_and_double_forward_is_summed():
+    """(1) harness.Trainer(net, reducer=...) re-points every parameter into the optimizer's flat tensor AFTER the reducer
+    mapped their addresses -- the chart backward must still find its slices (reducer.copied counts only the gradients torch autograd
+    produced); (2) two chart calls under ONE backward with a live arena must give the sum of the two gradients, not twice the last."""
+    from cliora_amd import harness as H
+    from cliora_amd import parallel
+    g = load_golden('net_diora.npz')
+    net = _build(g, False).eval()
+    bm = _batch(g)
+
+    class LocalReducer(parallel.FlatGradAllReduce):          # the collective left out: one rank, no process group in the test session
+        def _reduce(self):
+            pass
+    params = [p for p in net.parameters() if p.requires_grad]
+    red = LocalReducer(params)
+    tr = H.Trainer(net, lr=g['meta']['lr'], reducer=red)
+    net.train = lambda mode=True: torch.nn.Module.train(net, False)
+    assert tr.optimizer.grads is red
+    tr.step(bm, train=True)
+    chart = [n for n, p in net.named_parameters() if n.startswith('diora.') and p.requires_grad and p.grad is not None]
+    assert chart
+    for n, p in net.named_parameters():
+        if n in chart:
+            assert red.lookup(p.detach())[1].data_ptr() == p.grad.data_ptr(), n       # written where RCCL reduces
+    assert red.copied <= len(params) - len(chart)
+    # (2) the same batch twice under one backward: gradients = 2 x the single-call gradients
+    tr.optimizer.zero_grad()
+    out = net(bm['sentences'], bm['obj_feats'], bm['neg_samples'])
+    out['total_loss'].mean(0).sum().backward()
+    single = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    tr.optimizer.zero_grad()
+    o1 = net(bm['sentences'], bm['obj_feats'], bm['neg_samples'])['total_loss'].mean(0).sum()
+    o2 = net(bm['sentences'], bm['obj_feats'], bm['neg_samples'])['total_loss'].mean(0).sum()
+    (o1 + o2).backward()
+    for n, p in net.named_parameters():
+        if n in single:
+            sc = max(1.0, float(single[n].abs().max()))
+            assert float((p.grad - 2.0 * single[n]).abs().max()) <= 1e-5 * sc, n
+    red.close()

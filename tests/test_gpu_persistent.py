@@ -152,3 +152,31 @@ def test_persistent_no_grad_and_hooks(mfma_mode):
             assert torch.equal(res['off'][1][lv][1], res['on'][1][lv][1]), ('pair scores', lv)
     finally:
         _lib.set_persistent(prev)
+
+
+def test_a_persistent_timeout_fails_the_next_call_loudly():
+    """a persistent launch that gives up on a grid barrier returns with its chart partly written and only counts that
+    in a device word.  The word now follows every persistent launch to the host, and the next library call on the device raises
+    instead of training on garbage.  The give-up is injected (cliora_persistent_inject_timeout): nothing really times out here."""
+    import ctypes as C
+    from cliora_amd import _lib
+    from oracle import synth
+    D, B, L = 64, 4, 16
+    P, x, cot = synth.diora_case(D, B, L, 5)
+    m = _module_from_params(P, D, True, 'unit')
+    prev, prev_r = _lib.set_persistent('on'), _lib.set_resident('off')
+    try:
+        _run_gpu(m, x, cot)                                   # a clean persistent step
+        plan = _lib.get_plan(B, L, D, True, 'unit', 0, torch.cuda.current_device())
+        _lib.check(_lib.lib().cliora_persistent_inject_timeout(plan.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'inject')
+        xg = x.clone().cuda().requires_grad_(True)
+        m(xg, xg)                                             # this launch carries the moved word to the host
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.ChartLibError, match='gave up'):
+            torch.autograd.backward([m.inside_h], [cot['inside_h'].cuda()])
+        for p_ in m.parameters():
+            p_.grad = None
+        _run_gpu(m, x, cot)                                   # reported once: the next step is clean again
+    finally:
+        _lib.set_persistent(prev)
+        _lib.set_resident(prev_r)
