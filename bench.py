@@ -234,6 +234,74 @@ def other_measurements(torch, dev, budget_steps=12):
     return out
 
 
+def cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, use_dist, mfma_mode):
+    """BASELINE configs[2] (1 GPU) / configs[3] (8 GPUs, batch 512 global): CLIORA d = 400 with 36 x 2048-d region features, batch 64
+    per GPU, length 20 -- one step = the whole Trainer._step of the reference (trainer.py:437-501) on this library's kernels:
+    Embed + ImageEncoder, the chart with the region attention, span-region / word-region scorers, reconstruction + VG + contrastive
+    losses, backward, ONE flat-gradient all-reduce over RCCL (chart, head and ImageEncoder gradients in one buffer), clip 5.0, Adam."""
+    from cliora_amd import harness as H
+    from cliora_amd.parallel import FlatGradAllReduce
+    B, L, D = args.batch, args.length, args.dim
+    V, E, K, Rg = 10000, 1024, 100, 36                      # SURVEY 8(d): V 10 000, 1024-d embeddings, k_neg 100, 36 regions
+    torch.manual_seed(1234)                                  # same parameters on every rank (train_diora.sh:9)
+    net = H.build_net(D, torch.nn.Embedding(V, E), obj_feats=True, img_dim=2048, k_neg=K, vg_loss=True, use_contr=True).to(dev)
+    for p in net.img_encoder.parameters():
+        torch.nn.init.normal_(p, std=0.02)                   # the reference's zero init makes every VL score 0 (SURVEY 8d)
+    params = [p for p in net.parameters() if p.requires_grad]
+    reducer = FlatGradAllReduce(params) if use_dist else None
+    tr = H.Trainer(net, lr=2e-3, reducer=reducer)
+    g = torch.Generator().manual_seed(1234 + rank)           # every rank its own 64 sentences (weak scaling; batch_iterator.py:53-66)
+    bm = dict(sentences=torch.randint(0, V, (B, L), generator=g).to(dev), neg_samples=torch.randperm(V, generator=torch.Generator().manual_seed(99))[:K].to(dev),
+              obj_feats=torch.relu(torch.randn(B, Rg, 2048, generator=g)).to(dev))
+
+    def step():
+        tr.step(bm, train=True, sync=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    dt, step_ms = timed_steps(torch, step, fence, args.steps)
+    if use_dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        plan = _lib.get_plan(B, L, D, True, 'unit', Rg, local)
+        step_bytes, _ = algorithmic_bytes(plan, B, D)
+        scorer_bytes = 3.0 * (B * B * (L * (L + 1) // 2) * Rg * 4.0)        # the (B, B, C, 36) span-region scores: written, read by the loss, gradient
+        out = {
+            'metric': 'sentences/sec (CLIORA whole training step: chart fwd+bwd + heads + all-reduce + clip + Adam), len-%d d=%d bsz=%d' % (L, D, B),
+            'value': round(world * B * args.steps / dt, 2), 'unit': 'sentences/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (compose GEMMs and scorers: 3x bf16 MFMA per product, fp32 accumulate)' if mfma_mode == 'bf16x3' else 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'CLIORA d=%d + obj_feats (36 regions x 2048-d synthetic), batch %d per GPU, len %d, reconstruction + VG + contrastive '
+                                   'losses, whole training step (BASELINE configs[%d]); random-init weights, V 10000, 1024-d embeddings, k_neg 100'
+                                   % (D, B, L, 3 if world > 1 else 2),
+                       'global_batch': world * B, 'length': L, 'dim': D, 'mfma': mfma_mode,
+                       'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU',
+                       **({'gradient_exchange': 'RCCL all-reduce (backend %s) of one flat fp32 buffer of %d floats per step (chart + heads + ImageEncoder); '
+                                                '%d of %d gradients copied in (the chart backward writes the rest in place)'
+                                                % (args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
+            'step_ms': dict(median=round(pct(step_ms, 0.5), 4), p10=round(pct(step_ms, 0.1), 4), p90=round(pct(step_ms, 0.9), 4),
+                            note='per-step device time from HIP event pairs on the launch stream inside the timed region (rank 0)'),
+            'roofline': dict(bound='hbm', kernel='whole step (no single dominant kernel is timed for this workload; see --workload c2)',
+                             achieved=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                             frac=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4), traffic=None,
+                             model='SURVEY.md section 8(d) chart bytes (%d per step) + the (B, B, C, 36) scorer tensor three times (%d)' % (step_bytes, scorer_bytes)),
+            'cpu_baseline': None,
+        }
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -242,6 +310,11 @@ def main():
     ap.add_argument('--length', type=int, default=20)
     ap.add_argument('--dim', type=int, default=400)
     ap.add_argument('--batch', type=int, default=64, help='sentences per GPU')
+    ap.add_argument('--workload', choices=['c2', 'c3'], default='c2',
+                    help='c2 (default): BASELINE configs[1], DioraMLP chart forward + backward -- the configuration the metric is quoted on; '
+                         'c3: the CLIORA training step of configs[2] / configs[3] (Embed, ImageEncoder, chart with 36 x 2048-d regions, '
+                         'reconstruction + VG + contrastive losses, backward, gradient all-reduce, clip, Adam): `--gpus 8 --workload c3` '
+                         'is configs[3] (batch 512 global)')
     ap.add_argument('--mfma', choices=['bf16x3', 'f32'], default=None,
                     help='arithmetic of the compose GEMMs (default: the library default, split-bf16; see include/cliora_chart.h)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -280,6 +353,8 @@ def main():
     dev = torch.device('cuda', local)
     B, L, D = args.batch, args.length, args.dim
     C = L * (L + 1) // 2
+    if args.workload == 'c3':
+        return cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, use_dist, mfma_mode)
 
     torch.manual_seed(1234)                     # same parameters on every rank (train_diora.sh:9)
     model = DioraMLP(D, outside=True, normalize='unit', compress=False, share=True).to(dev)

@@ -129,8 +129,9 @@ def lib():
     L.cliora_set_persistent.restype = i32
     L.cliora_persistent_status.argtypes = [vp, C.POINTER(C.c_uint), vp]
     L.cliora_persistent_status.restype = i32
-    L.cliora_persistent_inject_timeout.argtypes = [vp, vp]
-    L.cliora_persistent_inject_timeout.restype = i32
+    if hasattr(L, 'cliora_persistent_inject_timeout'):      # diagnostics entry point (absent from older builds loaded through CLIORA_CHART_LIB)
+        L.cliora_persistent_inject_timeout.argtypes = [vp, vp]
+        L.cliora_persistent_inject_timeout.restype = i32
     L.cliora_persistent_trace.argtypes = [vp, vp, sz, vp]
     L.cliora_persistent_trace.restype = i32
     _lib = L

@@ -784,7 +784,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // from them nearly what it removes from the tail: profiles/r03_ubench_priority.txt).  CLIORA_WGRAD_EARLY_STEP = -1 turns it off.
     static const int early_env = [] { const char* e = getenv("CLIORA_WGRAD_EARLY_STEP"); return e ? atoi(e) : -2; }();
     static const int early_slices = [] { const char* e = getenv("CLIORA_WGRAD_EARLY_SLICES"); return e ? atoi(e) : 32; }();
-    const int early_auto = L >= 16 ? (L - 1) / 2 : -1;
+    // round 4 (the two ends now run as ONE launch with one reduction, so a shorter tail pays more than it did): c2 J = 9 / 10 / 11 / 12:
+    // 3.41 / 3.39 / 3.33 / 3.42 ms per step; L 40 J = 19 / 21 / 23: 19.25 / 19.22 / 19.60
+    const int early_auto = L >= 16 ? L / 2 + 1 : -1;
     const int early_pick = early_env == -2 ? early_auto : early_env;
     const int J_early = (p.share && ran_outside && !compress && !resident && early_pick >= 0 && early_pick <= L - 3) ? early_pick : -1;
     long long early_r0 = 0, early_r1 = 0;

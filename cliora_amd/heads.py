@@ -19,6 +19,11 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _grad_out(t):
+    from .diora import _grad_out as g
+    return g(t)
+
+
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -45,7 +50,7 @@ class Proj(torch.autograd.Function):
             ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
             _lib.check(lib.cliora_proj_forward(_p(x2), _p(index), nrows, K, _p(w), _p(bias), D, _p(y), _p(ws), nb, _st()), 'cliora_proj_forward')
         ctx.save_for_backward(x2, index, w)
-        ctx.has_bias, ctx.x_shape, ctx.ws = bias is not None, x.shape, ws
+        ctx.has_bias, ctx.x_shape, ctx.ws, ctx.bias = bias is not None, x.shape, ws, (bias.detach() if bias is not None else None)
         return y
 
     @staticmethod
@@ -57,8 +62,10 @@ class Proj(torch.autograd.Function):
         lib = _lib.lib()
         need_x = ctx.needs_input_grad[0]
         with torch.cuda.device(d_y.device):
-            d_w = torch.empty_like(w) if ctx.needs_input_grad[2] else None
-            d_b = torch.empty(D, device=d_y.device) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+            # the parameter's slice of a live flat gradient buffer when there is one (cliora_amd.parallel: the all-reduce and the fused
+            # clip + Adam then have nothing to copy), else a fresh tensor
+            d_w = _grad_out(w) if ctx.needs_input_grad[2] else None
+            d_b = _grad_out(ctx.bias) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
             d_rows = torch.empty((nrows, K), device=d_y.device) if need_x else None
             nb = ctx.ws.numel()
             _lib.check(lib.cliora_proj_backward(_p(x2), _p(index), nrows, K, _p(w), _p(d_y), D, _p(d_w), _p(d_b), _p(d_rows), _p(ctx.ws), nb, _st()),
@@ -112,7 +119,7 @@ class ReconLoss(torch.autograd.Function):
         with torch.cuda.device(emb.device):
             g = g.contiguous().float().reshape(1)
             d_cell = torch.empty((B * L, D), device=emb.device) if ctx.needs_input_grad[2] else None
-            d_mat = torch.empty_like(mat) if ctx.needs_input_grad[1] else None
+            d_mat = _grad_out(mat) if ctx.needs_input_grad[1] else None
             d_rows = torch.empty((B * L + Kn, E), device=emb.device) if ctx.needs_input_grad[0] else None
             nb = ctx.ws.numel()
             _lib.check(lib.cliora_recon_backward(_p(tokens), _p(neg), B, L, Cc, Kn, _p(emb), E, _p(mat), D, _p(outside_h), _p(g), _p(d_cell), _p(d_mat),

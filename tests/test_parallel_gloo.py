@@ -84,6 +84,72 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _cliora_step_grads(R, P, heads, sentences, neg, obj):
+    """Gradients of one rank's CLIORA training loss (Embed + ImageEncoder + chart + the three losses: the parameter set of
+    `bench.py --workload c3`, BASELINE configs[3]) from the CPU oracle.  Returns {name: grad} over chart and head parameters."""
+    Pq = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    Hq = {k: v.clone().requires_grad_(True) for k, v in heads.items()}
+    xs, xw = R.embed_forward(Hq['emb'], Hq['mat'], Hq['mat1'], sentences)
+    os_, ow = R.image_encoder_forward(Hq['fc.weight'], Hq['fc.bias'], Hq['fc_vis.weight'], Hq['fc_vis.bias'], obj)
+    ref = R.diora_forward(Pq, xs, xw, os_, ow, training=False)
+    loss = (R.reconstruction_loss(Hq['emb'], Hq['rmat'], sentences, neg, ref['outside_h']) + R.vg_loss(ref['vg_atten_score'], 1.0)
+            + R.contrastive_loss(ref['inside_s'], ref['outside_s'], ref['all_atten_score'], 0.2, 1.0))
+    loss.backward()
+    out = {k: v.grad for k, v in Pq.items() if v.grad is not None}
+    out.update({'head.' + k: v.grad for k, v in Hq.items() if v.grad is not None})
+    return out
+
+
+def _worker_cliora(rank, world, port, ret):
+    """One flat all-reduce over chart + head + ImageEncoder gradients (the c3 / c4 parameter set): every rank trains on its own chunk
+    of the global batch -- the in-batch negatives of the VG and contrastive losses stay local to a rank (trainer.py:101-121, 142-169),
+    so the reduced gradient is the MEAN OF THE RANKS' gradients, which rank 0 recomputes serially."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cliora_amd.parallel import FlatGradAllReduce, rank_chunk
+    from oracle import diora_ref as R
+    D, B, L, Rg, V, E, K, F = 12, 4, 5, 3, 30, 16, 5, 8
+    g = torch.Generator().manual_seed(5)
+    P = {k: v.detach() for k, v in R.init_params(D, share=True, seed=3).items()}
+    heads = {'emb': torch.randn(V, E, generator=g), 'mat': torch.randn(D, E, generator=g), 'mat1': torch.randn(D, E, generator=g),
+             'fc.weight': 0.1 * torch.randn(D, F, generator=g), 'fc.bias': 0.1 * torch.randn(D, generator=g),
+             'fc_vis.weight': 0.1 * torch.randn(D, F, generator=g), 'fc_vis.bias': 0.1 * torch.randn(D, generator=g),
+             'rmat': torch.randn(D, E, generator=g)}
+    sentences = torch.randint(0, V, (B, L), generator=g)
+    neg = torch.randperm(V, generator=g)[:K]
+    obj = torch.relu(torch.randn(B, Rg, F, generator=g))
+    mine = _cliora_step_grads(R, P, heads, rank_chunk(sentences, world, rank), neg, rank_chunk(obj, world, rank))
+    names = sorted(mine)
+    params = []
+    for n in names:
+        p = torch.nn.Parameter(torch.zeros_like(mine[n]))
+        p.grad = mine[n].clone()
+        params.append(p)
+    red = FlatGradAllReduce(params)
+    red.all_reduce_mean()
+    if rank == 0:
+        want = None
+        for r in range(world):
+            gr = _cliora_step_grads(R, P, heads, rank_chunk(sentences, world, r), neg, rank_chunk(obj, world, r))
+            want = gr if want is None else {n: want[n] + gr[n] for n in names}
+        err = max(float((p.grad - want[n] / world).abs().max() / max(1e-12, float(want[n].abs().max()))) for n, p in zip(names, params))
+        ret['cliora_err'] = err
+        ret['cliora_names'] = len(names)
+        ret['cliora_floats'] = red.flat.numel()
+    red.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2_cliora_parameter_set():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_cliora, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret['cliora_err'] < 1e-5, ret['cliora_err']
+    assert ret['cliora_names'] >= 14            # 6 chart tensors (shared weights) + Embed (3) + ImageEncoder (4) + the reconstruction head
+
+
 def test_flat_grad_allreduce_world2():
     world = 2
     mgr = mp.Manager()
