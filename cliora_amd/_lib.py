@@ -121,6 +121,8 @@ def lib():
     L.cliora_set_mfma_mode.restype = i32
     L.cliora_set_wavefront.argtypes = [i32]
     L.cliora_set_wavefront.restype = i32
+    if hasattr(L, 'cliora_built_with_rows_stationary'):
+        L.cliora_built_with_rows_stationary.restype = i32
     L.cliora_set_rows_stationary.argtypes = [i32]
     L.cliora_set_rows_stationary.restype = i32
     L.cliora_set_resident.argtypes = [i32]
@@ -257,6 +259,12 @@ def set_persistent(mode):
 
 
 RS_MODES = {'auto': -1, 'off': 0, 'on': 1, 'geometry': 2}
+
+
+def has_rows_stationary():
+    """True when the library was built with the optional rows-stationary compose kernel (include/cliora_chart.h)."""
+    L = lib()
+    return bool(hasattr(L, 'cliora_built_with_rows_stationary') and L.cliora_built_with_rows_stationary())
 
 
 def set_rows_stationary(mode):

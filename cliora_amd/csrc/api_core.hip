@@ -348,6 +348,13 @@ extern "C" int cliora_set_wavefront(int mode) {
 int g_cliora_persistent = [] { const char* e = getenv("CLIORA_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
 int g_cliora_rows_stationary = [] { const char* e = getenv("CLIORA_ROWS_STATIONARY"); return e ? atoi(e) : -1; }();
 int g_cliora_rs_min_rows = [] { const char* e = getenv("CLIORA_RS_MIN_ROWS"); return e ? atoi(e) : 0x7fffffff; }();
+extern "C" int cliora_built_with_rows_stationary(void) {
+#ifdef CLIORA_WITH_ROWS_STATIONARY
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int cliora_set_rows_stationary(int mode) {
     const int prev = g_cliora_rows_stationary;
     g_cliora_rows_stationary = mode < 0 ? -1 : std::min(mode, 2);

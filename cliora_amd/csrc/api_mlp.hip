@@ -2,7 +2,9 @@
 // See include/cliora_chart.h for the contract and the reference lines it replaces.
 #include "api_common.hpp"
 #include "level_kernels.hpp"
+#ifdef CLIORA_WITH_ROWS_STATIONARY      // the rows-stationary forward compose (measured: no level of any shape selects it) is an optional build
 #include "compose_rs_kernels.hpp"
+#endif
 #include "persist_kernels.hpp"
 #include "resident_kernels.hpp"
 #include "vl_kernels.hpp"
@@ -22,6 +24,10 @@ unsigned long long* g_rs_trace_buf = nullptr;      // diagnostic builds (-DCLIOR
 // Rows-stationary forward compose (compose_rs_kernels.hpp) for the levels whose operand gathers outweigh re-streaming the weights:
 // measured on MI355X at d 400 (tools/shapes.py, profiles/r03_rows_stationary.txt).  Only the Dp = 400 kernel is instantiated.
 static bool rows_stationary_level(const Plan& p, int ncell, int N, bool vl) {
+#ifndef CLIORA_WITH_ROWS_STATIONARY
+    (void)p; (void)ncell; (void)N; (void)vl;
+    return false;
+#endif
     if (g_cliora_rows_stationary == 0 || p.arch != 0 || p.Dp != 400 || N < 1 || N > 8 * HP_PARTS) return false;
     (void)vl;
     if (g_cliora_rows_stationary > 0) return true;
@@ -80,6 +86,7 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? W : Wimg);
     const int S = f32 ? Dp : S3;
+#ifdef CLIORA_WITH_ROWS_STATIONARY
     if (q.rs) {
         unsigned long long* rs_trace = nullptr;
 #ifdef CLIORA_RS_STAMPS
@@ -98,6 +105,7 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
         LAUNCHOK("level_compose_fwd_rs");
         return CLIORA_OK;
     }
+#endif
 #define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, q
 #define LC_CASE(c, k16) return f32 ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
     if (ct == 5 && Dp == 400) LC_CASE(5, 25);
@@ -679,6 +687,26 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
     float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
 
+    // Sibling uses of inside level s in the outside pass (cell_gather_bwd_sib), on the OUTSIDE chain's stream: they are complete once
+    // the outside backward has done level L-2-s, one step before the inside chain reaches level s (which already waits for that
+    // step's event).  Shared weights: two scratch charts that cell_gather_bwd_in adds; unshared: blocks 3 / 4 of dPI directly.
+    float *sibPL = p.share ? wb + bw.sib_pl : dPI + (size_t)3 * Dp, *sibQL = p.share ? wb + bw.sib_ql : dPI + (size_t)4 * Dp;
+    const int ldsib = p.share ? Dp : ldpi;
+    // Which chain sums them: in the first steps of the backward the OUTSIDE chain is the longer one (outside levels 0, 1, ... hold the
+    // most pair rows, the inside levels L-1, L-2, ... the fewest cells), later the inside chain (its low levels' cells have the most
+    // uses): the inside levels below `sib_split` (reached in the later steps) get their sibling sums from the outside chain, the others
+    // walk the list themselves.  Measured per step at c2 (profiles/r04_notes.md): inside / outside chain 57-84 / 75-103 us in steps
+    // 0-11 with everything on the outside chain, 100 / 60-99 in steps 12-19.  CLIORA_SIB_SPLIT = 0 (never) .. L (always).
+    static const int sib_env = [] { const char* e = getenv("CLIORA_SIB_SPLIT"); return e ? atoi(e) : -1; }();
+    const int sib_split = !two_streams ? 0 : sib_env >= 0 ? std::min(sib_env, L) : (L * 2) / 5;
+    auto sib_on_outside_chain = [&](int s_level) { return s_level < sib_split; };
+    auto sibling_gather = [&](int s_level) -> int {
+        if (s_level < 0 || s_level > L - 1 || !ran_outside || !sib_on_outside_chain(s_level)) return CLIORA_OK;
+        const LevelArgs gi = level_args(p, s_level, false);
+        hipLaunchKernelGGL(cell_gather_bwd_sib, dim3(B * gi.Lc), dim3(256), 0, sb, gi, dv.use[ROLE_OUTA], DA, DS, OH, sibPL, sibQL, ldsib, wb + bw.sib_s);
+        LAUNCHOK("cell_gather_bwd_sib");
+        return CLIORA_OK;
+    };
     auto outside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
         const int ncell = B * g.Lc;
@@ -707,6 +735,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         }
         hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
         LAUNCHOK("cell_dsoftmax(out)");
+        OKR(sibling_gather(L - 2 - level));      // the inside level whose sibling uses are final with this outside level
         return CLIORA_OK;
     };
 
@@ -714,15 +743,40 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // level's gather has run, and their share runs on the GEMM stream beside the remaining (latency-bound, small) levels; only the low
     // levels' rows are left for the tail, where the pair weight gradient owns the chip.
     static const int ksplit_env = [] { const char* e = getenv("CLIORA_WGRAD_SPLIT_LEVEL"); return e ? atoi(e) : -1; }();
-    const int ksplit = ksplit_env >= 0 ? ksplit_env : std::min(2, L - 1);   // measured at L = 20: 2 best (4.52 -> 4.42 ms), higher levels leave more for the tail
+    // fp32 element-load kernel (exact mode, other widths): level 2 (round 2, L = 20: 4.52 -> 4.42 ms, higher levels leave more for the tail).
+    // Split mode at d = 400 (round 4: the remapped LDS-DMA kernel, a launch per projection block): the early part is cheap enough to be
+    // worth starting in the MIDDLE of the chain, so that the GEMM stream is idle again when the low levels' share arrives -- c2 with
+    // level 2 / 4 / 8 / 10 / 12: 3.36 / 3.35 / 3.30-3.32 / 3.29 / 3.32 ms
+    const bool wcat_split_path = split_bf16() && tn_pairs_strided_ok(Dp);
+    const int ksplit = ksplit_env >= 0 ? ksplit_env : wcat_split_path ? std::max(1, std::min(L / 2, L - 1)) : std::min(2, L - 1);
     int tail_cells = C;                                         // chart rows per sentence still to be covered by the tail launch
+    bool dpi_done_recorded = false;                             // ev_fork[2] marks "every row of dPI is final" on the caller's stream
+    // d Wcat (+)= dPI^T IH over the cells [off, off + hi) of every sentence.  Split mode at d = 400 (round 4): one launch per projection
+    // block on the eight-wave split-bf16 kernel with the rows remapped inside it; else the fp32 element-load kernel over all blocks.
+    static const bool wcat_f32 = [] { const char* e = getenv("CLIORA_WCAT_GRAD"); return e && !strcmp(e, "f32"); }();
+    static const int wcat_slices = [] { const char* e = getenv("CLIORA_WCAT_SLICES"); return e ? atoi(e) : 48; }();
+    auto wcat_grad = [&](hipStream_t s_, int off, int hi, int accumulate) -> int {
+        if (!wcat_f32 && tn_pairs_strided_ok(Dp) && (long long)B * hi >= 512) {
+            for (int blk = 0; blk < nb; ++blk)
+                OKR(launch_tn_level_block(s_, dPI, ldpi, blk * Dp, IH, B, C, off, hi, Dp, wb + bw.slab2, bw.slab_floats,
+                                          wb + bw.gwcat + (size_t)blk * Dp * Dp, wb + bw.gbcat + (size_t)blk * Dp, accumulate, wcat_slices));
+            return CLIORA_OK;
+        }
+        return launch_tn(s_, B * hi, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, off, hi}, LevelRowsA{IH, Dp, C, off, hi}, wb + bw.slab2,
+                         bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat, accumulate);
+    };
     auto inside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
         const int ncell = B * g.Lc;
         hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, sa, g, D, d_inside_h,
-                           level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA], ran_outside,
-                           DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
+                           level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA],
+                           !ran_outside ? 0 : (sib_on_outside_chain(level) ? 1 : 2),
+                           sibPL, sibQL, ldsib, wb + bw.sib_s, DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
         LAUNCHOK("cell_gather_bwd_in");
+        if (level == 0) {       // dPI is complete: the low levels' share of the projections' weight gradient can start (GEMM stream)
+            HIPOK(hipEventRecord(plan->ev_fork[2], sa));
+            dpi_done_recorded = true;
+        }
         if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
@@ -738,8 +792,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             const int hi = C - g.off;                           // cells per sentence at levels >= ksplit (a level's cells are contiguous)
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
-            OKR(launch_tn(sw, B * hi, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, g.off, hi}, LevelRowsA{IH, Dp, C, g.off, hi}, wb + bw.slab2,
-                          bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat));
+            OKR(wcat_grad(sw, g.off, hi, 0));
             tail_cells = g.off;
         }
         if (level == 0) return CLIORA_OK;
@@ -752,6 +805,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         }
         hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
         LAUNCHOK("cell_dsoftmax(in)");
+        if (level == 1 && two_streams) HIPOK(hipEventRecord(plan->ev_join[2], sa));     // the last pair rows (DZ, X) are final
         return CLIORA_OK;
     };
 
@@ -760,6 +814,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         HIPOK(hipStreamWaitEvent(sb, plan->ev_fork[0], 0));
         fork_guard.arm(0, sb, plan->ev_join[0]);
     }
+    if (!ran_outside && !p.share)      // no outside pass: nobody writes the outside blocks of dPI (cell_gather_bwd_sib does otherwise)
+        HIPOK(hipMemsetAsync(dPI, 0, (size_t)B * C * ldpi * sizeof(float), st));
     if (!ran_outside) {
         HIPOK(hipMemsetAsync(wb + bw.gw2o, 0, (size_t)Dp * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(wb + bw.gb2o, 0, (size_t)Dp * sizeof(float), st));
@@ -837,16 +893,57 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // ---- weight gradients: the cell projections' and the leaf layer's on the GEMM stream, the pair rows' dW2 (tn_gemm_dma3 fills
     //      every CU's LDS) on the caller's stream once both chains are done ----
     HIPOK(hipEventRecord(plan->ev_fork[1], st));
+    // The pair rows' tail (the rows whose dW2 did not start early).  Two streams (round 4): on the OUTSIDE chain's stream -- that chain
+    // ends a step before the inside chain, and the last pair rows are final after inside level 1 (ev_join[2]), so the tail runs beside the
+    // inside chain's last gather, projection backward and leaf layer instead of after them.  One stream: on the caller's stream, last.
+    auto pair_rows_tail = [&](hipStream_t s_) -> int {
+        ProfScope ps(CLIORA_KCLASS_WGRAD, s_);
+        if (ran_outside && !p.share)
+            OKR(launch_tn_pairs(s_, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
+                                wb + bw.gw2o, wb + bw.gb2o));
+        // shared weights: inside and outside pair rows are one contiguous range -> one launch
+        const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
+        if (J_early >= 0) {          // the middle of the range is on its way on the GEMM stream (into gw2o / gb2o): the two ends here
+            static const int tail_slices = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES"); return e ? atoi(e) : 48; }();
+            static const int tail_slices2 = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES2"); return e ? atoi(e) : 72; }();
+            if (tn_pairs_two_ranges_ok(Dp))          // both ends in one launch (round 4): one slab, one reduction
+                OKR(launch_tn_pairs_two_ranges(s_, DZ, Xp, (int)early_r0, early_r1, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
+                                               wb + bw.gw2i, wb + bw.gb2i, tail_slices2));
+            else {
+                OKR(launch_tn_pairs(s_, DZ, Xp, (int)early_r0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0, tail_slices));
+                OKR(launch_tn_pairs(s_, DZ + (size_t)early_r1 * Dp, Xp + (size_t)early_r1 * Dp, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
+                                    wb + bw.gw2i, wb + bw.gb2i, 1, tail_slices));
+            }
+        } else
+            OKR(launch_tn_pairs(s_, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
+        // shared weights without the early part: gw2o / gb2o hold nothing of this call -- the scatter below leaves them out
+        return CLIORA_OK;
+    };
     if (ran_outside) {
         if (two_streams) {
+            // d W1R_out = dPO^T OH needs the outside chain only: on ITS stream, behind its last kernel (round 4; on the GEMM stream it
+            // queued behind the projections' weight gradient and ended the step) -- on the split-bf16 LDS-DMA kernel where there is one
+            // (plain contiguous rows: 100 + 31 us of fp32 element-load GEMM + reduction -> one short launch)
+            if (tn_pairs_strided_ok(Dp))
+                OKR(launch_tn_pairs(sb, dPO, OH, B * C, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro, (float*)nullptr, 0, 72));
+            else
+                OKR(launch_tn(sb, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab, bw.slab_floats, wb + bw.gw1ro,
+                              (float*)nullptr));
+            if (L >= 2) HIPOK(hipStreamWaitEvent(sb, plan->ev_join[2], 0));
+            OKR(pair_rows_tail(sb));
             HIPOK(hipEventRecord(plan->ev_join[0], sb));
-            HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
-            HIPOK(hipStreamWaitEvent(sw, plan->ev_join[0], 0));
-        } else {
+        } else {           // one chain: the same kernel (the two schedules agree to the bit), on the GEMM stream
             HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[1], 0));
+            if (tn_pairs_strided_ok(Dp))
+                OKR(launch_tn_pairs(sw, dPO, OH, B * C, Dp, wb + bw.slab2, bw.slab_floats, wb + bw.gw1ro, (float*)nullptr, 0, 72));
+            else
+                OKR(launch_tn(sw, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gw1ro,
+                              (float*)nullptr));
         }
-        OKR(launch_tn(sw, B * C, Dp, Dp, Dp, PlainRowsA{dPO, Dp}, PlainRowsA{OH, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gw1ro,
-                      (float*)nullptr));
+    }
+    if (dpi_done_recorded) {     // the low levels' d Wcat needs the last gather only, not the leaf layer's backward behind it
+        HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
+        OKR(wcat_grad(sw, 0, tail_cells, tail_cells < C));
     }
     HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[1], 0));
     if (vl && d_obj_span) {      // d obj: independent of the weight gradients, so beside the pair rows' tail on the GEMM stream
@@ -855,35 +952,11 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            wb + bw.dsc, dO);
         LAUNCHOK("obj_grad_reduce");
     }
-    OKR(launch_tn(sw, B * tail_cells, ldpi, Dp, Dp, LevelRowsA{dPI, ldpi, C, 0, tail_cells}, LevelRowsA{IH, Dp, C, 0, tail_cells},
-                  wb + bw.slab2, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat, tail_cells < C));
+    if (!dpi_done_recorded) OKR(wcat_grad(sw, 0, tail_cells, tail_cells < C));
     OKR(launch_tn(sw, B * L, Dp, Dp, Dp, PlainRowsA{dU, Dp}, PlainRowsA{X, Dp}, wb + bw.slab2, bw.slab_floats, wb + bw.gwl, wb + bw.gbl));
     HIPOK(hipEventRecord(plan->ev_join[1], sw));
-    {
-        ProfScope ps(CLIORA_KCLASS_WGRAD, st);
-        if (ran_outside && !p.share)
-            OKR(launch_tn_pairs(st, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
-                                wb + bw.gw2o, wb + bw.gb2o));
-        // shared weights: inside and outside pair rows are one contiguous range -> one launch
-        const long long nr = (p.share && ran_outside) ? p.R_in + p.R_out : p.R_in;
-        if (J_early >= 0) {          // the middle of the range is on its way on the GEMM stream (into gw2o / gb2o): the two ends here
-            // the two end ranges are short and run beside the side stream's small GEMMs: two thirds of the chip each (c2: 72 / 56 / 40 / 24
-            // slices: 3.497 / 3.484 / 3.481 / 3.547 ms)
-            static const int tail_slices = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES"); return e ? atoi(e) : 48; }();
-            static const int tail_slices2 = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES2"); return e ? atoi(e) : 72; }();
-            if (tn_pairs_two_ranges_ok(Dp))          // both ends in one launch (round 4): one slab, one reduction
-                OKR(launch_tn_pairs_two_ranges(st, DZ, Xp, (int)early_r0, early_r1, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
-                                               wb + bw.gw2i, wb + bw.gb2i, tail_slices2));
-            else {
-            OKR(launch_tn_pairs(st, DZ, Xp, (int)early_r0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0, tail_slices));
-            OKR(launch_tn_pairs(st, DZ + (size_t)early_r1 * Dp, Xp + (size_t)early_r1 * Dp, (int)(nr - early_r1), Dp, wb + bw.slab, bw.slab_floats,
-                                wb + bw.gw2i, wb + bw.gb2i, 1, tail_slices));
-            }
-        } else
-        OKR(launch_tn_pairs(st, DZ, Xp, (int)nr, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i));
-        // shared weights without the early part: gw2o / gb2o hold nothing of this call -- the scatter below leaves them out (two memset
-        // launches before)
-    }
+    if (!two_streams) OKR(pair_rows_tail(st));
+    else HIPOK(hipStreamWaitEvent(st, plan->ev_join[0], 0));
     HIPOK(hipStreamWaitEvent(st, plan->ev_join[1], 0));
     fork_guard.disarm();                                   // both side streams have been joined above
 

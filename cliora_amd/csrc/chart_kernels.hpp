@@ -220,14 +220,22 @@ __device__ __forceinline__ void wg_sum_pairs(float4 (*sh)[GATHER_SLOTS][64], int
         for (int k = 0; k < nslots; ++k) v[k] = f4add(v[k], sh[0][k][lane]);
 }
 
+// sib_pl / sib_ql / sib_s (round 4): the sums over the cell's sibling uses in the OUTSIDE pass (dPLo, dQLo, their ds), formed by the
+// outside chain one step earlier (cell_gather_bwd_sib) -- half of an inside cell's uses leave the inside chain, the longer of the two.
+// Shared weights: rows of two scratch charts, added into the PL / QL blocks here; unshared: the kernel wrote blocks 3 / 4 of dPI itself.
+// with_outside: 0 no outside pass; 1 the sibling sums come from cell_gather_bwd_sib (sib_pl / sib_ql / sib_s); 2 this kernel walks the
+// sibling use list itself (the steps in which the OUTSIDE chain is the longer one: api_mlp.hip picks per step) and -- unshared weights --
+// leaves its sums in sib_pl / sib_ql, which then are blocks 3 / 4 of dPI.
 static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
                                                           UseTab ina, UseTab inb, UseTab outa, int with_outside,
+                                                          float* __restrict__ sib_pl, float* __restrict__ sib_ql, int ldsib,
+                                                          const float* __restrict__ sib_s,
                                                           const float* __restrict__ DA, const float* __restrict__ DS,
                                                           const float* __restrict__ PI, int ldpi, int share,
                                                           const float* __restrict__ IH, const float* __restrict__ OH,
                                                           float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ dStot) {
     __shared__ float4 sh[2][GATHER_SLOTS][64];
-    __shared__ float sh_s[4];
+    __shared__ float sh_s[4], sh_s2[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x;
     const int b = t / g.Lc, p = t - b * g.Lc;
@@ -242,46 +250,82 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
     float4 v[GATHER_SLOTS];
 #pragma unroll
     for (int k = 0; k < GATHER_SLOTS; ++k) v[k] = f4zero();
-    float4 dPLo0 = f4zero(), dPLo1 = f4zero(), dQLo0 = f4zero(), dQLo1 = f4zero();
+    // the outside pass's share, on its way while the lists below are walked (shared weights; wave 0 adds it at the end)
+    const bool sib = with_outside == 1 && share && wave == 0;
+    float4 sp0 = f4zero(), sp1 = f4zero(), sq0 = f4zero(), sq1 = f4zero();
+    if (sib && act0) { sp0 = ld4(sib_pl + crow * Dp + col0); sq0 = ld4(sib_ql + crow * Dp + col0); }
+    if (sib && act1) { sp1 = ld4(sib_pl + crow * Dp + col1); sq1 = ld4(sib_ql + crow * Dp + col1); }
+    const float ss = (with_outside == 1 && wave == 0) ? sib_s[crow] : 0.f;
     // right-child uses: partner = left child; dH += ds * QL(left);  dPR += DA
     gather_uses(inb, c, b, bC, wave, DA, DS, Dp, PI + 2 * Dp, ldpi, col0, col1, act0, act1, v[4], v[5], v[0], v[1], vS);
     // left-child uses: partner = right child; dQL += ds * H(right);  dPL += DA
     gather_uses(ina, c, b, bC, wave, DA, DS, Dp, IH, Dp, col0, col1, act0, act1, v[2], v[3], v[6], v[7], vS);
-    // sibling uses in the outside pass: partner = parent (outside chart)
-    if (with_outside) gather_uses(outa, c, b, bC, wave, DA, DS, Dp, OH, Dp, col0, col1, act0, act1, dPLo0, dPLo1, dQLo0, dQLo1, vS);
-    if (share) {                       // shared weights: sibling uses feed the same PL / QL blocks
-        v[2] = f4add(v[2], dPLo0); v[3] = f4add(v[3], dPLo1); v[6] = f4add(v[6], dQLo0); v[7] = f4add(v[7], dQLo1);
-        wg_sum_pairs(sh, wave, lane, 8, v);
-    } else {
-        v[8] = dPLo0; v[9] = dPLo1;
-        wg_sum_pairs(sh, wave, lane, 10, v);
-    }
-    vS = wave == 0 ? vS : vS;          // every lane of a wave holds the same vS
-    if (lane == 0) sh_s[wave] = vS;
-    float4 q0 = f4zero(), q1 = f4zero();
-    if (!share) {                      // the fifth block (dQLo) goes through LDS in a second round
+    wg_sum_pairs(sh, wave, lane, 8, v);
+    if (with_outside == 2) {           // sibling uses in the outside pass, walked here: partner = parent (outside chart); own reduction round
+        float4 w[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
         __syncthreads();
-        float4 w2[2] = {dQLo0, dQLo1};
-        wg_sum_pairs(sh, wave, lane, 2, w2);
-        q0 = w2[0]; q1 = w2[1];
+        float vSo = 0.f;               // summed on its own, in cell_gather_bwd_sib's order: the result does not depend on who sums
+        gather_uses(outa, c, b, bC, wave, DA, DS, Dp, OH, Dp, col0, col1, act0, act1, w[0], w[1], w[2], w[3], vSo);
+        wg_sum_pairs(sh, wave, lane, 4, w);
+        if (lane == 0) sh_s2[wave] = vSo;
+        sp0 = w[0]; sp1 = w[1]; sq0 = w[2]; sq1 = w[3];
+        if (!share && wave == 0) {     // unshared weights: blocks 3 / 4 of dPI (what cell_gather_bwd_sib writes in the other mode)
+            if (act0) { st4(sib_pl + crow * ldsib + col0, sp0); st4(sib_ql + crow * ldsib + col0, sq0); }
+            if (act1) { st4(sib_pl + crow * ldsib + col1, sp1); st4(sib_ql + crow * ldsib + col1, sq1); }
+        }
+        if (!share) { sp0 = sp1 = sq0 = sq1 = f4zero(); }
     }
+    if (lane == 0) sh_s[wave] = vS;    // every lane of a wave holds the same vS
     __syncthreads();
     if (wave != 0) return;
-    const float vs = ((sh_s[0] + sh_s[1]) + sh_s[2]) + sh_s[3] + (dS_ext ? dS_ext[crow] : 0.f);
+    const float sso = with_outside == 2 ? ((sh_s2[0] + sh_s2[1]) + sh_s2[2]) + sh_s2[3] : ss;
+    const float vs = ((sh_s[0] + sh_s[1]) + sh_s[2]) + sh_s[3] + sso + (dS_ext ? dS_ext[crow] : 0.f);
     float* o = dPI + crow * ldpi;
     if (act0) {
         const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
-        st4(o + col0, v[2]); st4(o + Dp + col0, v[4]); st4(o + 2 * Dp + col0, v[6]);
-        if (!share) { st4(o + 3 * Dp + col0, v[8]); st4(o + 4 * Dp + col0, q0); }
+        st4(o + col0, f4add(v[2], sp0)); st4(o + Dp + col0, v[4]); st4(o + 2 * Dp + col0, f4add(v[6], sq0));
         st4(VH + crow * Dp + col0, f4add(v[0], e));
     }
     if (act1) {
         const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
-        st4(o + col1, v[3]); st4(o + Dp + col1, v[5]); st4(o + 2 * Dp + col1, v[7]);
-        if (!share) { st4(o + 3 * Dp + col1, v[9]); st4(o + 4 * Dp + col1, q1); }
+        st4(o + col1, f4add(v[3], sp1)); st4(o + Dp + col1, v[5]); st4(o + 2 * Dp + col1, f4add(v[7], sq1));
         st4(VH + crow * Dp + col1, f4add(v[1], e));
     }
     if (lane == 0) dStot[crow] = vs;
+}
+
+// Sibling uses of the inside cells of one level in the outside pass (partner = the parent, outside chart):
+//   dPLo = sum DA[row];  dQLo = sum ds[row] * OH(parent);  sib_s = sum ds[row]
+// They are final once the outside backward has passed level L-2-s for an inside level s -- one step before the inside chain gets to
+// that level -- so the OUTSIDE chain's stream sums them (after its cell_dsoftmax of that step) and cell_gather_bwd_in only adds the
+// result: in the backward wavefront the inside chain is the longer one, and these are half of its cells' uses.
+// out_pl / out_ql: row stride ldo (shared weights: scratch charts of stride Dp; unshared: blocks 3 / 4 of dPI, stride ldpi).
+static __global__ __launch_bounds__(256) void cell_gather_bwd_sib(LevelArgs g, UseTab outa, const float* __restrict__ DA, const float* __restrict__ DS,
+                                                           const float* __restrict__ OH, float* __restrict__ out_pl, float* __restrict__ out_ql,
+                                                           int ldo, float* __restrict__ sib_s) {
+    __shared__ float4 sh[2][GATHER_SLOTS][64];
+    __shared__ float sh_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x;
+    const int b = t / g.Lc, p = t - b * g.Lc;
+    const int c = g.off + p;
+    const size_t crow = (size_t)b * g.C + c;
+    const int Dp = g.Dp, nv = Dp >> 2;
+    const int bC = b * g.C;
+    const bool act0 = lane < nv, act1 = lane + 64 < nv;
+    const int col0 = 4 * lane, col1 = 4 * (lane + 64);
+    float vS = 0.f;
+    float4 v[GATHER_SLOTS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = f4zero();
+    gather_uses(outa, c, b, bC, wave, DA, DS, Dp, OH, Dp, col0, col1, act0, act1, v[2], v[3], v[0], v[1], vS);
+    wg_sum_pairs(sh, wave, lane, 4, v);
+    if (lane == 0) sh_s[wave] = vS;
+    __syncthreads();
+    if (wave != 0) return;
+    if (act0) { st4(out_pl + crow * ldo + col0, v[2]); st4(out_ql + crow * ldo + col0, v[0]); }
+    if (act1) { st4(out_pl + crow * ldo + col1, v[3]); st4(out_ql + crow * ldo + col1, v[1]); }
+    if (lane == 0) sib_s[crow] = ((sh_s[0] + sh_s[1]) + sh_s[2]) + sh_s[3];
 }
 
 //   outside cell c (as parent in the outside pass):

@@ -1077,7 +1077,11 @@ template <int NIT, int NJT, int NJW, bool COLSUM>
 static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int nrows,
                                                      int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
                                                      float* __restrict__ slab, float* __restrict__ colsum,
-                                                     int slice2 = 0x7fffffff, int nrows2 = 0, long long shift2 = 0) {
+                                                     int slice2 = 0x7fffffff, int nrows2 = 0, long long shift2 = 0,
+                                                     int rm_hi = 0, int rm_C = 0, int rm_off = 0) {
+    // rm_hi > 0: the rows are the cells [rm_off, rm_off + rm_hi) of every sentence's chart (rm_C cells per sentence) of BOTH
+    // matrices -- row r is chart row (r / rm_hi) * rm_C + rm_off + r % rm_hi: the projections' weight gradient over the levels
+    // that are final (round 4: the fp32 element-load tn_gemm took 233 us for them at d 400 and ended the step)
     // slices >= slice2 walk a SECOND row range of the same matrices: nrows2 rows starting shift2 rows further down (the two ends of the
     // pair rows around the part whose weight gradient started early: one launch, one slab, one reduction for both)
     static_assert(2 * NJW > NJT, "the second half of the j-tiles needs a spare slot for the ones-tile");
@@ -1119,6 +1123,7 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
 
     constexpr int NPW = (TN3_NP + 1) / 2;                   // pieces per wave per stage, upper bound
     const int npieces = (UA + UX) >> 6;
+    const float rm_inv = rm_hi ? 1.0f / (float)rm_hi : 0.f;   // (r + 0.5) * rm_inv floors to r / rm_hi exactly for r < 4e6
     int p_rr[NPW], p_off[NPW];
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
@@ -1145,7 +1150,9 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
                 const bool isA = piece * 64 < UA;
                 const float* base = isA ? A : B;
                 const int ld = isA ? lda : ldb;        // row strides of the two operands (Mi / Nj when they are plain matrices)
-                const float* src = base + (size_t)(r0 + min(p_rr[k], rmax)) * ld + p_off[k];
+                int row = r0 + min(p_rr[k], rmax);
+                if (rm_hi) { const int sb_ = (int)(((float)row + 0.5f) * rm_inv); row = sb_ * rm_C + rm_off + (row - sb_ * rm_hi); }
+                const float* src = base + (size_t)row * ld + p_off[k];
                 __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
             }
         }

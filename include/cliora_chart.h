@@ -350,6 +350,10 @@ int cliora_set_resident(int mode);
 #define CLIORA_ROWS_STATIONARY_ON 1
 #define CLIORA_ROWS_STATIONARY_GEOMETRY_ONLY 2
 int cliora_set_rows_stationary(int mode);
+/* Round 4: AUTO selects the kernel for no level of any shape, so it is an OPTIONAL part of the build (csrc compiled with
+ * -DCLIORA_WITH_ROWS_STATIONARY: `CLIORA_BUILD_EXTRA=-DCLIORA_WITH_ROWS_STATIONARY python -m cliora_amd.build --force`).  Without
+ * it cliora_set_rows_stationary still records the mode but every level runs the weight-stationary kernel.  1 if built in. */
+int cliora_built_with_rows_stationary(void);
 
 /* Float offset of a named region of the forward workspace ("pi", "po", "hp", "hp_o", "sp", "pp", "ymask", "nrmi", "nrmo", "t",
  * "qrleaf", "sync", "total"), for tests and tooling that compare two runs region by region; (size_t)-1 for an unknown name. */
