@@ -77,13 +77,14 @@ def cpu_baseline(L, D, B, budget_s=25.0):
                        % (len(times), b, L, D, torch.__version__, threads, med, t_all))
 
 
-def algorithmic_bytes(plan, B, D):
+def algorithmic_bytes(plan, B, D, cell_floats=None):
     """forward bytes per level = (unique chart cells read + cells written) x (D + 1) x 4, from the
     plan's own index tables (the reference's tables, tests/test_plan_tables.py); backward = 2 x forward.  Returns
-    (bytes per step of the whole path, forward bytes per level for the inside and the outside pass)."""
+    (bytes per step of the whole path, forward bytes per level for the inside and the outside pass).  cell_floats: floats per
+    chart cell (default D + 1: h and the score; the TreeLSTM also moves the cell state c: 2 D + 1, SURVEY 8d "included for TreeLSTM")."""
     import numpy as np
     L = plan.L
-    cell_b = (D + 1) * 4.0
+    cell_b = (cell_floats if cell_floats else D + 1) * 4.0
     per_level = {'in': [], 'out': []}
     for key, a_name, b_name, base_name, levels, nsplit in (
             ('in', 'pair_a_in', 'pair_b_in', 'pair_lvl_base_in', range(1, L), lambda lv: lv),
@@ -139,7 +140,7 @@ def other_measurements(torch, dev, budget_steps=12):
     from cliora_amd.treelstm import DioraTreeLSTM
     out = {}
 
-    def chart(make, B, L, D, R=0, steps=budget_steps, warmup=3):
+    def chart(make, B, L, D, R=0, steps=budget_steps, warmup=3, arch=0):
         torch.manual_seed(0)
         m = make().to(dev).train()
         for p in m.parameters():
@@ -166,7 +167,16 @@ def other_measurements(torch, dev, budget_steps=12):
             step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        return dict(B=B, L=L, D=D, R=R, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1))
+        res = dict(B=B, L=L, D=D, R=R, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1))
+        try:        # the shape's own SURVEY 8(d) bytes and what they come to against 8 TB/s (whole step)
+            from cliora_amd import _lib
+            plan = _lib.get_plan(B, L, D, True, 'unit', R, dev.index or 0, arch=arch)
+            step_bytes, _ = algorithmic_bytes(plan, B, D, cell_floats=(2 * D + 1) if arch == 1 else None)
+            res['roofline'] = dict(bound='hbm', algorithmic_bytes=round(step_bytes), achieved_GBs=round(step_bytes / dt / 1e9, 1), peak_GBs=PEAK_HBM_GBS,
+                                   frac=round(step_bytes / dt / 1e9 / PEAK_HBM_GBS, 4))
+        except Exception as e:                                # noqa: BLE001
+            res['roofline'] = 'failed: %s' % str(e)[:120]
+        return res
 
     def parse(B=64, L=20, D=400, steps=budget_steps, warmup=3):
         """Inference as scripts/parse.py runs it: eval-mode forward (no backward state kept) + the CKY decode of every sentence."""
@@ -221,13 +231,17 @@ def other_measurements(torch, dev, budget_steps=12):
     cases = (('c1 DioraMLP d50 B8 L10', lambda: chart(lambda: DioraMLP(50), 8, 10, 50)),
              ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36)),
              ('DioraMLP d400 B64 L40', lambda: chart(lambda: DioraMLP(400), 64, 40, 400, steps=6, warmup=2)),
-             ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2)),
+             ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2, arch=1)),
              ('parse c2 (eval forward + CKY trees on the GPU, trees copied to the host)', parse),
              ('whole step DIORA c2 (Embed, chart, reconstruction loss, clip, Adam)', lambda: whole(False)),
              ('whole step CLIORA c3 (+ ImageEncoder, VG and contrastive losses)', lambda: whole(True)))
+    impl_note = {'c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)':
+                 'implementation traffic ~118 GB per step (DESIGN.md section 7a: twelve rows per pair in the forward, nine rows per use and four uses per pair in the backward)'}
     for name, fn in cases:
         try:
             out[name] = fn()
+            if name in impl_note and isinstance(out[name], dict):
+                out[name]['implementation_bytes'] = impl_note[name]
         except Exception as e:                                   # noqa: BLE001 -- a side figure must not cost the headline
             out[name] = 'failed: %s: %s' % (type(e).__name__, str(e)[:200])
         torch.cuda.empty_cache()
@@ -467,11 +481,11 @@ def main():
                 tj = json.load(open(tp))
                 traffic = tj.get(dom)
                 traffic_src = dict(file='profiles/traffic.json', kind='committed rocprofv3 PMC figure (2 x FETCH_SIZE + WRITE_SIZE per launch, own --pmc passes), not collected in this run',
-                                   measured=tj.get('measured', 'see profiles/README.md'))
+                                   measured=tj.get('measured', 'see profiles/README.md'), commit=tj.get('commit', 'not recorded'))
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command, so that
             # frac can be reproduced from profiles/ alone (the two clocks agree within a few per cent)
             rocprof = None
-            for cand in ('r03_kernel_stats.csv', 'r02_kernel_stats.csv'):
+            for cand in ('r04_kernel_stats.csv', 'r03_kernel_stats.csv', 'r02_kernel_stats.csv'):
                 kp = os.path.join(ROOT, 'profiles', cand)
                 if os.path.exists(kp):
                     import csv

@@ -749,6 +749,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // level 2 / 4 / 8 / 10 / 12: 3.36 / 3.35 / 3.30-3.32 / 3.29 / 3.32 ms
     const bool wcat_split_path = split_bf16() && tn_pairs_strided_ok(Dp);
     const int ksplit = ksplit_env >= 0 ? ksplit_env : wcat_split_path ? std::max(1, std::min(L / 2, L - 1)) : std::min(2, L - 1);
+    // ... optionally a second part (the levels below the first part down to ksplit2, CLIORA_WGRAD_SPLIT_LEVEL2): three more launches
+    // beside the inside chain's heaviest steps cost more than they take from the tail
+    static const int ksplit2_env = [] { const char* e = getenv("CLIORA_WGRAD_SPLIT_LEVEL2"); return e ? atoi(e) : -1; }();
+    const int ksplit2 = ksplit2_env > 0 ? ksplit2_env : -1;         // measured at c2: 3.32 (none) vs 3.37 (levels 2-5): off
     int tail_cells = C;                                         // chart rows per sentence still to be covered by the tail launch
     bool dpi_done_recorded = false;                             // ev_fork[2] marks "every row of dPI is final" on the caller's stream
     // d Wcat (+)= dPI^T IH over the cells [off, off + hi) of every sentence.  Split mode at d = 400 (round 4): one launch per projection
@@ -788,11 +792,12 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                                drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
             LAUNCHOK("cell_attend_bwd");
         }
-        if (level == ksplit && level >= 1) {
-            const int hi = C - g.off;                           // cells per sentence at levels >= ksplit (a level's cells are contiguous)
+        if ((level == ksplit || level == ksplit2) && level >= 1) {
+            // cells per sentence at the levels from this one up to the part already on its way (a level's cells are contiguous)
+            const int hi = tail_cells - g.off;
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
-            OKR(wcat_grad(sw, g.off, hi, 0));
+            OKR(wcat_grad(sw, g.off, hi, tail_cells < C));
             tail_cells = g.off;
         }
         if (level == 0) return CLIORA_OK;

@@ -45,5 +45,7 @@ if __name__ == '__main__':
                                   note='bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950: FETCH_SIZE counts wide reads at half)')
     import datetime
     out['measured'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-cpu-baseline --no-kernel-events --no-extras --steps 2 --warmup 1` on %s (tools/final_profile.sh)' % datetime.date.today().isoformat()
+    import os
+    out['commit'] = os.environ.get('GRAFT_COMMIT', 'not recorded')       # the GPU box has no .git: pass GRAFT_COMMIT=$(git rev-parse --short HEAD) in the gpurun command
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(out))
