@@ -101,6 +101,9 @@ def lib():
     L.cliora_recon_forward.restype = i32
     L.cliora_recon_backward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.cliora_recon_backward.restype = i32
+    if hasattr(L, 'cliora_rows_scatter_add'):
+        L.cliora_rows_scatter_add.argtypes = [vp, vp, i32, i32, vp, C.c_int64, vp]
+        L.cliora_rows_scatter_add.restype = i32
     L.cliora_vg_workspace_bytes.argtypes = [i32, i32]
     L.cliora_vg_workspace_bytes.restype = sz
     L.cliora_vg_loss.argtypes = [i32, i32, i32, vp, C.c_float, vp, vp, vp, sz, vp]

@@ -242,6 +242,19 @@ extern "C" int cliora_recon_backward(const int64_t* tokens, const int64_t* neg, 
 }
 
 // ------------------------------------------------------------------ clip_grad_norm_ + Adam on one flat buffer
+// table_grad (V, K) = zeros, then table_grad[index[i]] += rows[i]: the scatter F.embedding's backward does (the last ATen op of the
+// training step in round 3: zeros_like + index_add_), deterministic
+extern "C" int cliora_rows_scatter_add(const float* rows, const int64_t* index, int n, int K, float* table_grad, int64_t V, void* stream) {
+    if (!rows || !index || !table_grad) return fail(CLIORA_EINVAL, "NULL argument");
+    if (n < 0 || K <= 0 || K % 4 != 0 || V <= 0) return fail(CLIORA_EINVAL, "rows_scatter_add: n >= 0, K a positive multiple of 4, V > 0");
+    hipStream_t st = (hipStream_t)stream;
+    HIPOK(hipMemsetAsync(table_grad, 0, (size_t)V * K * sizeof(float), st));
+    if (n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(rows_scatter_add, dim3(n), dim3(256), 0, st, rows, reinterpret_cast<const long long*>(index), n, K, table_grad, (long long)V);
+    LAUNCHOK("rows_scatter_add");
+    return CLIORA_OK;
+}
+
 extern "C" size_t cliora_clip_adam_workspace_bytes(void) { return (1024 + 64) * sizeof(float); }
 extern "C" int cliora_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm, float lr, float beta1, float beta2,
                                 float eps, int step, void* ws, size_t ws_bytes, void* stream) {

@@ -194,6 +194,31 @@ static __global__ void concat_index(int n0, const int64_t* __restrict__ a, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Gradient of an embedding table from the gradients of its looked-up rows (the backward of F.embedding, trainer.py:219 / :54-58):
+//   table_grad[index[i]] += rows[i]   for i < n,  every other row of table_grad zero (the caller clears it first).
+// One workgroup per looked-up row; the FIRST occurrence of a token owns its table row and adds the later occurrences in ascending i
+// (each workgroup scans the whole index list, n <= a few thousand): no atomics, the same bits every run -- torch's index_add_ adds
+// with float atomics in arrival order.  K a multiple of 4.
+static __global__ __launch_bounds__(256) void rows_scatter_add(const float* __restrict__ rows, const long long* __restrict__ index, int n, int K,
+                                                        float* __restrict__ table_grad, long long V) {
+    __shared__ int owner;
+    const int i = blockIdx.x;
+    const long long tok = index[i];
+    if (tok < 0 || tok >= V) return;
+    if (threadIdx.x == 0) owner = 1;
+    __syncthreads();
+    for (int j = threadIdx.x; j < i; j += 256)
+        if (index[j] == tok) owner = 0;            // an earlier occurrence owns the row (benign race: every writer stores 0)
+    __syncthreads();
+    if (!owner) return;
+    for (int c = 4 * threadIdx.x; c < K; c += 1024) {
+        float4 acc = ld4(rows + (size_t)i * K + c);
+        for (int j = i + 1; j < n; ++j)
+            if (index[j] == tok) acc = f4add(acc, ld4(rows + (size_t)j * K + c));
+        st4(table_grad + (size_t)tok * K + c, acc);
+    }
+}
+
 // Trainer.gradient_update (trainer.py:450-455): clip_grad_norm_(params, max_norm) + Adam step over ONE flat parameter / gradient
 // buffer: partial sums of g^2 per block -> total in block order (one lane) -> clip coefficient -> the update.
 // ---------------------------------------------------------------------------------------------------------------------------

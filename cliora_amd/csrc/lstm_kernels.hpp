@@ -15,10 +15,14 @@
 
 namespace cliora {
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate transcendentals on the hardware exp2 / rcp forms (round 4): sigmoid = rcp(1 + exp(-x)), tanh = 1 - 2 rcp(1 + exp(2x)) -- both
+// saturate correctly through exp -> inf / 0, absolute error ~1e-7 (the cell kernels recompute every gate twice per pair in the
+// backward: c5 at L 40 34.0 -> 31.4 ms, L 20 6.33 -> 5.90 against libm expf / tanhf; fixtures and oracle checks unchanged).
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float lstm_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 __device__ __forceinline__ float4 f4map(float4 a, float (*f)(float)) { return make_float4(f(a.x), f(a.y), f(a.z), f(a.w)); }
 __device__ __forceinline__ float4 f4sig(float4 a, float k) { return make_float4(sigm(a.x + k), sigm(a.y + k), sigm(a.z + k), sigm(a.w + k)); }
-__device__ __forceinline__ float4 f4tanh(float4 a) { return make_float4(tanhf(a.x), tanhf(a.y), tanhf(a.z), tanhf(a.w)); }
+__device__ __forceinline__ float4 f4tanh(float4 a) { return make_float4(lstm_tanh(a.x), lstm_tanh(a.y), lstm_tanh(a.z), lstm_tanh(a.w)); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 // g (1 - g)  and  (1 - t^2)
@@ -108,9 +112,9 @@ __device__ __forceinline__ LstmPairGrad<W> lstm_pair_grad(const VecW<W> (&x)[5],
     LstmPairGrad<W> r;
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-        const float u = tanhf(x[0].v[q]), i = sigm(x[1].v[q] + 0.f), o = sigm(x[2].v[q] + 0.f), f0 = sigm(x[3].v[q] + kf), f1 = sigm(x[4].v[q] + kf);
+        const float u = lstm_tanh(x[0].v[q]), i = sigm(x[1].v[q] + 0.f), o = sigm(x[2].v[q] + 0.f), f0 = sigm(x[3].v[q] + kf), f1 = sigm(x[4].v[q] + kf);
         const float c = (f0 * cA.v[q] + f1 * cB.v[q]) + i * u;          // as lstm_cell_fwd forms it
-        const float tc = tanhf(c);
+        const float tc = lstm_tanh(c);
         const float dh = pn * dGh.v[q];
         const float dc = pn * dGc.v[q] + (dh * o) * (1.f - tc * tc);
         r.da[0].v[q] = (dc * i) * (1.f - u * u);
@@ -310,14 +314,14 @@ static __global__ __launch_bounds__(512) void lstm_cell_fwd(LevelArgs g, const i
                 VecW<W> hh, cc;
 #pragma unroll
                 for (int q = 0; q < W; ++q) {
-                    const float u = tanhf(ga[j][0].v[q] + gb[j][0].v[q]);
+                    const float u = lstm_tanh(ga[j][0].v[q] + gb[j][0].v[q]);
                     const float i = sigm((ga[j][1].v[q] + gb[j][1].v[q]) + 0.f);
                     const float o = sigm((ga[j][2].v[q] + gb[j][2].v[q]) + 0.f);
                     const float f0 = sigm((ga[j][3].v[q] + gb[j][3].v[q]) + kf);
                     const float f1 = sigm((ga[j][4].v[q] + gb[j][4].v[q]) + kf);
                     const float c = (f0 * ca[j].v[q] + f1 * cb[j].v[q]) + i * u;
                     cc.v[q] = c;
-                    hh.v[q] = o * tanhf(c);
+                    hh.v[q] = o * lstm_tanh(c);
                     vh.v[q] = fmaf(pn[j], hh.v[q], vh.v[q]);
                     vc.v[q] = fmaf(pn[j], c, vc.v[q]);
                 }

@@ -32,6 +32,17 @@ def supported(*tensors):
     return all(t is None or (t.is_cuda and t.dtype in (torch.float32, torch.int64)) for t in tensors)
 
 
+def scatter_rows(d_rows, index, table):
+    """Gradient of the embedding `table` (V, K) from the gradients d_rows (n, K) of its looked-up rows index (n,): cliora_rows_scatter_add,
+    written into the table's slice of a live flat gradient buffer when this is the first producer of the pass (else a fresh tensor that
+    autograd adds).  Replaces zeros_like + index_add_ (round 3's last ATen op on the step), deterministic for repeated ids."""
+    out = _grad_out(table)
+    with torch.cuda.device(table.device):
+        _lib.check(_lib.lib().cliora_rows_scatter_add(_p(d_rows.contiguous()), _p(index.contiguous()), int(index.numel()), int(table.shape[1]), _p(out),
+                                                      int(table.shape[0]), _st()), 'cliora_rows_scatter_add')
+    return out
+
+
 class Proj(torch.autograd.Function):
     """y = gather(x, index) w^T + bias; index None = the rows of x themselves."""
 
@@ -74,8 +85,8 @@ class Proj(torch.autograd.Function):
             if need_x:
                 if index is None:
                     d_x = d_rows.view(ctx.x_shape)
-                else:       # the embedding table's gradient: rows of repeated tokens add up
-                    d_x = torch.zeros_like(x2).index_add_(0, index.reshape(-1), d_rows).view(ctx.x_shape)
+                else:       # the embedding table's gradient: rows of repeated tokens add up (in place in the flat gradient buffer when there is one)
+                    d_x = scatter_rows(d_rows, index.reshape(-1), x2).view(ctx.x_shape)
         return d_x, None, d_w, d_b
 
 
@@ -130,7 +141,7 @@ class ReconLoss(torch.autograd.Function):
                 d_oh[:, :L] = d_cell.view(B, L, D)
             d_emb = None
             if d_rows is not None:
-                d_emb = torch.zeros_like(emb).index_add_(0, torch.cat([tokens.reshape(-1), neg]), d_rows)
+                d_emb = scatter_rows(d_rows, torch.cat([tokens.reshape(-1), neg]), emb)
         return d_emb, d_mat, d_oh, None, None
 
 

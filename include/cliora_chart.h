@@ -216,6 +216,12 @@ int cliora_proj_forward(const float* x, const int64_t* index, int nrows, int K, 
 int cliora_proj_backward(const float* x, const int64_t* index, int nrows, int K, const float* w, const float* d_y, int D,
                          float* d_w, float* d_bias, float* d_rows, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Gradient of an embedding table from the gradients of its looked-up rows -- what autograd does behind F.embedding
+ * (cliora/net/trainer.py:219, :54-58; the table trains when emb = none: cliora/data/embeddings.py:164):
+ *   table_grad (V, K) = 0;  table_grad[index[i]] += rows[i], i < n      (index int64, K a multiple of 4; ids outside [0, V) are skipped)
+ * Repeated ids add up in ascending i, without atomics: bitwise reproducible. */
+int cliora_rows_scatter_add(const float* rows, const int64_t* index, int n, int K, float* table_grad, int64_t V, void* stream);
+
 /* ReconstructionSoftmaxLoss.forward (cliora/net/trainer.py:46-78): tokens (B*L) and neg (Kn) int64 ids into emb (V, E), mat (D, E),
  * outside_h (B, C, D) of which the leaf cells [:, :L] are read:
  *   proj = emb[ids] mat^T;  logits_r = [proj_pos_r . cell_r | cell_r proj_neg^T];  loss = mean_r CE(logits_r, 0)

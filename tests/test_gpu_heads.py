@@ -113,3 +113,28 @@ def test_fused_clip_adam_matches_torch():
             fused.step()
             for p, q in zip(p_ref, p_dev):
                 assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), (scale, step)
+
+
+def test_rows_scatter_add_matches_index_add_and_is_deterministic():
+    """cliora_rows_scatter_add (the backward of F.embedding, trainer.py:219: the embedding table trains when emb = none) against
+    torch's zeros + index_add_, with repeated ids (summed in ascending order, no atomics: the same bits every run), ids out of the
+    batch untouched (zero), and the sizes of the reconstruction head's lookup (B L + k_neg rows of 1024)."""
+    import ctypes as C
+    from cliora_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    for n, K, V in ((1380, 1024, 10000), (37, 48, 11), (1, 16, 5)):
+        idx = torch.randint(0, V, (n,), generator=g)
+        if n > 8:
+            idx[5] = idx[2]; idx[n - 1] = idx[2]; idx[7] = idx[6]          # repeats, one of them three times
+        rows = torch.randn(n, K, generator=g)
+        want = torch.zeros(V, K).index_add_(0, idx, rows)
+        outs = []
+        for rep in range(2):
+            out = torch.full((V, K), float('nan'), device='cuda')          # the call clears the table itself
+            rc = _lib.lib().cliora_rows_scatter_add(C.c_void_p(rows.cuda().data_ptr()), C.c_void_p(idx.cuda().data_ptr()), n, K,
+                                                    C.c_void_p(out.data_ptr()), V, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, 'cliora_rows_scatter_add')
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1])
+        assert float((outs[0] - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), (n, K, V)
