@@ -440,7 +440,10 @@ static int launch_tn_pairs(hipStream_t st, const float* DZ, const float* X, int 
         if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
         return CLIORA_OK;
     }
-    if (nrows <= TN_DIRECT_ROWS && (Dp / 16) * (Dp / 16) <= TN_DIRECT_BLOCKS && slices_cap == 0)
+    // ... and the pair rows only up to 1024 of them: at configs[0] (3 960 rows, 64 x 64 = 16 blocks) the direct form is 16 workgroups
+    // walking 495 rows per wave, 42 us on the caller's stream behind resident_bwd, against 10 + 7 us through the LDS-DMA kernel and
+    // the (round 4) parallel slab reduction
+    if (nrows <= 1024 && (Dp / 16) * (Dp / 16) <= TN_DIRECT_BLOCKS && slices_cap == 0)
         return launch_tn(st, nrows, Dp, Dp, Dp, PlainRowsA{DZ, ldz}, PlainRowsA{X, ldx}, slab, slab_floats, out, colsum_out, accumulate);
     // tile counts are compile-time (straight-line MFMA code): NIT = ceil(NT/4) i-tiles per wave,
     // nkb column blocks of NJT = ceil(NT/nkb) j-tiles

@@ -129,9 +129,10 @@ def test_rows_scatter_add_matches_index_add_and_is_deterministic():
         rows = torch.randn(n, K, generator=g)
         want = torch.zeros(V, K).index_add_(0, idx, rows)
         outs = []
+        rows_d, idx_d = rows.cuda(), idx.cuda()
         for rep in range(2):
             out = torch.full((V, K), float('nan'), device='cuda')          # the call clears the table itself
-            rc = _lib.lib().cliora_rows_scatter_add(C.c_void_p(rows.cuda().data_ptr()), C.c_void_p(idx.cuda().data_ptr()), n, K,
+            rc = _lib.lib().cliora_rows_scatter_add(C.c_void_p(rows_d.data_ptr()), C.c_void_p(idx_d.data_ptr()), n, K,
                                                     C.c_void_p(out.data_ptr()), V, C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, 'cliora_rows_scatter_add')
             torch.cuda.synchronize()
