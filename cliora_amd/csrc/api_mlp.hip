@@ -686,6 +686,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && ran_outside && !compress && !resident;
     hipStream_t sa = st, sb = two_streams ? plan->side : st, sw = plan->side2;
     float *VHo = wb + bw.vh_o, *dGo = wb + bw.dg_o, *dStoto = wb + bw.dstot_o;
+    // unit-norm backward in the projection-backward GEMM's epilogue (chart_kernels.hpp: NormBwdLevelE): text-only charts without compress
+    // (CLIORA normalises around the attention residual; compress keeps per-sentence root gradients in dGo).  CLIORA_FUSE_DNORM=0: off.
+    static const bool fuse_off = [] { const char* e = getenv("CLIORA_FUSE_DNORM"); return e && atoi(e) == 0; }();
+    const bool fuse_dnorm = !fuse_off && !vl && !compress && !resident;
 
     // Sibling uses of inside level s in the outside pass (cell_gather_bwd_sib), on the OUTSIDE chain's stream: they are complete once
     // the outside backward has done level L-2-s, one step before the inside chain reaches level s (which already waits for that
@@ -710,10 +714,17 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     auto outside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
         const int ncell = B * g.Lc;
+        // levels 1 .. L-2: the unit-norm backward rides in the projection-backward GEMM's epilogue (NormBwdLevelE; the gather leaves
+        // H . vH behind), no cell_dnorm launch
+        const bool fused_norm = fuse_dnorm && level >= 1 && level <= L - 2;
         hipLaunchKernelGGL(cell_gather_bwd_out, dim3(ncell), dim3(256), 0, sb, g, D, d_outside_h,
-                           level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VHo, dStoto);
+                           level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VHo, dStoto,
+                           OH, ws + f.po, fused_norm ? wb + bw.dots_o : nullptr);
         LAUNCHOK("cell_gather_bwd_out");
-        if (level >= 1)
+        if (fused_norm)
+            OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                            NormBwdLevelE{dGo, VHo, OH, ws + f.nrmo, wb + bw.dots_o, Dp, C, g.off, g.Lc, p.normalize}));
+        else if (level >= 1)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                             StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == L - 1) {
@@ -726,8 +737,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             LAUNCHOK("root_bwd");
             return CLIORA_OK;
         }
-        hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, VHo, OH, ws + f.nrmo, p.normalize, dGo);
-        LAUNCHOK("cell_dnorm(out)");
+        if (!fused_norm) {
+            hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, VHo, OH, ws + f.nrmo, p.normalize, dGo);
+            LAUNCHOK("cell_dnorm(out)");
+        }
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sb);
             OKR(launch_level_compose_bwd(sb, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dGo, YM, Pp,
@@ -772,16 +785,21 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     auto inside_bwd_step = [&](int level) -> int {
         const LevelArgs g = level_args(p, level, false);        // N == 0 at the leaves
         const int ncell = B * g.Lc;
+        const bool fused_norm = fuse_dnorm && p.share && !vl && level >= 1 && level <= L - 2;      // as in outside_bwd_step
         hipLaunchKernelGGL(cell_gather_bwd_in, dim3(ncell), dim3(256), 0, sa, g, D, d_inside_h,
                            level == 0 ? nullptr : d_inside_s, dv.use[ROLE_INA], dv.use[ROLE_INB], dv.use[ROLE_OUTA],
                            !ran_outside ? 0 : (sib_on_outside_chain(level) ? 1 : 2),
-                           sibPL, sibQL, ldsib, wb + bw.sib_s, DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot);
+                           sibPL, sibQL, ldsib, wb + bw.sib_s, DA, DS, PI, ldpi, p.share, IH, OH, dPI, VH, dStot,
+                           ws + f.bcat, fused_norm ? wb + bw.dots : nullptr);
         LAUNCHOK("cell_gather_bwd_in");
         if (level == 0) {       // dPI is complete: the low levels' share of the projections' weight gradient can start (GEMM stream)
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             dpi_done_recorded = true;
         }
-        if (level <= L - 2)
+        if (fused_norm)
+            OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                            NormBwdLevelE{dG, VH, IH, ws + f.nrmi, wb + bw.dots, Dp, C, g.off, g.Lc, p.normalize}));
+        else if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         else if (compress && ran_outside)       // d inside_h[root] += d root @ root_mat_out^T   (diora.py:342-343)
@@ -801,8 +819,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             tail_cells = g.off;
         }
         if (level == 0) return CLIORA_OK;
-        hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, VH, IHn, nrmIn, p.normalize, dG);
-        LAUNCHOK("cell_dnorm(in)");
+        if (!fused_norm) {
+            hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, VH, IHn, nrmIn, p.normalize, dG);
+            LAUNCHOK("cell_dnorm(in)");
+        }
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sa);
             OKR(launch_level_compose_bwd(sa, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,

@@ -233,7 +233,8 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
                                                           const float* __restrict__ DA, const float* __restrict__ DS,
                                                           const float* __restrict__ PI, int ldpi, int share,
                                                           const float* __restrict__ IH, const float* __restrict__ OH,
-                                                          float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ dStot) {
+                                                          float* __restrict__ dPI, float* __restrict__ VH, float* __restrict__ dStot,
+                                                          const float* __restrict__ bcat, float* __restrict__ dots) {
     __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4], sh_s2[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -292,6 +293,27 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
         st4(VH + crow * Dp + col1, f4add(v[1], e));
     }
     if (lane == 0) dStot[crow] = vs;
+    if (dots) {      // H . vH of the cell without the finished vH (NormBwdLevelE): H . vHg + dP . (P - bias) over the cell's projection blocks
+        float d = 0.f;
+        const float* hr = IH + crow * Dp;
+        const float* pr = PI + crow * ldpi;
+        if (act0) {
+            const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
+            d += f4dot(ld4(hr + col0), f4add(v[0], e));
+            const float4 b = ld4(bcat + col0), pl = ld4(pr + col0);
+            d += f4dot(f4add(v[2], sp0), make_float4(pl.x - b.x, pl.y - b.y, pl.z - b.z, pl.w - b.w));
+            d += f4dot(v[4], ld4(pr + Dp + col0)) + f4dot(f4add(v[6], sq0), ld4(pr + 2 * Dp + col0));
+        }
+        if (act1) {
+            const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
+            d += f4dot(ld4(hr + col1), f4add(v[1], e));
+            const float4 b = ld4(bcat + col1), pl = ld4(pr + col1);
+            d += f4dot(f4add(v[3], sp1), make_float4(pl.x - b.x, pl.y - b.y, pl.z - b.z, pl.w - b.w));
+            d += f4dot(v[5], ld4(pr + Dp + col1)) + f4dot(f4add(v[7], sq1), ld4(pr + 2 * Dp + col1));
+        }
+        d = wave_sum(d);
+        if (lane == 0) dots[crow] = d;
+    }
 }
 
 // Sibling uses of the inside cells of one level in the outside pass (partner = the parent, outside chart):
@@ -333,7 +355,8 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_sib(LevelArgs g, U
 static __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, int D, const float* __restrict__ dH_ext, const float* __restrict__ dS_ext,
                                                            UseTab outb, const float* __restrict__ DA, const float* __restrict__ DS,
                                                            const float* __restrict__ PI, int ldpi, int blk_qlo,
-                                                           float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ dStot) {
+                                                           float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ dStot,
+                                                           const float* __restrict__ OHc, const float* __restrict__ PO, float* __restrict__ dots) {
     __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -364,6 +387,19 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, i
         st4(dPO + crow * Dp + col1, v[3]); st4(VH + crow * Dp + col1, f4add(v[1], e));
     }
     if (lane == 0) dStot[crow] = vs;
+    if (dots) {      // H . vH = H . vHg + dPO . PO (the outside projection has no bias): see NormBwdLevelE
+        float d = 0.f;
+        if (act0) {
+            const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col0) : f4zero();
+            d += f4dot(ld4(OHc + crow * Dp + col0), f4add(v[0], e)) + f4dot(v[2], ld4(PO + crow * Dp + col0));
+        }
+        if (act1) {
+            const float4 e = dH_ext ? ld_ext(dH_ext + crow * D, D, col1) : f4zero();
+            d += f4dot(ld4(OHc + crow * Dp + col1), f4add(v[1], e)) + f4dot(v[3], ld4(PO + crow * Dp + col1));
+        }
+        d = wave_sum(d);
+        if (lane == 0) dots[crow] = d;
+    }
 }
 
 // unit-norm backward for one row held as two float4 per lane: H = g / max(||g||, eps)
@@ -511,6 +547,30 @@ struct StoreLevelE {           // level row r -> chart row; out[crow*ld + col] =
         if (bias) v = f4add(v, ld4(bias + col));
         if (accumulate) v = f4add(v, ld4(rc.o + col));
         st4(rc.o + col, v);
+    }
+};
+
+// Projection-backward GEMM with the unit-norm backward in its epilogue (round 4): the GEMM's accumulator is dP Wcat for the level's
+// rows; with vH = vHg + dP Wcat the gradient w.r.t. the aggregate g (H = g / max(||g||, eps)) is
+//     dG = (vH - H (H . vH)) / ||g||        and   H . vH = H . vHg + dP . (P - bias)      (P = H Wcat^T + bias is the stored projection)
+// -- the right-hand side needs no finished vH, so the gather kernels, which hold vHg and dP of the cell in registers, leave the dot
+// product in `dots` and this epilogue turns each 16 x 16 tile of the product straight into dG: the cell_dnorm launch of every level
+// (but the root / leaf ones, which have no GEMM) leaves both backward chains.  Same formulas as unit_norm_bwd, per element.
+struct NormBwdLevelE {
+    float* dG; const float* VHg; const float* H; const float* nrm; const float* dots; int ld, C, off, Lc, normalize;
+    struct RCtx { float* o; const float* v; const float* h; float dot, inv; int plain; };
+    __device__ RCtx row(int r) const {
+        const int b = r / Lc;
+        const size_t crow = (size_t)b * C + off + (r - b * Lc);
+        const float nr = nrm[crow];
+        const int small = !(nr > UNIT_EPS);
+        return RCtx{dG + crow * ld, VHg + crow * ld, H + crow * ld, (normalize && !small) ? dots[crow] : 0.f,
+                    !normalize ? 1.f : (small ? 1.f / UNIT_EPS : 1.f / nr), 0};
+    }
+    __device__ void store4(const RCtx& rc, int col, float4 v) const {
+        const float4 g = ld4(rc.v + col), h = ld4(rc.h + col);
+        st4(rc.o + col, make_float4(((v.x + g.x) - h.x * rc.dot) * rc.inv, ((v.y + g.y) - h.y * rc.dot) * rc.inv,
+                                    ((v.z + g.z) - h.z * rc.dot) * rc.inv, ((v.w + g.w) - h.w * rc.dot) * rc.inv));
     }
 };
 

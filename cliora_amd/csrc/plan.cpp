@@ -219,6 +219,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.dpb = take(arch == 0 ? Rt : 0);
         b.dcb = take(0); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);
         b.dpi = take(BC * nb * Dp); b.dpo = take(BC * npo * Dp);
+        b.dots = take(arch == 0 ? BC : 0); b.dots_o = take(arch == 0 ? BC : 0);
         b.sib_pl = take((arch == 0 && p.share) ? BC * Dp : 0); b.sib_ql = take((arch == 0 && p.share) ? BC * Dp : 0); b.sib_s = take(arch == 0 ? BC : 0);
         b.du = take(BL * nlf * Dp); b.dxp = take(padded ? BL * Dp : 0);
         // split-K slabs: at most 1024 wave-sized partial blocks of 80x80 per weight-gradient GEMM

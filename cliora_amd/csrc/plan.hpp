@@ -72,6 +72,7 @@ struct BwdLayout {
     size_t dpp, dpb;                    // DioraMLP: partial dG.y_n per pair row and column block (R x ncb3), and its bias term (R)
     size_t dcb, vc, dgc, grootc;        // TreeLSTM: d c_b per pair (R x Dp), cell-state grads per cell (B*C x Dp) x2, d root c
     size_t dpi, dpo;                    // grads of the projections
+    size_t dots, dots_o;                // DioraMLP: H . vH per cell, left by the gathers for the unit-norm backward in the GEMM epilogue (NormBwdLevelE)
     size_t sib_pl, sib_ql, sib_s;       // DioraMLP: sums over the inside cells' sibling uses in the outside pass (cell_gather_bwd_sib): two charts (shared weights only), one scalar per cell
     size_t du, dxp;                     // leaf pre-activation grad, padded dx
     size_t slab, slab2;                 // split-K partial sums for the weight-gradient GEMMs (slab2: the side stream's)
