@@ -1,12 +1,12 @@
 #!/bin/bash
-# end-of-round measurement set (run on the MI355X box from the repo root): bench line, kernel stats, PMC passes.
+# end-of-round measurement set (run on the MI355X box from the repo root): bench line, kernel stats, PMC passes, other shapes.
 # Every rocprofv3 run is its own pass (kernel-trace only next to --pmc); summaries are copied to profiles/ by hand.
+#   gpurun -- "GRAFT_COMMIT=$(git rev-parse --short HEAD) bash tools/final_profile.sh"      (the box has no .git)
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-CLIORA_PERSISTENT=1 python bench.py --no-cpu-baseline --no-extras > $O/bench_persistent_on.json 2> $O/bench_persistent_on.err
-python tools/persist_ab.py > $O/persist_ab.txt 2>&1
-CLIORA_PERSIST_TRACE=1 python tools/persist_trace.py > $O/persist_trace.txt 2>&1
+python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
+python tools/shapes.py > $O/shapes.jsonl 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-events --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ks -- $B --steps 10 --warmup 3 > $O/prof.log 2>&1
@@ -14,9 +14,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc -o write -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc -o mfma -- $B --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
 cd $R
+python tools/timeline.py $O/prof/ks_kernel_trace.csv > $O/timeline.txt 2>&1
 python tools/summarize_pmc.py $O/pmc/fetch_counter_collection.csv $O/pmc_fetch_by_kernel.csv
 python tools/summarize_pmc.py $O/pmc/write_counter_collection.csv $O/pmc_write_by_kernel.csv
 python tools/summarize_pmc.py $O/pmc/mfma_counter_collection.csv $O/pmc_mfma_busy.csv --mfma-busy
 python tools/pmc_traffic.py $O/pmc/fetch_counter_collection.csv $O/pmc/write_counter_collection.csv $O/traffic.json
-rm -rf $O/pmc/*_counter_collection.csv $O/prof/ks_kernel_trace.csv    # big raw files stay on the box
+rm -rf $O/pmc/*_counter_collection.csv $O/prof/ks_kernel_trace.csv $O/pmc/*_kernel_trace.csv    # big raw files stay on the box
+for c in "c1 DioraMLP" "c3 CLIORA" "DioraMLP len 40" "c5 DioraTreeLSTM len 40"; do
+  t=$(echo $c | tr -d ' ' | tr 'A-Z' 'a-z'); bash tools/prof_shape.sh fin_$t "$c" > $O/stats_$t.txt 2>&1; cp gpurun_out/prof/fin_${t}_kernel_stats.csv $O/ 2>/dev/null
+done
+rm -f gpurun_out/prof/fin_*_kernel_trace.csv
 ls -la $O $O/prof
