@@ -518,6 +518,29 @@ static int build_weight_images(hipStream_t st, const ImageList& l) {
     LAUNCHOK("split_weight_image");
     return CLIORA_OK;
 }
+static int build_frag_images3(hipStream_t st, const ImageList& l) {       // split-bf16 fragment images (rows_gemm_ksplit3)
+    if (l.n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(frag_weight_image3, dim3(256, 1, l.n), dim3(256), 0, st, l.tab);
+    LAUNCHOK("frag_weight_image3");
+    return CLIORA_OK;
+}
+// out = A W^T on split-bf16 products, W as its frag_weight_image3 (ncols a multiple of 16 output columns, the image's first `ncols`;
+// K any multiple of 16): the TreeLSTM's gate projections and their backward in the default arithmetic mode
+template <class AP, class EP>
+static int launch_rows_direct3(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0 || ncols <= 0) return CLIORA_OK;
+    const int nt = ncols / 16, nrg = (nrows + 15) / 16;
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(img3);
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+#define R3_CASE(ct) hipLaunchKernelGGL((rows_gemm_ksplit3<ct, AP, EP>), dim3(nrgp * (nt / ct)), dim3(256), 0, st, I, K, nrg, nrgp, nrows, ap, ep)
+    if (nt % 5 == 0) R3_CASE(5);
+    else if (nt % 4 == 0) R3_CASE(4);
+    else if (nt % 2 == 0) R3_CASE(2);
+    else R3_CASE(1);
+#undef R3_CASE
+    LAUNCHOK("rows_gemm_ksplit3");
+    return CLIORA_OK;
+}
 static int build_frag_images(hipStream_t st, const ImageList& l) {
     if (l.n == 0) return CLIORA_OK;
     hipLaunchKernelGGL(frag_weight_image, dim3(256, 1, l.n), dim3(256), 0, st, l.tab);

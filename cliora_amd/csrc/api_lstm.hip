@@ -9,6 +9,14 @@
 #define LSTM_W 4          // floats per thread in the cell-centric backward kernels (lstm_kernels.hpp: VecW); 1, 2 and 4 time the same on MI355X
 #endif
 
+// The gate projections (10 of the 11 / 15 of the 17 blocks per inside cell, all 5 per outside cell) and the projection backward on
+// split-bf16 MFMA (gemm_kernels.hpp: rows_gemm_ksplit3) in the default arithmetic mode -- their outputs feed sigmoid / tanh, which the
+// fixtures and the oracle hold to 1e-4; the score blocks (QL = mat^T h) stay on exact fp32 products.  CLIORA_LSTM_PROJ=f32: the fp32 kernels.
+static bool lstm_proj_split() {
+    static const bool off = [] { const char* e = getenv("CLIORA_LSTM_PROJ"); return e && !strcmp(e, "f32"); }();
+    return !off && split_bf16();
+}
+
 // two streams pay under the same rule as for DioraMLP (api_mlp.hip: wavefront_pays)
 static bool wavefront_pays_lstm(const Plan& p, int mode) {
     if (p.L <= 2 || mode == 0) return false;
@@ -89,15 +97,39 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
             pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
             pj.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
             OKR(build_frag_images(st, pj));
+            ImageList p3;       // built in either mode: the backward call may run under the other one
+            p3.add(ws + f.wcat, ws + f.wcat3s, ldpi, Dp, Dp); p3.add(ws + f.wcatT, ws + f.wcatT3s, Dp, ldpi, ldpi);
+            p3.add(ws + f.w1ro, ws + f.w1ro3s, ldpo, Dp, Dp); p3.add(ws + f.w1roT, ws + f.w1roT3s, Dp, ldpo, ldpo);
+            OKR(build_frag_images3(st, p3));
         }
     }
+    const bool proj3 = lstm_proj_split();
+    // projections of the cells [off, off + Lc) of every sentence: every block on split-bf16 products, then the score blocks (10, and 16
+    // with unshared outside functions) again on exact fp32 products -- their fragment image is a column-tile range of the whole one
+    auto project_inside = [&](hipStream_t s_, int ncell, int off, int Lc) -> int {
+        const LevelRowsA rows{IH, Dp, C, off, Lc};
+        if (!proj3)
+            return launch_rows_direct(s_, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, rows, StoreLevelE{ws + f.pi, ldpi, C, off, Lc, ws + f.bcat, 0});
+        OKR(launch_rows_direct3(s_, ws + f.wcat3s, Dp, ldpi, ncell, rows, StoreLevelE{ws + f.pi, ldpi, C, off, Lc, ws + f.bcat, 0}));
+        for (int blk : {10, 16}) {
+            if (blk >= p.nblk) break;
+            OKR(launch_rows_direct(s_, ws + f.wcat + (size_t)blk * DD, ws + f.wcat3 + (size_t)blk * DD, IMG_FRAG_F32, Dp, Dp, ncell, rows,
+                                   StoreLevelE{ws + f.pi + (size_t)blk * Dp, ldpi, C, off, Lc, ws + f.bcat + (size_t)blk * Dp, 0}));
+        }
+        return CLIORA_OK;
+    };
+    auto project_outside = [&](hipStream_t s_, int ncell, int off, int Lc) -> int {
+        const LevelRowsA rows{OH, Dp, C, off, Lc};
+        if (!proj3)
+            return launch_rows_direct(s_, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, rows, StoreLevelE{ws + f.po, ldpo, C, off, Lc, nullptr, 0});
+        return launch_rows_direct3(s_, ws + f.w1ro3s, Dp, ldpo, ncell, rows, StoreLevelE{ws + f.po, ldpo, C, off, Lc, nullptr, 0});
+    };
     // leaves
     OKR(launch_rows_direct(st, ws + f.wl, PROJ_IMG(f.wl3), Dp, 3 * Dp, B * L, PlainRowsA{X, Dp}, StoreRowsE{ws + f.t, 3 * Dp, ws + f.bl, 0, 3 * Dp}));
     hipLaunchKernelGGL(lstm_leaf_fwd, dim3(cells_grid(B * L)), dim3(256), 0, st, B, L, C, Dp, ws + f.t, p.normalize, IH, IC, ws + f.nrmi,
                        ws + f.nrmic, IS);
     LAUNCHOK("lstm_leaf_fwd");
-    if (L > 1)
-        OKR(launch_rows_direct(st, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, B * L, LevelRowsA{IH, Dp, C, 0, L}, StoreLevelE{ws + f.pi, ldpi, C, 0, L, ws + f.bcat, 0}));
+    if (L > 1) OKR(project_inside(st, B * L, 0, L));
     // The two passes as a wavefront (see cliora_chart_forward): step k runs inside level k on the caller's stream and outside level
     // L-k on the side stream, which needs the inside projections of the levels <= k-2 (its siblings).
     // run_outside carries the flag bits of cliora_chart_forward: without a backward to come and without a hook the per-split rows
@@ -117,9 +149,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
                            ws + f.pi + 5 * Dp, ldpi, IC, IC, 1.0f, ws + f.pp, p.normalize, keep_pairs ? ws + f.y : nullptr, ws + f.x, IH, IC,
                            ws + f.nrmi, ws + f.nrmic);
         LAUNCHOK("lstm_cell_fwd");
-        if (level < L - 1)
-            OKR(launch_rows_direct(sa, ws + f.wcat, PROJ_IMG(f.wcat3), Dp, ldpi, ncell, LevelRowsA{IH, Dp, C, g.off, g.Lc},
-                                   StoreLevelE{ws + f.pi, ldpi, C, g.off, g.Lc, ws + f.bcat, 0}));
+        if (level < L - 1) OKR(project_inside(sa, ncell, g.off, g.Lc));
         return CLIORA_OK;
     };
     auto outside_step = [&](int level) -> int {
@@ -132,9 +162,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
                            ws + f.pi + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, ldpo, IC, OC, 0.0f, ws + f.pp, p.normalize,
                            keep_pairs ? ws + f.y : nullptr, ws + f.x, OH, OC, ws + f.nrmo, ws + f.nrmoc);
         LAUNCHOK("lstm_cell_fwd(out)");
-        if (level >= 1)
-            OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, ncell, LevelRowsA{OH, Dp, C, g.off, g.Lc},
-                                   StoreLevelE{ws + f.po, ldpo, C, g.off, g.Lc, nullptr, 0}));
+        if (level >= 1) OKR(project_outside(sb, ncell, g.off, g.Lc));
         return CLIORA_OK;
     };
     if (two_streams) {
@@ -146,8 +174,7 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
         hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootp, 0, B, 1, C, C - 1, Dp, p.normalize, OH, ws + f.nrmo, OS);
         hipLaunchKernelGGL(unit_norm_rows, dim3(cells_grid(B)), dim3(256), 0, sb, ws + f.rootc, 0, B, 1, C, C - 1, Dp, p.normalize, OC, ws + f.nrmoc, OS);
         LAUNCHOK("unit_norm_rows(root)");
-        if (L > 1)
-            OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, ldpo, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, ldpo, C, C - 1, 1, nullptr, 0}));
+        if (L > 1) OKR(project_outside(sb, B, C - 1, 1));
     } else {
         HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
         HIPOK(hipMemsetAsync(OC, 0, (size_t)B * C * Dp * sizeof(float), st));
@@ -213,6 +240,7 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
     const float *Y = ws + f.y, *Xc = ws + f.x, *Sp = ws + f.sp, *Pp = ws + f.pp, *PI = ws + f.pi, *PO = ws + f.po;
 
     const bool two_streams = wavefront_pays_lstm(p, g_cliora_wavefront) && ran_outside;
+    const bool proj3 = lstm_proj_split();
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
     float *VHo = wb + bw.vh_o, *VCo = wb + bw.vc_o, *dGo = wb + bw.dg_o, *dGco = wb + bw.dgc_o, *dStoto = wb + bw.dstot_o;
     auto outside_bwd_step = [&](int level) -> int {
@@ -221,7 +249,9 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         hipLaunchKernelGGL(lstm_cell_bwd_out<LSTM_W>, dim3(ncell), dim3((Dp / LSTM_W + 63) / 64 * 64), 0, sb, g, D, d_oh, d_oc, level == L - 1 ? nullptr : d_os, dv.use[ROLE_OUTB], dv.trow,
                            Pp, DS, PI, ldpi, p.blk_plo, p.blk_qlo, PO, ldpo, IC, OC, dGo, dGco, dPO, VHo, VCo, dStoto);
         LAUNCHOK("lstm_cell_bwd_out");
-        if (level >= 1)
+        if (level >= 1 && proj3)
+            OKR(launch_rows_direct3(sb, ws + f.w1roT3s, ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc}, StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
+        else if (level >= 1)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), ldpo, Dp, ncell, LevelRowsA{dPO, ldpo, C, g.off, g.Lc},
                                    StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == L - 1) {
@@ -241,7 +271,9 @@ extern "C" int cliora_lstm_backward(cliora_plan* plan, const cliora_params* P, c
         hipLaunchKernelGGL(lstm_cell_bwd_in<LSTM_W>, dim3(ncell), dim3((Dp / LSTM_W + 63) / 64 * 64), 0, sa, g, D, d_ih, d_ic, level == 0 ? nullptr : d_is, dv.use[ROLE_INA], dv.use[ROLE_INB],
                            dv.use[ROLE_OUTA], ran_outside, dv.trow, Pp, DS, PI, ldpi, p.blk_plo, p.blk_qlo, PO, ldpo, IH, IC, OH, OC, dG, dGc, dGo, dGco, dPI, VH, VC, dStot);
         LAUNCHOK("lstm_cell_bwd_in");
-        if (level <= L - 2)
+        if (level <= L - 2 && proj3)
+            OKR(launch_rows_direct3(sa, ws + f.wcatT3s, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc}, StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
+        else if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                                    StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (level == 0) return CLIORA_OK;

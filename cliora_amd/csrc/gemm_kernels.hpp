@@ -589,6 +589,99 @@ static __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __re
 
 
 // ---------------------------------------------------------------------------------
+// rows_gemm_ksplit3 (round 4): rows_gemm_ksplit on split-bf16 operands (three v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate:
+// the arithmetic of the compose GEMMs) for the TreeLSTM's per-cell gate projections and their backward -- 10 of its 11 projection
+// blocks feed sigmoid / tanh gates, not scores: [cells x 400] x [400 x 4000] per level on the fp32-input MFMA was 40 % of the c5
+// step.  A 32-deep k-step of a 16 x 16 tile is 48 MFMA cycles instead of 256, so a workgroup owns 16 rows x 80 columns.
+// Weights: frag_weight_image3 -- per (column tile, k-step) the 64 lanes' hi registers (1 KiB) then their lo registers, k in the
+// operand order of split_weight_image, zero beyond K.  (Measured NOT to pay for DioraMLP's K = 1200 backward GEMM, which is
+// ingest-bound at its size: profiles/r04_notes.md.)  Score projections (QL) stay on exact fp32 products.
+// ---------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void frag_weight_image3(SplitImageTab tab) {
+    const int m = blockIdx.z;
+    const int K = tab.K[m], nst = (K + 31) >> 5;
+    const size_t n = (size_t)(tab.nrows[m] >> 4) * nst * 512;      // dwords: 16 columns x 32 k per (tile, step)
+    uint32_t* img = tab.dst[m];
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int q = (int)(e & 3), lane = (int)((e >> 2) & 63), plane = (int)((e >> 8) & 1);
+        const size_t blk = e >> 9;
+        const int st = (int)(blk % nst), ct = (int)(blk / nst);
+        const int g = lane >> 4;
+        const int k0 = 32 * st + 4 * g + (q < 2 ? 2 * q : 16 + 2 * (q - 2));
+        const float* src = tab.src[m] + (size_t)(ct * 16 + (lane & 15)) * tab.ldw[m];
+        const float v0 = k0 < K ? src[k0] : 0.f, v1 = k0 + 1 < K ? src[k0 + 1] : 0.f;
+        const uint32_t h = pack_bf16(v0, v1);
+        img[e] = plane == 0 ? h : pack_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+    }
+}
+
+template <int CT, class AProd, class Epi>
+static __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* __restrict__ Wimg, int K, int nrg, int nrgp, int nrows,
+                                                         AProd ap, Epi epi) {
+    __shared__ float4 part[4][CT][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;   // row group fastest (XCD L2 reuse of the rows)
+    if (rg >= nrg) return;
+    const int col0 = cb * (CT * 16);
+    const int nst = (K + 31) >> 5;
+    const int sbase = nst / 4, srem = nst % 4;
+    const int s0 = wave * sbase + min(wave, srem);
+    const int ns = sbase + (wave < srem ? 1 : 0);
+    using Ctx = decltype(ap.row(0));
+    const Ctx ctx = ap.row(min(rg * 16 + li, nrows - 1));
+    const u32x4* wfrag = reinterpret_cast<const u32x4*>(Wimg) + ((size_t)(cb * CT) * nst) * 128 + lane;
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int PD = 3;
+    float4 ra[PD][2];
+    u32x4 rh[PD][CT], rl[PD][CT];
+    auto load = [&](int slot, int s) {
+        const int st = s0 + s;
+        const int k = 32 * st + 4 * lq;
+        ra[slot][0] = ap.finish(ctx, ap.fetch(ctx, k));
+        ra[slot][1] = 32 * st + 16 < K ? ap.finish(ctx, ap.fetch(ctx, k + 16)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            rh[slot][c] = wfrag[((size_t)c * nst + st) * 128];
+            rl[slot][c] = wfrag[((size_t)c * nst + st) * 128 + 64];
+        }
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl)
+        if (sl < ns) load(sl, sl);
+    for (int base = 0; base < ns; base += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+            if (base + sl < ns) {
+                u32x4 xh, xl;
+                split_bf16x8(to_mfma_lanes(psrc, ra[sl][0]), to_mfma_lanes(psrc, ra[sl][1]), xh, xl);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(rl[sl][c], xh, acc[c]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(rh[sl][c], xl, acc[c]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = mfma32bf(rh[sl][c], xh, acc[c]);
+                if (base + sl + PD < ns) load(sl, base + sl + PD);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) part[wave][c][lane] = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    __syncthreads();
+    for (int t = wave; t < CT; t += 4) {                 // fixed summation order over the four k-slices
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                     ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        const int row = rg * 16 + i;
+        if (row < nrows) epi.store4(epi.row(row), col0 + t * 16 + 4 * q, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // tn_gemm:  C[i][j] = sum_r A(r,i) B(r,j),  i < Mi, j < Nj  (both multiples of 16*T)
 //   grid.x = (Mi/(TI*16)) * (Nj/(TJ*16)) blocks of C; grid.y*4 + wave = row slice.
 //   AProd/BProd: Ctx row(int r) const; float val(const Ctx&, int col) const;

@@ -40,6 +40,7 @@ struct FwdLayout {
     size_t w2i3, w2iT3, w2o3, w2oT3;    // split-bf16 LDS images of the four (Dp rows x S3 dwords each; see split_weight_image)
     int Kp3, S3;                        // image geometry for K = Dp: k rounded up to 32, row stride in dwords
     size_t wl3, wlT3, wcat3, wcatT3, w1ro3, w1roT3;   // images of the leaf / projection weights and their transposes
+    size_t wcat3s, wcatT3s, w1ro3s, w1roT3s;          // TreeLSTM: split-bf16 fragment images of the projection weights (rows_gemm_ksplit3)
     size_t rootp;                       // root vector, padded
     size_t rootw, rootwT, rootw3, rootwT3, rootpb;   // compress = True (diora.py:342-343): root_mat_out^T / root_mat_out (padded), their fragment images, per-sentence root rows (B x Dp)
     size_t matp, matq3, qrleaf;         // inside score matrix padded (Dp x Dp), its fragment image, and QR = M h of the leaves (B*L x Dp)
