@@ -16,6 +16,7 @@
 #include "../../include/cliora_chart.h"
 #include "chart_kernels.hpp"
 #include "gemm_kernels.hpp"
+#include "wgrad_tiles.hpp"
 #include "plan.hpp"
 
 using namespace cliora;
@@ -418,6 +419,45 @@ static int launch_tn_level_block(hipStream_t st, const float* A, int lda, int ac
     hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, A + acol0, lda, Bm, Dp, nrows, rps, nsl, Dp, Dp,
                        nkb, slab, csl, 0x7fffffff, 0, 0LL, hi, C, off);
     LAUNCHOK("tn_gemm_dma3x(level rows)");
+    launch_slab_reduce(st, slab, nsl, (size_t)Dp * Dp, out, accumulate, csl, (size_t)Dp, colsum_out);
+    LAUNCHOK("slab_reduce");
+    return CLIORA_OK;
+}
+
+// The pair rows' weight gradient from the TILED split-bf16 operands (wgrad_tiles.hpp): tiles [tile0, tile0 + ntiles) and, in the same
+// launch, [tile0b, tile0b + ntilesb).  Only where pair_tiles_ok(Dp).
+static bool pair_tiles_ok(int Dp) {
+    static const bool off = [] { const char* e = getenv("CLIORA_PAIR_TILES"); return e && atoi(e) == 0; }();
+    return !off && split_bf16() && Dp == 400;      // the <7, 9, 5> instance and level_compose_bwd's <5, 25> instance
+}
+static int launch_tn_tiles(hipStream_t st, const float* DZt, const float* Xt, long long tile0, long long ntiles, long long tile0b, long long ntilesb,
+                           int Dp, float* slab, size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap) {
+    const int NT = Dp / 16;
+    const long long nt = ntiles + ntilesb;
+    if (nt <= 0) {
+        if (accumulate) return CLIORA_OK;
+        HIPOK(hipMemsetAsync(out, 0, (size_t)Dp * Dp * sizeof(float), st));
+        if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
+        return CLIORA_OK;
+    }
+    constexpr int NTc = 25, NIT = 7, NJT = 9, NJW = 5, nkb = 3;      // d = 400 (pair_tiles_ok)
+    if (NT != NTc) return fail(CLIORA_EINVAL, "tiled pair-row operands: d = 400 only");
+    const size_t per_slice = (size_t)Dp * Dp + Dp;
+    long long cap = std::min<long long>((long long)(slab_floats / per_slice), slices_cap > 0 ? slices_cap : std::max(1, 230 / (8 * nkb)) * 8);
+    cap = std::max<long long>(2, std::min(cap, (nt + 3) / 4));
+    long long tps = (nt + cap - 1) / cap;
+    tps = (tps + 1) / 2 * 2;                                   // whole stages (two tiles)
+    long long s1 = (ntiles + tps - 1) / tps, s2 = (ntilesb + tps - 1) / tps;
+    while (s1 + s2 > cap) { tps += 2; s1 = (ntiles + tps - 1) / tps; s2 = (ntilesb + tps - 1) / tps; }
+    const int nsl = (int)(s1 + s2);
+    float* csl = slab + (size_t)nsl * Dp * Dp;
+    const size_t lds = (size_t)2 * 2048 * (NT + NJT) + 1024;  // two stage buffers + the spare KiB the last X slot reads into
+    // the next stage's LDS-DMA: 1 = all of it right behind the barrier, 0 = two pieces beside each row tile's MFMAs
+    static const int issue_mode = [] { const char* e = getenv("CLIORA_TILES_ISSUE"); return e ? atoi(e) : 1; }();
+    OKR(cliora_ensure_max_lds((const void*)tn_gemm_tiles<NTc, NIT, NJT, NJW, true>));
+    hipLaunchKernelGGL((tn_gemm_tiles<NTc, NIT, NJT, NJW, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds, st, reinterpret_cast<const uint32_t*>(DZt),
+                       reinterpret_cast<const uint32_t*>(Xt), tile0, (int)ntiles, (int)tps, nsl, nkb, slab, csl, (int)s1, tile0b, (int)ntilesb, issue_mode);
+    LAUNCHOK("tn_gemm_tiles");
     launch_slab_reduce(st, slab, nsl, (size_t)Dp * Dp, out, accumulate, csl, (size_t)Dp, colsum_out);
     LAUNCHOK("slab_reduce");
     return CLIORA_OK;

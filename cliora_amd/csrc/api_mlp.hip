@@ -119,17 +119,17 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
 #undef LC_ARGS
 }
 
-template <int CT, int K16, bool F32>
+template <int CT, int K16, bool F32, bool TILED = false>
 static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* dG,
                                          const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB, int ldb, const float* b2,
                                          float* DA, float* DZ, float* X, float* DPP, float* DPB, int cus) {
-    OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32>));
+    OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32, TILED>));
     const int ntiles = (lv.ncell + 15) / 16 * lv.N;
     const int cap = std::max(1, cus / ncb);
     const int passes = (ntiles + 8 * cap - 1) / (8 * cap);
     int gx = (ntiles + 8 * passes - 1) / (8 * passes);
     if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;      // column blocks of the same tiles on one XCD
-    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false) + (size_t)((K + 31) / 32 * 32) * sizeof(float), st, Wimg, S, K, lv, dG, ymask,
+    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32, TILED>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false) + (size_t)((K + 31) / 32 * 32) * sizeof(float), st, Wimg, S, K, lv, dG, ymask,
                        Pp, PA, lda, PB, ldb, b2, K, DA, DZ, X, DPP, DPB);
     LAUNCHOK("level_compose_bwd");
     return CLIORA_OK;
@@ -138,9 +138,14 @@ static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, i
 // backward of the level's compose layer: DA, DZ, X rows and the partial dG.y_n (see level_compose_bwd).  WT: plain fp32 W2^T.
 static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float* WTimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
                                     const float* dG, const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB,
-                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB, int cus = 256) {
+                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB, bool tiled = false, int cus = 256) {
     if (lv.N <= 0 || lv.ncell <= 0) return CLIORA_OK;
     const bool f32 = !split_bf16();
+    if (tiled) {         // X, DZ as tiled split-bf16 operands of tn_gemm_tiles (pair_tiles_ok: d = 400, split mode)
+        if (f32 || ct != 5 || Dp != 400) return fail(CLIORA_EINVAL, "tiled pair-row operands: d = 400 in split-bf16 mode only");
+        return launch_level_compose_bwd_inst<5, 25, false, true>(st, reinterpret_cast<const uint32_t*>(WTimg), S3, Dp, ncb, lv, dG, ymask, Pp, PA, lda,
+                                                                   PB, ldb, b2, DA, DZ, X, DPP, DPB, cus);
+    }
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? WT : WTimg);
     const int S = f32 ? Dp : S3;
 #define LB_ARGS st, I, S, Dp, ncb, lv, dG, ymask, Pp, PA, lda, PB, ldb, b2, DA, DZ, X, DPP, DPB, cus
@@ -412,6 +417,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         lv.pa = t + (outside_pass ? p.dev.pair_a_out : p.dev.pair_a_in) + base;
         lv.pb = t + (outside_pass ? p.dev.pair_b_out : p.dev.pair_b_in) + base;
         lv.Lc = g.Lc; lv.N = g.N; lv.C = C; lv.ncell = B * g.Lc; lv.rowbase = g.rowbase; lv.off = g.off;
+        lv.tilebase = outside_pass ? p.tile_base_out(level) : p.tile_base_in(level);
         return lv;
     };
 
@@ -667,6 +673,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         lv.pa = t + (outside_pass ? p.dev.pair_a_out : p.dev.pair_a_in) + base;
         lv.pb = t + (outside_pass ? p.dev.pair_b_out : p.dev.pair_b_in) + base;
         lv.Lc = g.Lc; lv.N = g.N; lv.C = C; lv.ncell = B * g.Lc; lv.rowbase = g.rowbase; lv.off = g.off;
+        lv.tilebase = outside_pass ? p.tile_base_out(level) : p.tile_base_in(level);
         return lv;
     };
     const float* OBJ = vl ? (padded ? ws + f.objp : obj_span) : nullptr;
@@ -690,6 +697,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // (CLIORA normalises around the attention residual; compress keeps per-sentence root gradients in dGo).  CLIORA_FUSE_DNORM=0: off.
     static const bool fuse_off = [] { const char* e = getenv("CLIORA_FUSE_DNORM"); return e && atoi(e) == 0; }();
     const bool fuse_dnorm = !fuse_off && !vl && !compress && !resident;
+    // X / DZ of the pair rows as tiled split-bf16 operands (wgrad_tiles.hpp) instead of fp32 rows.  CLIORA_PAIR_TILES=0: off.
+    const bool tiled = pair_tiles_ok(Dp) && !resident;
 
     // Sibling uses of inside level s in the outside pass (cell_gather_bwd_sib), on the OUTSIDE chain's stream: they are complete once
     // the outside backward has done level L-2-s, one step before the inside chain reaches level s (which already waits for that
@@ -744,7 +753,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sb);
             OKR(launch_level_compose_bwd(sb, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dGo, YM, Pp,
-                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB));
+                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB, tiled));
         }
         hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
         LAUNCHOK("cell_dsoftmax(out)");
@@ -826,7 +835,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sa);
             OKR(launch_level_compose_bwd(sa, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
-                                         PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB));
+                                         PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB, tiled));
         }
         hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
         LAUNCHOK("cell_dsoftmax(in)");
@@ -870,7 +879,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const int early_auto = L >= 16 ? L / 2 + 1 : -1;
     const int early_pick = early_env == -2 ? early_auto : early_env;
     const int J_early = (p.share && ran_outside && !compress && !resident && early_pick >= 0 && early_pick <= L - 3) ? early_pick : -1;
-    long long early_r0 = 0, early_r1 = 0;
+    long long early_r0 = 0, early_r1 = 0, early_t0 = 0, early_t1 = 0;       // ... as pair rows and as 16-row tiles
     if (resident) {
         // ---- both chains and the leaves' pre-activation gradient: one workgroup per sentence (resident_kernels.hpp) ----
         ResArgs a = resident_args(plan, ws, const_cast<float*>(IH), const_cast<float*>(OH), const_cast<float*>(IS), const_cast<float*>(OS), ran_outside);
@@ -903,8 +912,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
             if (two_streams) HIPOK(hipStreamWaitEvent(sw, plan->ev_level[j], 0));
-            OKR(launch_tn_pairs(sw, DZ + (size_t)early_r0 * Dp, Xp + (size_t)early_r0 * Dp, (int)(early_r1 - early_r0), Dp, wb + bw.slab2, bw.slab_floats,
-                                wb + bw.gw2o, wb + bw.gb2o, 0, early_slices));
+            early_t0 = p.tile_base_in(L - 1 - j);
+            early_t1 = p.tile_base_out(j + 1);
+            if (tiled)
+                OKR(launch_tn_tiles(sw, DZ, Xp, early_t0, early_t1 - early_t0, 0, 0, Dp, wb + bw.slab2, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o, 0,
+                                    early_slices));
+            else
+                OKR(launch_tn_pairs(sw, DZ + (size_t)early_r0 * Dp, Xp + (size_t)early_r0 * Dp, (int)(early_r1 - early_r0), Dp, wb + bw.slab2, bw.slab_floats,
+                                    wb + bw.gw2o, wb + bw.gb2o, 0, early_slices));
         }
     }
     // leaves
@@ -923,6 +938,18 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // inside chain's last gather, projection backward and leaf layer instead of after them.  One stream: on the caller's stream, last.
     auto pair_rows_tail = [&](hipStream_t s_) -> int {
         ProfScope ps(CLIORA_KCLASS_WGRAD, s_);
+        if (tiled) {
+            if (ran_outside && !p.share)
+                OKR(launch_tn_tiles(s_, DZ, Xp, p.T_in, p.T_out, 0, 0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o, 0, 0));
+            const long long ntl = (p.share && ran_outside) ? p.T_in + p.T_out : p.T_in;
+            static const int tail_slices2 = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES2"); return e ? atoi(e) : 72; }();
+            if (J_early >= 0)
+                OKR(launch_tn_tiles(s_, DZ, Xp, 0, early_t0, early_t1, ntl - early_t1, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0,
+                                    tail_slices2));
+            else
+                OKR(launch_tn_tiles(s_, DZ, Xp, 0, ntl, 0, 0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0, 0));
+            return CLIORA_OK;
+        }
         if (ran_outside && !p.share)
             OKR(launch_tn_pairs(s_, DZ + (size_t)p.R_in * Dp, Xp + (size_t)p.R_in * Dp, (int)p.R_out, Dp, wb + bw.slab, bw.slab_floats,
                                 wb + bw.gw2o, wb + bw.gb2o));

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "chart_kernels.hpp"
+#include "wgrad_tiles.hpp"
 
 namespace cliora {
 
@@ -32,6 +33,7 @@ struct PairLevel {
     int Lc, N, C, ncell;      // cells per sentence at the level, splits per cell, cells per chart, B*Lc
     int rowbase;              // global pair row of (t, n) = rowbase + t*N + n, t = b*Lc + p
     int off;                  // chart offset of the level: chart row of t = b*C + off + p
+    long long tilebase;       // level_compose_bwd, tiled operands: storage tile of the level's wave tile 0 (Plan::tile_base_*)
 };
 
 constexpr int LC_SLOTS = 4;   // LDS slots of the cross-wave reduction (one per writer of a round)
@@ -546,7 +548,9 @@ static __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, in
 //                                -- the softmax backward gets its dp_n without y_n (cell_dsoftmax)
 // Tiles are independent here (no reduction over the splits): waves walk the level's tiles (g-major) with a stride.
 // ---------------------------------------------------------------------------------
-template <int CT, int K16, bool F32>
+// TILED: X and DZ leave as 16-row tiles of bf16 hi / lo planes (wgrad_tiles.hpp: the operand image of tn_gemm_tiles; storage tile =
+// lv.tilebase + the wave tile's index; rows past the level's last cell are zeros) instead of fp32 rows.
+template <int CT, int K16, bool F32, bool TILED = false>
 __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
                                                          const float* __restrict__ dG, const uint32_t* __restrict__ ymask,
                                                          const float* __restrict__ Pp, const float* __restrict__ PA, int lda,
@@ -579,11 +583,15 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
     const int stride = gridDim.x * WAVES;
 
     struct Ctx { const float* gp; const uint32_t* mp; float* zo; float pn; float* bo; };
+    const int NT = Dp >> 4;
     auto rowctx = [&](int tile) {                    // fetch-lane view of tile = gt * N + n
         const int gt = tile / lv.N, n = tile - gt * lv.N;
         const int t = min(gt * 16 + li, lv.ncell - 1);
         const int b = t / lv.Lc, p = t - b * lv.Lc;
         const size_t prow = (size_t)lv.rowbase + (size_t)t * lv.N + n;
+        if (TILED)       // the lane's 8 bytes of the tile's hi planes (row li, columns 4 lg ..): lane-linear; zero rows past the last cell
+            return Ctx{dG + ((size_t)b * lv.C + lv.off + p) * Dp, ymask + prow * gy * 4 + lg,
+                       DZ + (size_t)(lv.tilebase + tile) * NT * 256 + 2 * lane, gt * 16 + li < lv.ncell ? Pp[prow] : 0.f, DPB + prow};
         return Ctx{dG + ((size_t)b * lv.C + lv.off + p) * Dp, ymask + prow * gy * 4 + lg, DZ + prow * Dp, Pp[prow], DPB + prow};
     };
     struct Slot { float4 g0, g1; uint32_t m0, m1; };
@@ -641,8 +649,14 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
             const float4 f1 = masked(q.g1, q.m1 >> (4 * ((2 * st + (second ? 1 : 0)) % CT)));
             const int k = 32 * st + 4 * lg;
             if (st % gy == by) {
-                st4(ctx.zo + k, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
-                if (second) st4(ctx.zo + k + 16, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
+                if (TILED) {
+                    uint32_t* zt = reinterpret_cast<uint32_t*>(ctx.zo) + (2 * st) * 256;
+                    store_split_tile(zt, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
+                    if (second) store_split_tile(zt + 256, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
+                } else {
+                    st4(ctx.zo + k, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
+                    if (second) st4(ctx.zo + k + 16, make_float4(ctx.pn * f1.x, ctx.pn * f1.y, ctx.pn * f1.z, ctx.pn * f1.w));
+                }
             }
             if (by == 0) {
                 bdot += f4dot(f0, *reinterpret_cast<const float4*>(b2s + k));
@@ -686,8 +700,11 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
                 const size_t o = prow * Dp + col0 + c * 16 + 4 * g;
                 st4(DA + o, make_float4(x.x > 0.f ? pn * acc[c][0] : 0.f, x.y > 0.f ? pn * acc[c][1] : 0.f,
                                         x.z > 0.f ? pn * acc[c][2] : 0.f, x.w > 0.f ? pn * acc[c][3] : 0.f));
-                st4(X + o, x);
+                if (!TILED) st4(X + o, x);
             }
+            if (TILED)
+                store_split_tile(reinterpret_cast<uint32_t*>(X) + ((size_t)(lv.tilebase + tile) * NT + by * CT + c) * 256 + 8 * i + 2 * g,
+                                 ok ? x : f4zero());
         }
         dp += __shfl_xor(dp, 16);
         dp += __shfl_xor(dp, 32);

@@ -71,6 +71,13 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
     p.R_in = (long long)B * p.P_in;
     p.R_out = (long long)B * p.P_out;
     if (p.R_in + p.R_out > 0x7fffffffLL / 2) return "batch too large for 32-bit pair rows";
+    p.tile_base_in_.assign(L + 1, 0); p.tile_base_out_.assign(L + 1, 0);
+    for (int lv = 0; lv < L; ++lv) {
+        const long long g16 = ((long long)B * (L - lv) + 15) / 16;
+        p.tile_base_in_[lv + 1] = p.tile_base_in_[lv] + g16 * lv;
+        p.tile_base_out_[lv + 1] = p.tile_base_out_[lv] + g16 * (L - lv - 1);
+    }
+    p.T_in = p.tile_base_in_[L]; p.T_out = p.tile_base_out_[L];
 
     const int C = p.C;
     p.level_offset.resize(L);
@@ -217,8 +224,10 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         b.vc_o = take(lstm * BC * Dp); b.dgc_o = take(lstm * BC * Dp);
         // TreeLSTM keeps no per-pair gradient rows: its cell-centric backward recomputes them per use (lstm_kernels.hpp)
         b.da = take(lstm ? 0 : Rt * Dp); b.ds = take(Rt);
-        b.dz = take(lstm ? 0 : Rt * Dp);
-        b.x = take(arch == 0 ? Rt * Dp : 0);
+        // (DioraMLP: both also hold the tiled form, whole 16-row tiles per level and split)
+        const size_t Rtile = std::max(Rt, (size_t)(p.T_in + p.T_out) * 16);
+        b.dz = take(lstm ? 0 : Rtile * Dp);
+        b.x = take(arch == 0 ? Rtile * Dp : 0);
         b.dpp = take(arch == 0 ? Rt * p.fwd.ncb3 : 0);
         b.dpb = take(arch == 0 ? Rt : 0);
         b.dcb = take(0); b.vc = take(lstm * BC * Dp); b.dgc = take(lstm * BC * Dp); b.grootc = take(lstm * Dp);

@@ -119,6 +119,13 @@ struct Plan {
     int Nout(int level) const { return L - level - 1; }
     long long row_base_in(int level) const { return (long long)B * lvl_base_in[level]; }
     long long row_base_out(int level) const { return R_in + (long long)B * lvl_base_out[level]; }
+    // The pair rows as 16-row tiles (one tile = 16 target cells of one level x one split: a wave tile of level_compose_bwd), in the
+    // pair rows' order (inside levels, then outside levels): the storage unit of the tiled split-bf16 operands of the pair rows'
+    // weight gradient (gemm_kernels.hpp: tn_gemm_tiles).  A level with B * Lc not a multiple of 16 carries zero rows in its last tiles.
+    std::vector<long long> tile_base_in_, tile_base_out_;      // L + 1 each (the last entry: the pass's end)
+    long long T_in = 0, T_out = 0;
+    long long tile_base_in(int level) const { return tile_base_in_[level]; }
+    long long tile_base_out(int level) const { return T_in + tile_base_out_[level]; }
 };
 
 // Tasks of level_compose_fwd for a level of `ncell` target cells with N splits each: TG cell tiles per workgroup (8 / TG waves
