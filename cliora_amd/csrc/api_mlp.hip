@@ -119,17 +119,17 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
 #undef LC_ARGS
 }
 
-template <int CT, int K16, bool F32, bool TILED = false, bool FROMDZ = false>
+template <int CT, int K16, bool F32, bool TILED = false>
 static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, int S, int K, int ncb, const PairLevel& lv, const float* dG,
                                          const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB, int ldb, const float* b2,
                                          float* DA, float* DZ, float* X, float* DPP, float* DPB, int cus) {
-    OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32, TILED, FROMDZ>));
+    OKR(cliora_ensure_max_lds((const void*)level_compose_bwd<CT, K16, F32, TILED>));
     const int ntiles = (lv.ncell + 15) / 16 * lv.N;
     const int cap = std::max(1, cus / ncb);
     const int passes = (ntiles + 8 * cap - 1) / (8 * cap);
     int gx = (ntiles + 8 * passes - 1) / (8 * passes);
     if (gx >= 8 && (gx + 7) / 8 * 8 <= cap) gx = (gx + 7) / 8 * 8;      // column blocks of the same tiles on one XCD
-    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32, TILED, FROMDZ>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false) + (size_t)((K + 31) / 32 * 32) * sizeof(float), st, Wimg, S, K, lv, dG, ymask,
+    hipLaunchKernelGGL((level_compose_bwd<CT, K16, F32, TILED>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, false) + (size_t)((K + 31) / 32 * 32) * sizeof(float), st, Wimg, S, K, lv, dG, ymask,
                        Pp, PA, lda, PB, ldb, b2, K, DA, DZ, X, DPP, DPB);
     LAUNCHOK("level_compose_bwd");
     return CLIORA_OK;
@@ -138,14 +138,11 @@ static int launch_level_compose_bwd_inst(hipStream_t st, const uint32_t* Wimg, i
 // backward of the level's compose layer: DA, DZ, X rows and the partial dG.y_n (see level_compose_bwd).  WT: plain fp32 W2^T.
 static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float* WTimg, int S3, int Dp, int ct, int ncb, const PairLevel& lv,
                                     const float* dG, const uint32_t* ymask, const float* Pp, const float* PA, int lda, const float* PB,
-                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB, bool tiled = false, bool fromdz = false, int cus = 256) {
+                                    int ldb, const float* b2, float* DA, float* DZ, float* X, float* DPP, float* DPB, bool tiled = false, int cus = 256) {
     if (lv.N <= 0 || lv.ncell <= 0) return CLIORA_OK;
     const bool f32 = !split_bf16();
     if (tiled) {         // X, DZ as tiled split-bf16 operands of tn_gemm_tiles (pair_tiles_ok: d = 400, split mode)
         if (f32 || ct != 5 || Dp != 400) return fail(CLIORA_EINVAL, "tiled pair-row operands: d = 400 in split-bf16 mode only");
-        if (fromdz)      // ... and DZ is already there (NormBwdPairsE)
-            return launch_level_compose_bwd_inst<5, 25, false, true, true>(st, reinterpret_cast<const uint32_t*>(WTimg), S3, Dp, ncb, lv, dG, ymask, Pp,
-                                                                             PA, lda, PB, ldb, b2, DA, DZ, X, DPP, DPB, cus);
         return launch_level_compose_bwd_inst<5, 25, false, true>(st, reinterpret_cast<const uint32_t*>(WTimg), S3, Dp, ncb, lv, dG, ymask, Pp, PA, lda,
                                                                    PB, ldb, b2, DA, DZ, X, DPP, DPB, cus);
     }
@@ -702,16 +699,6 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const bool fuse_dnorm = !fuse_off && !vl && !compress && !resident;
     // X / DZ of the pair rows as tiled split-bf16 operands (wgrad_tiles.hpp) instead of fp32 rows.  CLIORA_PAIR_TILES=0: off.
     const bool tiled = pair_tiles_ok(Dp) && !resident;
-    // ... and DZ formed once per pair row in the epilogue of the cells' projection-backward GEMM (NormBwdPairsE) instead of once per column
-    // block inside level_compose_bwd, on the levels whose unit-norm backward rides in that epilogue.  CLIORA_DZ_EPILOGUE=0: off.
-    static const bool dz_epi_off = [] { const char* e = getenv("CLIORA_DZ_EPILOGUE"); return e && atoi(e) == 0; }();
-    const bool dz_epilogue = tiled && !dz_epi_off;
-    auto pairs_epilogue = [&](const NormBwdLevelE& nb, const PairLevel& lv) {
-        NormBwdPairsE e;
-        e.nb = nb; e.Pp = Pp; e.ymask = YM; e.DZt = reinterpret_cast<uint32_t*>(DZ);
-        e.N = lv.N; e.rowbase = lv.rowbase; e.gy = f.ncb3; e.ct3 = f.ct3; e.NT = Dp / 16; e.G = (lv.ncell + 15) / 16; e.tilebase = lv.tilebase;
-        return e;
-    };
 
     // Sibling uses of inside level s in the outside pass (cell_gather_bwd_sib), on the OUTSIDE chain's stream: they are complete once
     // the outside backward has done level L-2-s, one step before the inside chain reaches level s (which already waits for that
@@ -743,11 +730,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VHo, dStoto,
                            OH, ws + f.po, fused_norm ? wb + bw.dots_o : nullptr);
         LAUNCHOK("cell_gather_bwd_out");
-        const bool from_dz = fused_norm && dz_epilogue;
-        if (from_dz)
-            OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
-                            pairs_epilogue(NormBwdLevelE{dGo, VHo, OH, ws + f.nrmo, wb + bw.dots_o, Dp, C, g.off, g.Lc, p.normalize}, pair_level(level, true))));
-        else if (fused_norm)
+        if (fused_norm)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                             NormBwdLevelE{dGo, VHo, OH, ws + f.nrmo, wb + bw.dots_o, Dp, C, g.off, g.Lc, p.normalize}));
         else if (level >= 1)
@@ -770,9 +753,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sb);
             OKR(launch_level_compose_bwd(sb, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dGo, YM, Pp,
-                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB, tiled, from_dz));
+                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB, tiled));
         }
-        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS, from_dz ? 1 : 0);
+        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
         LAUNCHOK("cell_dsoftmax(out)");
         OKR(sibling_gather(L - 2 - level));      // the inside level whose sibling uses are final with this outside level
         return CLIORA_OK;
@@ -822,11 +805,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             dpi_done_recorded = true;
         }
-        const bool from_dz = fused_norm && dz_epilogue;
-        if (from_dz)
-            OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
-                            pairs_epilogue(NormBwdLevelE{dG, VH, IH, ws + f.nrmi, wb + bw.dots, Dp, C, g.off, g.Lc, p.normalize}, pair_level(level, false))));
-        else if (fused_norm)
+        if (fused_norm)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             NormBwdLevelE{dG, VH, IH, ws + f.nrmi, wb + bw.dots, Dp, C, g.off, g.Lc, p.normalize}));
         else if (level <= L - 2)
@@ -856,9 +835,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sa);
             OKR(launch_level_compose_bwd(sa, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
-                                         PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB, tiled, from_dz));
+                                         PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB, tiled));
         }
-        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS, from_dz ? 1 : 0);
+        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
         LAUNCHOK("cell_dsoftmax(in)");
         if (level == 1 && two_streams) HIPOK(hipEventRecord(plan->ev_join[2], sa));     // the last pair rows (DZ, X) are final
         return CLIORA_OK;

@@ -14,7 +14,6 @@
 #include <stdint.h>
 
 #include "gemm_kernels.hpp"
-#include "wgrad_tiles.hpp"
 
 namespace cliora {
 
@@ -573,45 +572,6 @@ struct NormBwdLevelE {
         st4(rc.o + col, make_float4(((v.x + g.x) - h.x * rc.dot) * rc.inv, ((v.y + g.y) - h.y * rc.dot) * rc.inv,
                                     ((v.z + g.z) - h.z * rc.dot) * rc.inv, ((v.w + g.w) - h.w * rc.dot) * rc.inv));
     }
-};
-
-// NormBwdLevelE + the level's pair rows of DZ (round 4): with dG of a cell in registers, the epilogue also leaves, for each of the
-// cell's N splits, DZ = p_n * (dG masked by the ReLU bits of y_n) as tiled split-bf16 rows (wgrad_tiles.hpp) -- the row operand of
-// level_compose_bwd's GEMM and the A operand of the weight gradient.  level_compose_bwd formed that operand itself, once per COLUMN
-// BLOCK (five times per pair row: gather of the dG row, mask, scale, lane exchange, bf16 split -- more VALU cycles per k-step than
-// the step's MFMAs); here it is formed once, and the compose kernel's k-loop loads finished operand registers.
-// Rows of the level's last 16-row tile past its last cell are stored as zeros (pad4).
-struct NormBwdPairsE {
-    static constexpr bool kPad = true;
-    NormBwdLevelE nb;
-    const float* Pp; const uint32_t* ymask; uint32_t* DZt;
-    int N, rowbase, gy, ct3, NT, G; long long tilebase;          // G: 16-row tiles of the level
-    struct RCtx { NormBwdLevelE::RCtx c; int r; };
-    __device__ RCtx row(int r) const { return RCtx{nb.row(r), r}; }
-    __device__ void pairs(int r, int col, bool valid, float4 d, int n0, int nstep) const {
-        if ((r >> 4) >= G) return;             // a row tile of the GEMM's last block beyond the level's tiles
-        const int q = (col & 15) >> 2, blk = col / (ct3 * 16), sh = 4 * ((col - blk * ct3 * 16) >> 4);
-        const size_t prow0 = (size_t)rowbase + (size_t)r * N;
-        uint32_t* dst = DZt + ((size_t)(tilebase + (long long)(r >> 4) * N) * NT + (col >> 4)) * 256 + (r & 15) * 8 + q * 2;
-        for (int n = n0; n < N; n += nstep) {
-            float4 v = f4zero();
-            if (valid) {
-                const float pn = Pp[prow0 + n];
-                const uint32_t nib = ymask[(prow0 + n) * gy * 4 + blk * 4 + q] >> sh;
-                v = make_float4((nib & 1u) ? pn * d.x : 0.f, (nib & 2u) ? pn * d.y : 0.f, (nib & 4u) ? pn * d.z : 0.f, (nib & 8u) ? pn * d.w : 0.f);
-            }
-            store_split_tile(dst + (size_t)n * NT * 256, v);
-        }
-    }
-    // share `part` of `nparts` of the row's splits (the first share also stores dG itself)
-    __device__ void store4(const RCtx& rc, int col, float4 v, int part, int nparts) const {
-        const float4 g = ld4(rc.c.v + col), h = ld4(rc.c.h + col);
-        const float4 d = make_float4(((v.x + g.x) - h.x * rc.c.dot) * rc.c.inv, ((v.y + g.y) - h.y * rc.c.dot) * rc.c.inv,
-                                     ((v.z + g.z) - h.z * rc.c.dot) * rc.c.inv, ((v.w + g.w) - h.w * rc.c.dot) * rc.c.inv);
-        if (part == 0) st4(rc.c.o + col, d);
-        pairs(rc.r, col, true, d, part, nparts);
-    }
-    __device__ void pad4(int r, int col, int part, int nparts) const { pairs(r, col, false, f4zero(), part, nparts); }
 };
 
 }  // namespace cliora

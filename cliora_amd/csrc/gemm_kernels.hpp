@@ -21,7 +21,6 @@
 // chunk; A and B use the same permutation, the sum over k is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #include <stdint.h>
 
 namespace cliora {
@@ -493,10 +492,6 @@ static __global__ __launch_bounds__(WAVES * 64) void rows_gemm_ws3(const uint32_
 // weight load is one fully used run of cache lines instead of sixteen 64-byte pieces 4*K bytes apart (the per-level
 // launches are bound by how fast ONE CU can pull its block's operands through its texture-address path).
 // ---------------------------------------------------------------------------------
-// epilogues that also want the rows of the last 16-row tile past `nrows` (Epi::kPad, pad4(row, col))
-template <class E, class = void> struct epi_pads : std::false_type {};
-template <class E> struct epi_pads<E, std::enable_if_t<E::kPad>> : std::true_type {};
-
 template <int RT, int CT, bool FRAG, class AProd, class Epi>
 static __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __restrict__ W, int K, int nrg, int nrgp, int ncolblocks, int nrows,
                                                         AProd ap, Epi epi) {
@@ -581,28 +576,14 @@ static __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __re
         for (int c = 0; c < CT; ++c)
             part[wave][r * CT + c][lane] = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
     __syncthreads();
-    if constexpr (epi_pads<Epi>::value) {
-        // an epilogue with per-row work that splits (NormBwdPairsE: a store per split of the cell): every wave sums every tile and takes
-        // the shares `wave` of 4 of that work; rows of the last tile past the last one are handed over too (pad4)
-        for (int t = 0; t < RT * CT; ++t) {
-            const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
-            const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
-                                         ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
-            const int r = t / CT, c = t - r * CT;
-            const int row = (tile0 + r) * 16 + i;
-            if (row < nrows) epi.store4(epi.row(row), col0 + c * 16 + 4 * q, v, wave, 4);
-            else epi.pad4(row, col0 + c * 16 + 4 * q, wave, 4);
-        }
-    } else {
-        // wave w finishes output tiles w, w+4, ...: fixed summation order over the four k-slices
-        for (int t = wave; t < RT * CT; t += 4) {
-            const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
-            const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
-                                         ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
-            const int r = t / CT, c = t - r * CT;
-            const int row = (tile0 + r) * 16 + i;
-            if (row < nrows) epi.store4(epi.row(row), col0 + c * 16 + 4 * q, v);
-        }
+    // wave w finishes output tiles w, w+4, ...: fixed summation order over the four k-slices
+    for (int t = wave; t < RT * CT; t += 4) {
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                     ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        const int r = t / CT, c = t - r * CT;
+        const int row = (tile0 + r) * 16 + i;
+        if (row < nrows) epi.store4(epi.row(row), col0 + c * 16 + 4 * q, v);
     }
 }
 

@@ -550,11 +550,7 @@ static __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, in
 // ---------------------------------------------------------------------------------
 // TILED: X and DZ leave as 16-row tiles of bf16 hi / lo planes (wgrad_tiles.hpp: the operand image of tn_gemm_tiles; storage tile =
 // lv.tilebase + the wave tile's index; rows past the level's last cell are zeros) instead of fp32 rows.
-// FROMDZ (with TILED): the DZ tiles are already there (NormBwdPairsE: the epilogue of the cells' projection-backward GEMM formed
-// them, p_n included) -- the k-loop loads finished operand registers from them, 8 bytes per lane, plane and column tile, and
-// carries no VALU work besides block 0's bias dot; the accumulator is p_n u, so DA needs no scaling and DPP / DPB come out as
-// p_n dp_n (cell_dsoftmax: scaled = 1).
-template <int CT, int K16, bool F32, bool TILED = false, bool FROMDZ = false>
+template <int CT, int K16, bool F32, bool TILED = false>
 __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
                                                          const float* __restrict__ dG, const uint32_t* __restrict__ ymask,
                                                          const float* __restrict__ Pp, const float* __restrict__ PA, int lda,
@@ -616,110 +612,6 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
 
     int tile = blockIdx.x * WAVES + wave;
     const bool work = tile < ntiles;
-    if constexpr (FROMDZ) {
-        static_assert(TILED && !F32, "operands from DZ tiles: the tiled split-bf16 form");
-        struct ZSlot { uint2 h0, l0, h1, l1; };
-        ZSlot rz[PD];
-        // MFMA-lane view: row i, k pieces 4g .. 4g+3 of both column tiles of a k-step = this lane's 8 bytes of their hi / lo planes
-        auto zbase = [&](int tl) { return reinterpret_cast<const uint32_t*>(DZ) + (size_t)(lv.tilebase + tl) * NT * 256 + 8 * i + 2 * g; };
-        auto zissue = [&](int slot, const uint32_t* zb, int s) {
-            const uint32_t* p0 = zb + (2 * s) * 256;
-            const bool second = 32 * s + 16 < K;
-            const uint32_t* p1 = second ? p0 + 256 : p0;
-            rz[slot].h0 = *reinterpret_cast<const uint2*>(p0); rz[slot].l0 = *reinterpret_cast<const uint2*>(p0 + 128);
-            rz[slot].h1 = *reinterpret_cast<const uint2*>(p1); rz[slot].l1 = *reinterpret_cast<const uint2*>(p1 + 128);
-        };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (!work) return;
-        const uint32_t* zb = zbase(tile);
-#pragma unroll
-        for (int sl = 0; sl < PD; ++sl) zissue(sl, zb, sl < nsteps ? sl : 0);
-        while (true) {
-            const int ntile = tile + stride;
-            const bool has_next = ntile < ntiles;
-            const uint32_t* zbn = zbase(has_next ? ntile : tile);
-            const int gt = tile / lv.N, n = tile - gt * lv.N;
-            const int ti = gt * 16 + i;
-            const bool ok = ti < lv.ncell;
-            const int tc = min(ti, lv.ncell - 1);
-            const int eb = tc / lv.Lc, ep = tc - eb * lv.Lc;
-            const size_t prow = (size_t)lv.rowbase + (size_t)tc * lv.N + n;
-            const float* xa = PA + ((size_t)eb * lv.C + lv.pa[ep * lv.N + n]) * lda + col0 + 4 * g;
-            const float* xb = PB + ((size_t)eb * lv.C + lv.pb[ep * lv.N + n]) * ldb + col0 + 4 * g;
-            float4 ea[CT], ebv[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) { ea[c] = ld4(xa + c * 16); ebv[c] = ld4(xb + c * 16); }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+v"(wimg_off));
-            const uint32_t* wimg = lds_img + wimg_off;
-            float bdot = 0.f;                       // block 0: DZ . b2 over this lane's k pieces (hi + lo of each element)
-            auto zprep = [&](int st, const ZSlot& q) {
-                const bool second = 32 * st + 16 < K;
-                StepOperand o;
-                o.h = u32x4{q.h0.x, q.h0.y, second ? q.h1.x : 0u, second ? q.h1.y : 0u};
-                o.l = u32x4{q.l0.x, q.l0.y, second ? q.l1.x : 0u, second ? q.l1.y : 0u};
-                if (by == 0) {
-                    const float* bp = b2s + 32 * st + 4 * g;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        if (d >= 2 && !second) break;
-                        const float v0 = __uint_as_float(o.h[d] << 16) + __uint_as_float(o.l[d] << 16);
-                        const float v1 = __uint_as_float(o.h[d] & 0xffff0000u) + __uint_as_float(o.l[d] & 0xffff0000u);
-                        const int k = (d < 2 ? 2 * d : 16 + 2 * (d - 2));
-                        bdot = fmaf(v0, bp[k], bdot);
-                        bdot = fmaf(v1, bp[k + 1], bdot);
-                    }
-                }
-                return o;
-            };
-            StepOperand cur = zprep(0, rz[0]);
-#pragma unroll UNROLL_STEPS
-            for (int base = 0; base < nsteps_p; base += PD) {
-#pragma unroll
-                for (int sl = 0; sl < PD; ++sl) {
-                    const int st = base + sl;
-                    if (st < nsteps) {
-                        StepOperand nxt = cur;
-                        if (st + 1 < nsteps) nxt = zprep(st + 1, rz[(sl + 1) % PD]);
-                        kstep_mfma<CT, F32>(wimg, i, g, S, half, st, 32 * st + 16 < K, cur, acc);
-                        const int nst = st + PD;
-                        const bool in_cur = nst < nsteps;
-                        zissue(sl, in_cur ? zb : zbn, in_cur ? nst : (sl < nsteps ? sl : 0));
-                        __builtin_amdgcn_sched_barrier(0);
-                        cur = nxt;
-                    }
-                }
-            }
-            if (by == 0) {                          // the four lanes of a row hold its k pieces
-                bdot += __shfl_xor(bdot, 16);
-                bdot += __shfl_xor(bdot, 32);
-                if (g == 0 && ok) DPB[prow] = bdot;
-            }
-            float dp = 0.f;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const float4 pa4 = ea[c], pb4 = ebv[c];
-                const float4 x = make_float4(fmaxf(pa4.x + pb4.x, 0.f), fmaxf(pa4.y + pb4.y, 0.f), fmaxf(pa4.z + pb4.z, 0.f), fmaxf(pa4.w + pb4.w, 0.f));
-                dp = fmaf(acc[c][0], x.x, dp); dp = fmaf(acc[c][1], x.y, dp); dp = fmaf(acc[c][2], x.z, dp); dp = fmaf(acc[c][3], x.w, dp);
-                if (ok)
-                    st4(DA + prow * Dp + col0 + c * 16 + 4 * g, make_float4(x.x > 0.f ? acc[c][0] : 0.f, x.y > 0.f ? acc[c][1] : 0.f,
-                                                                              x.z > 0.f ? acc[c][2] : 0.f, x.w > 0.f ? acc[c][3] : 0.f));
-                store_split_tile(reinterpret_cast<uint32_t*>(X) + ((size_t)(lv.tilebase + tile) * NT + by * CT + c) * 256 + 8 * i + 2 * g,
-                                 ok ? x : f4zero());
-            }
-            dp += __shfl_xor(dp, 16);
-            dp += __shfl_xor(dp, 32);
-            if (ok && g == 0) DPP[prow * gy + by] = dp;
-            if (!has_next) break;
-            zb = zbn;
-            tile = ntile;
-        }
-        return;
-    }
     Ctx ctx = rowctx(work ? tile : 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -848,7 +740,7 @@ static __global__ __launch_bounds__(256) void cell_dnorm(LevelArgs g, const floa
 static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb, const float* __restrict__ DPP, const float* __restrict__ DPB,
                                                             const float* __restrict__ Sp, const float* __restrict__ Pp,
                                                             const float* __restrict__ Schart, const float* __restrict__ dStot,
-                                                            float* __restrict__ DS, int scaled = 0) {
+                                                            float* __restrict__ DS) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= g.B * g.Lc || g.N == 0) return;
@@ -861,12 +753,10 @@ static __global__ __launch_bounds__(256) void cell_dsoftmax(LevelArgs g, int ncb
         for (int cb = 0; cb < ncb; ++cb) dp += DPP[(row0 + lane) * ncb + cb];
     const float pn = an ? Pp[row0 + lane] : 0.f;
     const float sn = an ? Sp[row0 + lane] : 0.f;
-    // scaled: DPP / DPB hold p_n dp_n (level_compose_bwd<.., FROMDZ>)
-    const float mean = wave_sum(scaled ? dp : pn * dp);
+    const float mean = wave_sum(pn * dp);
     // 1 + (s_n - S), in that order: the scores reach 1e8 without unit normalisation, where (1 + s_n) - S loses the 1 (found by
     // tools/fuzz_parity.py: every gradient through outside_s of a cell with |S| > 2^24 vanished)
-    const float ds = scaled ? (dp - pn * mean) + pn * (dStot[crow] * (1.f + (sn - Schart[crow])))
-                            : pn * ((dp - mean) + dStot[crow] * (1.f + (sn - Schart[crow])));
+    const float ds = pn * ((dp - mean) + dStot[crow] * (1.f + (sn - Schart[crow])));
     if (an) DS[row0 + lane] = ds;
 }
 
