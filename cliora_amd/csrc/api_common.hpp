@@ -3,6 +3,7 @@
 // so the units compile in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -73,6 +74,19 @@ static inline int fail(int code, const std::string& msg) { g_cliora_err = msg; r
             return fail(CLIORA_EHIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
     } while (0)
 #define OKR(expr) do { int rc_ = (expr); if (rc_ != CLIORA_OK) return rc_; } while (0)
+// A launch that signals `ev` (or none: nullptr) itself -- hipExtLaunchKernelGGL's stop event is the dispatch packet's own completion
+// signal; a hipEventRecord behind the launch is a barrier packet of its own on the queue, and the next kernel of that queue started
+// ~1 us later for it at every level of the two-chain wavefronts (c2: 3.22 -> 3.17 ms with the forward's inside chain alone).
+#define LAUNCH_SIGNALLING(ev, kernel, grid, block, lds, stream, ...)                                          \
+    do {                                                                                                       \
+        if (ev) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev, 0, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
+    } while (0)
+// CLIORA_STOP_EVENT=0: every event by hipEventRecord
+static bool stop_events_on() {
+    static const bool on = [] { const char* e = getenv("CLIORA_STOP_EVENT"); return !e || atoi(e) != 0; }();
+    return on;
+}
 
 // kernels that need more than 64 KiB of dynamic LDS: the attribute is per device, so it is set once per (function, device)
 int cliora_ensure_max_lds(const void* fn);
@@ -452,8 +466,9 @@ static int launch_tn_tiles(hipStream_t st, const float* DZt, const float* Xt, lo
     const int nsl = (int)(s1 + s2);
     float* csl = slab + (size_t)nsl * Dp * Dp;
     const size_t lds = (size_t)2 * 2048 * (NT + NJT) + 1024;  // two stage buffers + the spare KiB the last X slot reads into
-    // the next stage's LDS-DMA: 1 = all of it right behind the barrier, 0 = two pieces beside each row tile's MFMAs
-    static const int issue_mode = [] { const char* e = getenv("CLIORA_TILES_ISSUE"); return e ? atoi(e) : 1; }();
+    // the next stage's LDS-DMA: 0 = two pieces beside each row tile's MFMAs, 1 = all of it right behind the barrier (the kernel alone at
+    // L 40: 2.30 / 2.48 ms; c2 step 3.21 / 3.24 ms)
+    static const int issue_mode = [] { const char* e = getenv("CLIORA_TILES_ISSUE"); return e ? atoi(e) : 0; }();
     OKR(cliora_ensure_max_lds((const void*)tn_gemm_tiles<NTc, NIT, NJT, NJW, true>));
     hipLaunchKernelGGL((tn_gemm_tiles<NTc, NIT, NJT, NJW, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds, st, reinterpret_cast<const uint32_t*>(DZt),
                        reinterpret_cast<const uint32_t*>(Xt), tile0, (int)ntiles, (int)tps, nsl, nkb, slab, csl, (int)s1, tile0b, (int)ntilesb, issue_mode);

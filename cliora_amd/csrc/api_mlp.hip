@@ -1,6 +1,7 @@
 // C ABI, DioraMLP / CLIORA chart unit: forward / backward sequencing of the level kernels.
 // See include/cliora_chart.h for the contract and the reference lines it replaces.
 #include "api_common.hpp"
+#include <hip/hip_ext.h>
 #include "level_kernels.hpp"
 #ifdef CLIORA_WITH_ROWS_STATIONARY      // the rows-stationary forward compose (measured: no level of any shape selects it) is an optional build
 #include "compose_rs_kernels.hpp"
@@ -161,6 +162,11 @@ static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float
 #undef LB_ARGS
 }
 
+// An event to be signalled by the NEXT level_project launch itself (hipExtLaunchKernelGGL's stop event: the dispatch packet's own
+// completion signal) instead of by a hipEventRecord behind it -- the record is a barrier packet of its own on the chain's queue, and the
+// kernel behind it started 6-7 us late at every level of the forward's inside chain (profiles/r04_notes.md).  Consumed by the launch.
+static thread_local hipEvent_t g_project_stop_event = nullptr;
+
 template <int CT, int SP>
 static int launch_level_project_inst(hipStream_t st, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
                                      size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm,
@@ -168,8 +174,9 @@ static int launch_level_project_inst(hipStream_t st, const float* Wfrag, int K, 
     const int nrg = (ncell + 15) / 16;
     const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;          // column blocks of one row group share an XCD
     const int ncb = ncols / (16 * CT);
-    hipLaunchKernelGGL((level_project<CT, SP>), dim3(sc.nscore + nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc, C, off, HP,
-                       hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+    LAUNCH_SIGNALLING(g_project_stop_event, (level_project<CT, SP>), dim3(sc.nscore + nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc,
+                      C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+    g_project_stop_event = nullptr;
     LAUNCHOK("level_project");
     return CLIORA_OK;
 }
@@ -597,8 +604,11 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     }
     for (int k = 1; k <= L && !persist && !resident; ++k) {
         if (k <= L - 1) {
+            const bool by_kernel = two_streams && stop_events_on() && !vl && k < L - 1;      // the step ends with a level_project launch
+            g_project_stop_event = by_kernel ? plan->ev_level[k] : nullptr;
             OKR(inside_step(k));
-            if (two_streams) HIPOK(hipEventRecord(plan->ev_level[k], sa));
+            g_project_stop_event = nullptr;
+            if (two_streams && !by_kernel) HIPOK(hipEventRecord(plan->ev_level[k], sa));
         }
         if (run_outside && k >= 2 && !compress) {
             const int level = L - k;
@@ -713,14 +723,16 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     static const int sib_env = [] { const char* e = getenv("CLIORA_SIB_SPLIT"); return e ? atoi(e) : -1; }();
     const int sib_split = !two_streams ? 0 : sib_env >= 0 ? std::min(sib_env, L) : (L * 2) / 5;
     auto sib_on_outside_chain = [&](int s_level) { return s_level < sib_split; };
-    auto sibling_gather = [&](int s_level) -> int {
-        if (s_level < 0 || s_level > L - 1 || !ran_outside || !sib_on_outside_chain(s_level)) return CLIORA_OK;
+    auto sibling_runs = [&](int s_level) { return s_level >= 0 && s_level <= L - 1 && ran_outside && sib_on_outside_chain(s_level); };
+    auto sibling_gather = [&](int s_level, hipEvent_t done) -> int {
+        if (!sibling_runs(s_level)) return CLIORA_OK;
         const LevelArgs gi = level_args(p, s_level, false);
-        hipLaunchKernelGGL(cell_gather_bwd_sib, dim3(B * gi.Lc), dim3(256), 0, sb, gi, dv.use[ROLE_OUTA], DA, DS, OH, sibPL, sibQL, ldsib, wb + bw.sib_s);
+        LAUNCH_SIGNALLING(done, cell_gather_bwd_sib, dim3(B * gi.Lc), dim3(256), 0, sb, gi, dv.use[ROLE_OUTA], DA, DS, OH, sibPL, sibQL, ldsib, wb + bw.sib_s);
         LAUNCHOK("cell_gather_bwd_sib");
         return CLIORA_OK;
     };
-    auto outside_bwd_step = [&](int level) -> int {
+    // `done`: an event that the step's LAST launch signals itself (LAUNCH_SIGNALLING) -- nullptr: the caller records
+    auto outside_bwd_step = [&](int level, hipEvent_t done) -> int {
         const LevelArgs g = level_args(p, level, true);     // N == 0 at the root level
         const int ncell = B * g.Lc;
         // levels 1 .. L-2: the unit-norm backward rides in the projection-backward GEMM's epilogue (NormBwdLevelE; the gather leaves
@@ -742,7 +754,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                 LAUNCHOK("cell_dnorm(root)");
                 return CLIORA_OK;
             }
-            hipLaunchKernelGGL(root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, sb, B, C, Dp, VHo, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
+            LAUNCH_SIGNALLING(done, root_bwd, dim3(1), dim3(ROOT_WAVES * 64), 0, sb, B, C, Dp, VHo, OH, ws + f.nrmo, p.normalize, wb + bw.groot);
             LAUNCHOK("root_bwd");
             return CLIORA_OK;
         }
@@ -755,9 +767,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             OKR(launch_level_compose_bwd(sb, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dGo, YM, Pp,
                                          PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB, tiled));
         }
-        hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
+        const bool sib_last = sibling_runs(L - 2 - level);
+        LAUNCH_SIGNALLING(sib_last ? nullptr : done, cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
         LAUNCHOK("cell_dsoftmax(out)");
-        OKR(sibling_gather(L - 2 - level));      // the inside level whose sibling uses are final with this outside level
+        OKR(sibling_gather(L - 2 - level, done));      // the inside level whose sibling uses are final with this outside level
         return CLIORA_OK;
     };
 
@@ -857,7 +870,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         HIPOK(hipMemsetAsync(wb + bw.groot, 0, (size_t)Dp * sizeof(float), st));
     }
     if (compress) {          // the whole outside backward (down to the per-sentence roots), then the inside backward
-        for (int j = 0; j <= L - 1 && ran_outside; ++j) OKR(outside_bwd_step(j));
+        for (int j = 0; j <= L - 1 && ran_outside; ++j) OKR(outside_bwd_step(j, nullptr));
         for (int j = 0; j <= L - 1; ++j) OKR(inside_bwd_step(L - 1 - j));
         if (ran_outside)     // d root_mat_out^T = sum_b d root[b]^T inside_h[b, root]
             OKR(launch_tn(st, B, Dp, Dp, Dp, LevelRowsA{dGo, Dp, C, C - 1, 1}, LevelRowsA{IH, Dp, C, C - 1, 1}, wb + bw.slab, bw.slab_floats,
@@ -900,8 +913,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     }
     for (int j = 0; j <= L - 1 && !compress && !resident; ++j) {
         if (ran_outside) {
-            OKR(outside_bwd_step(j));
-            if (two_streams) HIPOK(hipEventRecord(plan->ev_level[j], sb));
+            // (the compress root step ends in a launch that takes no event; it never runs on two streams)
+            const bool by_kernel = two_streams && stop_events_on();
+            OKR(outside_bwd_step(j, by_kernel ? plan->ev_level[j] : nullptr));
+            if (two_streams && !by_kernel) HIPOK(hipEventRecord(plan->ev_level[j], sb));
         }
         // the gather of inside level L-1-j reads the outside pairs whose sibling it is: outside levels <= j-1
         if (two_streams && j >= 1) HIPOK(hipStreamWaitEvent(sa, plan->ev_level[j - 1], 0));
