@@ -461,7 +461,7 @@ def main():
                 # what this implementation moves per step in the class, by construction
                 'compose_fwd': 'operand rows re-gathered by each of the %d column blocks through L2 (5 x 3.2 kB per pair row), '
                                'partial aggregates written once; no per-pair row stored' % (Dp // 80 if Dp % 80 == 0 else 1),
-                'compose_bwd': 'dG rows + ReLU bits gathered per column block; DA, DZ, X rows written (3 x %d MB per step)' % (pairs * B * Dp * 4 // 2**20),
+                'compose_bwd': 'dG rows + ReLU bits gathered per column block; DA rows and X / DZ (d 400: as 16-row tiles of bf16 hi + lo planes, the weight gradient\'s operand form) written (3 x %d MB per step)' % (pairs * B * Dp * 4 // 2**20),
                 'wgrad': 2.0 * pairs * B * Dp * 4.0,
             }
             peak_mfma = PEAK_BF16_MFMA_TFLOPS / 3.0 if mfma_mode == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS   # 3 bf16 MFMAs per product
