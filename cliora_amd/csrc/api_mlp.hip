@@ -706,7 +706,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // unit-norm backward in the projection-backward GEMM's epilogue (chart_kernels.hpp: NormBwdLevelE): text-only charts without compress
     // (CLIORA normalises around the attention residual; compress keeps per-sentence root gradients in dGo).  CLIORA_FUSE_DNORM=0: off.
     static const bool fuse_off = [] { const char* e = getenv("CLIORA_FUSE_DNORM"); return e && atoi(e) == 0; }();
-    const bool fuse_dnorm = !fuse_off && !vl && !compress && !resident;
+    // (the OUTSIDE chart has no attention residual: its chain keeps the fusion in CLIORA plans too -- round 4, c3 chart step)
+    const bool fuse_dnorm = !fuse_off && !compress && !resident;
     // X / DZ of the pair rows as tiled split-bf16 operands (wgrad_tiles.hpp) instead of fp32 rows.  CLIORA_PAIR_TILES=0: off.
     const bool tiled = pair_tiles_ok(Dp) && !resident;
 
@@ -828,8 +829,9 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             OKR(launch_rows_direct(sa, ws + f.rootwT, PROJ_IMG(f.rootwT3), Dp, Dp, ncell, LevelRowsA{dGo, Dp, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));
         if (vl) {
+            // (levels >= 1: with the unit-norm backward through u = unit(g) at its end, cell_dnorm's launch of round 3)
             ATTEND_LAUNCH(cell_attend_bwd, p.R, dim3(ncell), sa, g, VH, IH, ws + f.nrmi, p.normalize, OBJ, p.R,
-                               drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc);
+                               drop_mask, ws + f.att_pk, wb + bw.dctx, wb + bw.pmo, wb + bw.dsc, IHn, nrmIn, level >= 1 ? dG : (float*)nullptr);
             LAUNCHOK("cell_attend_bwd");
         }
         if ((level == ksplit || level == ksplit2) && level >= 1) {
@@ -841,7 +843,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             tail_cells = g.off;
         }
         if (level == 0) return CLIORA_OK;
-        if (!fused_norm) {
+        if (!fused_norm && !vl) {
             hipLaunchKernelGGL(cell_dnorm, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, VH, IHn, nrmIn, p.normalize, dG);
             LAUNCHOK("cell_dnorm(in)");
         }

@@ -143,7 +143,10 @@ template <int NRW>
 static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float* __restrict__ VH, const float* __restrict__ H,
                                                        const float* __restrict__ nrmV, int normalize, const float* __restrict__ OBJ,
                                                        int R, const float* __restrict__ mask, const float* __restrict__ PK,
-                                                       float* __restrict__ DCTX, float* __restrict__ PMo, float* __restrict__ DSC) {
+                                                       float* __restrict__ DCTX, float* __restrict__ PMo, float* __restrict__ DSC,
+                                                       const float* __restrict__ U, const float* __restrict__ nrmU, float* __restrict__ dG) {
+    // dG != nullptr (round 4): the unit-norm backward through u = unit(g) that cell_dnorm did in a launch of its own behind this one --
+    // same loads, same formulas (unit_norm_bwd on the du this kernel just formed), one launch less on the inside chain of every level
     // one workgroup (4 waves) per cell, the regions dealt over the waves as in cell_attend_fwd
     __shared__ float4 sh_v[4][128];
     __shared__ float sh_d[VL_MAXR];
@@ -197,8 +200,17 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
     if (a1) sh_v[wave][lane + 64] = u1;
     __syncthreads();
     if (wave != 0) return;
-    if (a0) { st4(DCTX + crow * Dp + c0, v0); st4(VH + crow * Dp + c0, f4add(f4add(f4add(sh_v[0][lane], sh_v[1][lane]), sh_v[2][lane]), sh_v[3][lane])); }
-    if (a1) { st4(DCTX + crow * Dp + c1, v1); st4(VH + crow * Dp + c1, f4add(f4add(f4add(sh_v[0][lane + 64], sh_v[1][lane + 64]), sh_v[2][lane + 64]), sh_v[3][lane + 64])); }
+    float4 d0 = f4zero(), d1 = f4zero();
+    if (a0) { d0 = f4add(f4add(f4add(sh_v[0][lane], sh_v[1][lane]), sh_v[2][lane]), sh_v[3][lane]); st4(DCTX + crow * Dp + c0, v0); st4(VH + crow * Dp + c0, d0); }
+    if (a1) { d1 = f4add(f4add(f4add(sh_v[0][lane + 64], sh_v[1][lane + 64]), sh_v[2][lane + 64]), sh_v[3][lane + 64]); st4(DCTX + crow * Dp + c1, v1); st4(VH + crow * Dp + c1, d1); }
+    if (dG) {
+        float4 hu0 = f4zero(), hu1 = f4zero();
+        if (a0) hu0 = ld4(U + crow * Dp + c0);
+        if (a1) hu1 = ld4(U + crow * Dp + c1);
+        unit_norm_bwd(d0, d1, hu0, hu1, nrmU[crow], normalize);
+        if (a0) st4(dG + crow * Dp + c0, d0);
+        if (a1) st4(dG + crow * Dp + c1, d1);
+    }
 }
 
 // d obj[b][k][:] = sum over the inside cells of sentence b of  pm[cell][k] * dctx[cell][:] + dsc[cell][k] * u[cell][:]
