@@ -278,6 +278,36 @@ def test_compress_root_against_oracle(D, B, L, share, mfma_mode):
     assert float(m2.root_mat_out.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('B,L,share,outside', [(3, 7, False, True), (5, 6, True, False), (2, 9, False, False), (17, 5, True, True)])
+def test_d400_tiled_pair_rows_variants_against_oracle(B, L, share, outside, mfma_mode):
+    """d = 400 in the default arithmetic keeps X / DZ of the backward as 16-row tiles of bf16 hi / lo planes and runs the pair rows'
+    weight gradient on them (csrc/wgrad_tiles.hpp).  The headline shape covers shared weights, both passes and whole tiles (B * Lc a
+    multiple of 16); here the other branches of that path: unshared weights (the outside rows are a tile range of their own), the inside
+    pass alone, and batches whose levels end in ragged tiles (rows past the last cell are stored as zeros)."""
+    from oracle import diora_ref as R
+    from oracle import synth
+    D = 400
+    P, x, cot = synth.diora_case(D, B, L, 17, share=share)
+    m = _module_from_params(P, D, share, 'unit', outside=outside)
+    if not outside:
+        cot = {k: cot[k] for k in ('inside_h', 'inside_s')}
+    outs, xg = _run_gpu(m, x, cot)
+    for v in P.values():
+        v.requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = R.diora_forward(P, xc, xc, share=share, outside=outside)
+    sum((ref[k] * cot[k]).sum() for k in cot).backward()
+    for k in cot:
+        assert _err(outs[k], ref[k]) <= OUT_TOL * _scale(ref[k].detach().numpy()), k
+    named = dict(m.named_parameters())
+    for k, p_ in P.items():
+        if p_.grad is None:
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
+        else:
+            _grad_ok(named[k].grad, p_.grad, k, mfma_mode)
+    _grad_ok(xg.grad, xc.grad, 'x_span', mfma_mode)
+
+
 def test_cpu_tensor_fails_loudly():
     from cliora_amd.diora import DioraMLP
     from cliora_amd._lib import ChartLibError
