@@ -416,24 +416,26 @@ static int launch_tn_pairs_two_ranges(hipStream_t st, const float* DZ, const flo
 // out[i][j] (+)= sum over the cells [off, off + hi) of every sentence of A[cell][acol0 + i] * Bm[cell][j] (i, j < Dp; A of row stride lda,
 // Bm of row stride Dp; colsum_out (+)= the column sums of that A block): one block of the projections' weight gradient on the
 // eight-wave split-bf16 kernel, the rows remapped inside it.  Only where tn_pairs_strided_ok(Dp).
+// nblk > 1 (round 4): the blocks acol0, acol0 + Dp, ... of A in ONE launch (gridDim.y) and one reduction -- out / colsum_out are then
+// nblk consecutive Dp x Dp / Dp outputs.
 static int launch_tn_level_block(hipStream_t st, const float* A, int lda, int acol0, const float* Bm, int nsent, int C, int off, int hi, int Dp,
-                                 float* slab, size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap) {
+                                 float* slab, size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap, int nblk = 1) {
     constexpr int NIT = 7, NJT = 9, nkb = 3;
     const int nrows = nsent * hi;
     if (nrows <= 0) return CLIORA_OK;
-    const size_t per_slice = (size_t)Dp * Dp + Dp;
+    const size_t per_slice = ((size_t)Dp * Dp + Dp) * nblk;
     const size_t lds3 = (size_t)2 * TN3_RS * (Dp + NJT * 16) * sizeof(float) + (size_t)NJT * 2048;
     int cap = std::min<int>((int)(slab_floats / per_slice), slices_cap > 0 ? slices_cap : std::max(1, 230 / (8 * nkb)) * 8);
     cap = std::max(1, std::min(cap, (nrows + 63) / 64));
     int rps = (nrows + cap - 1) / cap;
     rps = (rps + TN3_RS - 1) / TN3_RS * TN3_RS;
     const int nsl = (nrows + rps - 1) / rps;
-    float* csl = slab + (size_t)nsl * Dp * Dp;
+    float* csl = slab + (size_t)nsl * nblk * Dp * Dp;
     OKR(cliora_ensure_max_lds((const void*)tn_gemm_dma3x<NIT, NJT, 5, true>));
-    hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds3, st, A + acol0, lda, Bm, Dp, nrows, rps, nsl, Dp, Dp,
-                       nkb, slab, csl, 0x7fffffff, 0, 0LL, hi, C, off);
+    hipLaunchKernelGGL((tn_gemm_dma3x<NIT, NJT, 5, true>), dim3(8 * nkb * ((nsl + 7) / 8), nblk), dim3(512), lds3, st, A + acol0, lda, Bm, Dp, nrows, rps, nsl,
+                       Dp, Dp, nkb, slab, csl, 0x7fffffff, 0, 0LL, hi, C, off, (long long)Dp);
     LAUNCHOK("tn_gemm_dma3x(level rows)");
-    launch_slab_reduce(st, slab, nsl, (size_t)Dp * Dp, out, accumulate, csl, (size_t)Dp, colsum_out);
+    launch_slab_reduce(st, slab, nsl, (size_t)nblk * Dp * Dp, out, accumulate, csl, (size_t)nblk * Dp, colsum_out);
     LAUNCHOK("slab_reduce");
     return CLIORA_OK;
 }

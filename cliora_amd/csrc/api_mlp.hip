@@ -797,6 +797,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     static const int wcat_slices = [] { const char* e = getenv("CLIORA_WCAT_SLICES"); return e ? atoi(e) : 48; }();
     auto wcat_grad = [&](hipStream_t s_, int off, int hi, int accumulate) -> int {
         if (!wcat_f32 && tn_pairs_strided_ok(Dp) && (long long)B * hi >= 512) {
+            // all projection blocks in one launch + one reduction (CLIORA_WCAT_FUSED=0: a launch and a reduction per block, 48 slices each):
+            // the three launches + three reductions of the low levels' part ended the step ~120 us after the inside chain.  Slices per block
+            // (x 3 column blocks x nb workgroups), c2: 8 / 12 / 16 / 20 / 24 / 28 -> 3.17 / 3.14 / 3.11 / 3.11 / 3.11 / 3.15 ms (unfused 3.195)
+            static const bool fused = [] { const char* e = getenv("CLIORA_WCAT_FUSED"); return !e || atoi(e) != 0; }();
+            static const int fused_slices = [] { const char* e = getenv("CLIORA_WCAT_FUSED_SLICES"); return e ? atoi(e) : 0; }();
+            if (fused)
+                return launch_tn_level_block(s_, dPI, ldpi, 0, IH, B, C, off, hi, Dp, wb + bw.slab2, bw.slab_floats, wb + bw.gwcat, wb + bw.gbcat, accumulate,
+                                             fused_slices > 0 ? fused_slices : std::max(8, (180 / (3 * nb)) / 4 * 4), nb);
             for (int blk = 0; blk < nb; ++blk)
                 OKR(launch_tn_level_block(s_, dPI, ldpi, blk * Dp, IH, B, C, off, hi, Dp, wb + bw.slab2, bw.slab_floats,
                                           wb + bw.gwcat + (size_t)blk * Dp * Dp, wb + bw.gbcat + (size_t)blk * Dp, accumulate, wcat_slices));

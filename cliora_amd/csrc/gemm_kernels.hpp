@@ -1171,7 +1171,10 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
                                                      int rows_per_slice, int nslices, int Mi, int Nj, int nkb,
                                                      float* __restrict__ slab, float* __restrict__ colsum,
                                                      int slice2 = 0x7fffffff, int nrows2 = 0, long long shift2 = 0,
-                                                     int rm_hi = 0, int rm_C = 0, int rm_off = 0) {
+                                                     int rm_hi = 0, int rm_C = 0, int rm_off = 0, long long a_prob_stride = 0) {
+    // gridDim.y > 1: that many problems in one launch -- problem y reads A + y * a_prob_stride (the projection blocks of dPI: column
+    // offsets of one row-major matrix) against the same B, and its slab / column-sum slices are interleaved [slice][problem] so that
+    // ONE reduction finishes all of them into consecutive outputs (round 4: three launches + three reductions ended the step)
     // rm_hi > 0: the rows are the cells [rm_off, rm_off + rm_hi) of every sentence's chart (rm_C cells per sentence) of BOTH
     // matrices -- row r is chart row (r / rm_hi) * rm_C + rm_off + r % rm_hi: the projections' weight gradient over the levels
     // that are final (round 4: the fp32 element-load tn_gemm took 233 us for them at d 400 and ended the step)
@@ -1203,6 +1206,8 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
 
     const bool second = slice >= slice2;
     if (second) { A += shift2 * lda; B += shift2 * ldb; }
+    const int prob = blockIdx.y, nprob = gridDim.y;
+    A += (size_t)prob * a_prob_stride;
     const int rbeg = (second ? slice - slice2 : slice) * rows_per_slice;
     const int rend = min(second ? nrows2 : nrows, rbeg + rows_per_slice);
     const int nstages = rend > rbeg ? (rend - rbeg + TN3_RS - 1) / TN3_RS : 0;
@@ -1331,7 +1336,7 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
             }
         }
     }
-    float* out = slab + (size_t)slice * Mi * Nj;
+    float* out = slab + ((size_t)slice * nprob + prob) * Mi * Nj;
     if (has_tiles) {
 #pragma unroll
         for (int t = 0; t < NIT; ++t)
@@ -1348,7 +1353,7 @@ static __global__ __launch_bounds__(512) void tn_gemm_dma3x(const float* __restr
         for (int t = 0; t < NIT; ++t)
             if (t < nit)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) colsum[(size_t)slice * Mi + (it0 + t) * 16 + g * 4 + reg] = acc[t][NJW - 1][reg];
+                for (int reg = 0; reg < 4; ++reg) colsum[((size_t)slice * nprob + prob) * Mi + (it0 + t) * 16 + g * 4 + reg] = acc[t][NJW - 1][reg];
     }
 }
 
