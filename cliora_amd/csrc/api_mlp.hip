@@ -784,7 +784,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // worth starting in the MIDDLE of the chain, so that the GEMM stream is idle again when the low levels' share arrives -- c2 with
     // level 2 / 4 / 8 / 10 / 12: 3.36 / 3.35 / 3.30-3.32 / 3.29 / 3.32 ms
     const bool wcat_split_path = split_bf16() && tn_pairs_strided_ok(Dp);
-    const int ksplit = ksplit_env >= 0 ? ksplit_env : wcat_split_path ? std::max(1, std::min(L / 2, L - 1)) : std::min(2, L - 1);
+    // (with all blocks in one launch the part pays a little earlier still: level 8 / 10 at L 20: 3.146 / 3.172 ms)
+    const int ksplit = ksplit_env >= 0 ? ksplit_env : wcat_split_path ? std::max(1, std::min(2 * L / 5, L - 1)) : std::min(2, L - 1);
     // ... optionally a second part (the levels below the first part down to ksplit2, CLIORA_WGRAD_SPLIT_LEVEL2): three more launches
     // beside the inside chain's heaviest steps cost more than they take from the tail
     static const int ksplit2_env = [] { const char* e = getenv("CLIORA_WGRAD_SPLIT_LEVEL2"); return e ? atoi(e) : -1; }();
