@@ -903,6 +903,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     const int early_auto = L >= 16 ? L / 2 + 1 : -1;
     const int early_pick = early_env == -2 ? early_auto : early_env;
     const int J_early = (p.share && ran_outside && !compress && !resident && early_pick >= 0 && early_pick <= L - 3) ? early_pick : -1;
+    static const int early2_env = [] { const char* e = getenv("CLIORA_WGRAD_EARLY_STEP2"); return e ? atoi(e) : -2; }();      // -1: off
+    const int early2_auto = L >= 28 ? (J_early + L) / 2 : -1;
+    const int early2_pick = early2_env == -2 ? early2_auto : early2_env;
+    const int J_early2 = (J_early >= 0 && early2_pick > J_early && early2_pick <= L - 3) ? early2_pick : -1;
     long long early_r0 = 0, early_r1 = 0, early_t0 = 0, early_t1 = 0;       // ... as pair rows and as 16-row tiles
     if (resident) {
         // ---- both chains and the leaves' pre-activation gradient: one workgroup per sentence (resident_kernels.hpp) ----
@@ -946,6 +950,20 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             else
                 OKR(launch_tn_pairs(sw, DZ + (size_t)early_r0 * Dp, Xp + (size_t)early_r0 * Dp, (int)(early_r1 - early_r0), Dp, wb + bw.slab2, bw.slab_floats,
                                     wb + bw.gw2o, wb + bw.gb2o, 0, early_slices));
+        }
+        // Long charts, tiled operands: a SECOND early part.  At L 40 the first part (the middle 60 % of the pair rows) is done a millisecond
+        // before the chains are, the GEMM stream idles, and the tail -- the two ends, 0.5 ms with the whole chip -- then meets the chains' last
+        // kernels (the level-0 projection backward took 450 us beside it instead of 40).  The rows that became final since the first part are two
+        // ranges (inside levels L-1-J2 .. L-2-J, outside levels J+1 .. J2): one two-range launch, accumulated onto the first part's result.
+        if (tiled && J_early >= 0 && j == J_early2) {
+            const long long t0 = p.tile_base_in(L - 1 - j), t1 = p.tile_base_out(j + 1);
+            HIPOK(hipEventRecord(plan->ev_fork[2], sa));
+            HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
+            if (two_streams) HIPOK(hipStreamWaitEvent(sw, plan->ev_level[j], 0));
+            OKR(launch_tn_tiles(sw, DZ, Xp, t0, early_t0 - t0, early_t1, t1 - early_t1, Dp, wb + bw.slab2, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o, 1,
+                                early_slices));
+            early_t0 = t0; early_t1 = t1;
+            early_r0 = p.row_base_in(L - 1 - j); early_r1 = p.row_base_out(j + 1);
         }
     }
     // leaves
