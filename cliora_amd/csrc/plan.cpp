@@ -74,8 +74,8 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
     p.tile_base_in_.assign(L + 1, 0); p.tile_base_out_.assign(L + 1, 0);
     for (int lv = 0; lv < L; ++lv) {
         const long long g16 = ((long long)B * (L - lv) + 15) / 16;
-        p.tile_base_in_[lv + 1] = p.tile_base_in_[lv] + g16 * lv;
-        p.tile_base_out_[lv + 1] = p.tile_base_out_[lv] + g16 * (L - lv - 1);
+        p.tile_base_in_[lv + 1] = (int32_t)(p.tile_base_in_[lv] + g16 * lv);
+        p.tile_base_out_[lv + 1] = (int32_t)(p.tile_base_out_[lv] + g16 * (L - lv - 1));
     }
     p.T_in = p.tile_base_in_[L]; p.T_out = p.tile_base_out_[L];
 
@@ -362,6 +362,8 @@ const std::vector<int32_t>* find_table(Plan& p, const std::string& name) {
     if (name == "pair_lvl_base_in") return &p.lvl_base_in;
     if (name == "pair_lvl_base_out") return &p.lvl_base_out;
     if (name == "persist_levels") return &p.persist_levels;
+    if (name == "tile_base_in") return &p.tile_base_in_;          // 16-row tiles of the pair rows (wgrad_tiles.hpp): first tile of a level, per pass
+    if (name == "tile_base_out") return &p.tile_base_out_;
     if (name == "arow" || name == "brow" || name == "trow") build_row_maps(p);
     if (name == "arow") return &p.arow;
     if (name == "brow") return &p.brow;

@@ -122,7 +122,7 @@ struct Plan {
     // The pair rows as 16-row tiles (one tile = 16 target cells of one level x one split: a wave tile of level_compose_bwd), in the
     // pair rows' order (inside levels, then outside levels): the storage unit of the tiled split-bf16 operands of the pair rows'
     // weight gradient (gemm_kernels.hpp: tn_gemm_tiles).  A level with B * Lc not a multiple of 16 carries zero rows in its last tiles.
-    std::vector<long long> tile_base_in_, tile_base_out_;      // L + 1 each (the last entry: the pass's end)
+    std::vector<int32_t> tile_base_in_, tile_base_out_;        // L + 1 each (the last entry: the pass's end); fewer tiles than pair rows / 16 + L^2, which fit 32 bits
     long long T_in = 0, T_out = 0;
     long long tile_base_in(int level) const { return tile_base_in_[level]; }
     long long tile_base_out(int level) const { return T_in + tile_base_out_[level]; }

@@ -136,3 +136,25 @@ def test_mfma_mode_switch_round_trips():
     prev = _lib.set_mfma_mode('f32')
     assert _lib.set_mfma_mode('bf16x3') == 'f32'
     assert _lib.set_mfma_mode(prev) == 'bf16x3'
+
+
+def test_pair_row_tiles_follow_the_pair_rows_level_by_level():
+    """The tiled split-bf16 operands of the pair rows' weight gradient (csrc/wgrad_tiles.hpp) are stored per 16-row tile = 16 target cells of
+    one level x one split, levels in the pair rows' order.  tile_base_{in,out}[lv] is the first tile of level lv of a pass, entry L its end:
+    N(lv) * ceil(B * Lc / 16) tiles per level, and exactly row_base / 16 where every level's cell count is a multiple of 16."""
+    from cliora_amd import _lib
+    for B, L in ((64, 20), (3, 9), (17, 5), (1, 1), (16, 2)):
+        pl = _lib.Plan(B, L, 400, True, 'unit', 0, 0)
+        tin, tout = pl.table('tile_base_in'), pl.table('tile_base_out')
+        assert len(tin) == L + 1 and len(tout) == L + 1 and tin[0] == 0 and tout[0] == 0
+        for lv in range(L):
+            g16 = (B * (L - lv) + 15) // 16
+            assert tin[lv + 1] - tin[lv] == g16 * lv, (B, L, lv)
+            assert tout[lv + 1] - tout[lv] == g16 * (L - lv - 1), (B, L, lv)
+        if B % 16 == 0:
+            bin_, bout = pl.table('pair_lvl_base_in'), pl.table('pair_lvl_base_out')
+            for lv in range(L):
+                if lv >= 1:                 # levels with pairs: inside 1 .. L-1, outside 0 .. L-2
+                    assert tin[lv] * 16 == B * int(bin_[lv]), (B, L, lv)
+                if lv <= L - 2:
+                    assert tout[lv] * 16 == B * int(bout[lv]), (B, L, lv)
