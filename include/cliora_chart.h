@@ -93,7 +93,9 @@ size_t cliora_plan_bwd_workspace_bytes(const cliora_plan* plan);
 /* Host view of a plan table (int32), for tests and tooling.  Names:
  * "level_offset", "pair_a_in", "pair_b_in", "pair_a_out", "pair_b_out",
  * "pair_lvl_base_in", "pair_lvl_base_out", "use_off_<role>", "use_row_<role>",
- * "use_stride_<role>", "use_partner_<role>" with role in {ina, inb, outa, outb}.
+ * "use_stride_<role>", "use_partner_<role>" with role in {ina, inb, outa, outb};
+ * "tile_base_in", "tile_base_out" (L + 1 each): first 16-row tile of a level's pair rows in the
+ * tiled split-bf16 operand form of the pair rows' weight gradient (csrc/wgrad_tiles.hpp), per pass.
  * Works without a GPU. */
 int cliora_plan_table(const cliora_plan* plan, const char* name, const int32_t** data, size_t* count);
 
