@@ -42,6 +42,45 @@ def usable_cpus():
     return n
 
 
+def host_cpu():
+    """CPU model string, logical CPUs and physical cores of this host ("state the count and CPU model")."""
+    model, phys, logical = 'unknown', set(), 0
+    try:
+        pid = cid = None
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                model = ln.split(':', 1)[1].strip()
+                logical += 1
+            elif ln.startswith('physical id'):
+                pid = ln.split(':', 1)[1].strip()
+            elif ln.startswith('core id'):
+                cid = ln.split(':', 1)[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return dict(model=model, logical_cpus=logical or (os.cpu_count() or 1), physical_cores=len(phys) or None, usable_by_this_process=usable_cpus())
+
+
+def port_vs_reference():
+    """Measured wall-time ratio of the oracle to the imported reference (tools/cpu_port_check.py, build container: the reference cannot
+    travel to the GPU box) -- SURVEY 8(d) wants the port within +-10 %; the committed measurement is printed beside the baseline."""
+    for cand in ('r05_cpu_port_check.json',):
+        fp = os.path.join(ROOT, 'profiles', cand)
+        if os.path.exists(fp):
+            try:
+                j = json.load(open(fp))
+                return dict(file='profiles/' + cand, d400_ratio=j.get('port_vs_reference_d400'),
+                            cases=[dict(D=c['D'], B=c['B'], L=c['L'], threads=c['threads'], ratio=c['port_vs_reference']) for c in j.get('cases', [])],
+                            note='oracle seconds / reference seconds on the same inputs, alternating, measured in the build container (the GPU box '
+                                 'has no reference); value above is the port as timed on THIS host')
+            except (OSError, ValueError, KeyError):
+                return None
+    return None
+
+
 def cpu_baseline(L, D, B, budget_s=25.0):
     """The CPU oracle (a restatement of the reference's torch op sequence, oracle/diora_ref.py)
     timed on this host: chart-only forward + backward, all host cores torch exposes."""
@@ -72,9 +111,19 @@ def cpu_baseline(L, D, B, budget_s=25.0):
         t_all += t
     times.sort()
     med = times[len(times) // 2]
+    # the 1-thread figure SURVEY 8(d) asks for: one step of 8 sentences after a 2-sentence warm-up (about 2 s)
+    one = None
+    try:
+        torch.set_num_threads(1)
+        step(2)
+        t1 = step(8)
+        one = dict(value=round(8 / t1, 3), unit='sentences/s', sample='1 step of 8 sentences, 1 thread, %.2f s' % t1)
+    finally:
+        torch.set_num_threads(threads)
     return dict(value=b / med, unit='sentences/s', cores=threads, kind='port',
                 sample='%d steps of %d sentences (L=%d, d=%d), chart fwd+bwd, torch %s CPU oracle, %d threads, median %.2f s/step, %.1f s total'
-                       % (len(times), b, L, D, torch.__version__, threads, med, t_all))
+                       % (len(times), b, L, D, torch.__version__, threads, med, t_all),
+                host=host_cpu(), one_thread=one, port_vs_reference=port_vs_reference())
 
 
 def algorithmic_bytes(plan, B, D, cell_floats=None):

@@ -101,9 +101,8 @@ def lib():
     L.cliora_recon_forward.restype = i32
     L.cliora_recon_backward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.cliora_recon_backward.restype = i32
-    if hasattr(L, 'cliora_rows_scatter_add'):
-        L.cliora_rows_scatter_add.argtypes = [vp, vp, i32, i32, vp, C.c_int64, vp]
-        L.cliora_rows_scatter_add.restype = i32
+    L.cliora_rows_scatter_add.argtypes = [vp, vp, i32, i32, vp, C.c_int64, vp]     # mandatory: heads.scatter_rows has no other path
+    L.cliora_rows_scatter_add.restype = i32
     L.cliora_vg_workspace_bytes.argtypes = [i32, i32]
     L.cliora_vg_workspace_bytes.restype = sz
     L.cliora_vg_loss.argtypes = [i32, i32, i32, vp, C.c_float, vp, vp, vp, sz, vp]
@@ -241,9 +240,9 @@ WAVEFRONT_MODES = {'auto': -1, 'off': 0, 'on': 1}
 
 def set_wavefront(mode):
     """Scheduling of the inside / outside passes (include/cliora_chart.h: cliora_set_wavefront): 'auto' (default), 'off' (the
-    reference's order on the caller's stream alone) or 'on'.  Results are bitwise identical.  Returns the previous mode."""
-    prev = lib().cliora_set_wavefront(WAVEFRONT_MODES[mode])
-    return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
+    reference's order on the caller's stream alone), 'on' (two streams) or 'merged' (the two passes' launches of a step as one grid on one queue).  Results are bitwise identical.  Returns the previous mode."""
+    prev = lib().cliora_set_wavefront({'merged': 2}.get(mode, WAVEFRONT_MODES.get(mode)))
+    return {-1: 'auto', 0: 'off', 1: 'on', 2: 'merged'}[prev]
 
 
 def set_resident(mode):

@@ -133,7 +133,7 @@ struct ProfScope {
 
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
-extern int g_cliora_wavefront;      // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_wavefront)
+extern int g_cliora_wavefront;      // -1 auto, 0 off, 1 two streams, 2 merged: one queue (include/cliora_chart.h: cliora_set_wavefront)
 extern int g_cliora_rows_stationary; // -1 auto, 0 off, 1 every eligible level, 2 the rows-stationary geometry on the weight-stationary kernel (tests)
 extern int g_cliora_rs_min_rows;      // auto: levels with at least this many pair rows (CLIORA_RS_MIN_ROWS)
 extern int g_cliora_persistent;     // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_persistent)

@@ -338,10 +338,10 @@ extern "C" int cliora_set_mfma_mode(int mode) {
     return prev;
 }
 
-int g_cliora_wavefront = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+int g_cliora_wavefront = [] { const char* e = getenv("CLIORA_WAVEFRONT"); return e ? std::max(0, std::min(atoi(e), 2)) : -1; }();
 extern "C" int cliora_set_wavefront(int mode) {
     const int prev = g_cliora_wavefront;
-    g_cliora_wavefront = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
+    g_cliora_wavefront = mode < 0 ? -1 : std::min(mode, 2);
     return prev;
 }
 
@@ -374,7 +374,8 @@ extern "C" int cliora_set_persistent(int mode) {
 }
 // A persistent launch that gives up on a grid barrier (another process held CUs for seconds) returns early with its chart partly
 // written and counts that in a device word.  The word follows every such launch to pinned host memory; the next call into the
-// library on that device -- normally the backward of the same step -- looks at it and fails loudly instead of training on garbage.
+// library on that device looks at it and fails loudly instead of training on garbage: cliora_chart_backward waits for the copy (wait =
+// true: the backward of the same step is enqueued before the copy lands), cliora_chart_forward only queries.
 // Both run under the device's lanes mutex (the callers hold it).
 int cliora_persist_note(cliora_plan* plan, hipStream_t st) {
     PersistWatch* w = plan->watch;
@@ -401,7 +402,7 @@ int cliora_persist_check(cliora_plan* plan, bool wait) {
         const unsigned n = now - w->seen;
         w->seen = now;
         return fail(CLIORA_EHIP, "a persistent level-loop launch gave up on " + std::to_string(n) + " grid barrier wait(s) (the device was shared): "
-                                 "the charts of that forward are incomplete; rerun the step, or set CLIORA_PERSISTENT=0");
+                                 "the charts of that forward are incomplete and no gradient was produced from them; rerun the step, or set CLIORA_PERSISTENT=0");
     }
     return CLIORA_OK;
 }

@@ -20,7 +20,7 @@ static bool lstm_proj_split() {
 // two streams pay under the same rule as for DioraMLP (api_mlp.hip: wavefront_pays)
 static bool wavefront_pays_lstm(const Plan& p, int mode) {
     if (p.L <= 2 || mode == 0) return false;
-    if (mode == 1) return true;
+    if (mode >= 1) return true;      // (2 = merged: DioraMLP only; here two streams)
     return (double)(p.R_in + p.R_out) / (2.0 * (p.L - 1)) * p.Dp >= 100e3;
 }
 

@@ -162,45 +162,99 @@ static int launch_level_compose_bwd(hipStream_t st, const float* WT, const float
 #undef LB_ARGS
 }
 
-// An event to be signalled by the NEXT level_project launch itself (hipExtLaunchKernelGGL's stop event: the dispatch packet's own
+// `stop`: an event to be signalled by the level_project launch itself (hipExtLaunchKernelGGL's stop event: the dispatch packet's own
 // completion signal) instead of by a hipEventRecord behind it -- the record is a barrier packet of its own on the chain's queue, and the
-// kernel behind it started 6-7 us late at every level of the forward's inside chain (profiles/r04_notes.md).  Consumed by the launch.
-static thread_local hipEvent_t g_project_stop_event = nullptr;
-
+// kernel behind it started 6-7 us late at every level of the forward's inside chain (profiles/r04_notes.md).  nullptr: none.
 template <int CT, int SP>
 static int launch_level_project_inst(hipStream_t st, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
                                      size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm,
-                                     const ScoreArgs& sc) {
+                                     const ScoreArgs& sc, hipEvent_t stop) {
     const int nrg = (ncell + 15) / 16;
     const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;          // column blocks of one row group share an XCD
     const int ncb = ncols / (16 * CT);
-    LAUNCH_SIGNALLING(g_project_stop_event, (level_project<CT, SP>), dim3(sc.nscore + nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc,
+    LAUNCH_SIGNALLING(stop, (level_project<CT, SP>), dim3(sc.nscore + nrgp * ncb), dim3(256), 0, st, Wfrag, K, nrg, nrgp, ncb, ncell, Lc,
                       C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
-    g_project_stop_event = nullptr;
     LAUNCHOK("level_project");
     return CLIORA_OK;
 }
 template <int CT>
 static int launch_level_project_sp(hipStream_t st, int SP, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off,
                                    const float* HP, size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm,
-                                   const ScoreArgs& sc) {
+                                   const ScoreArgs& sc, hipEvent_t stop) {
     switch (SP) {
-        case 1: return launch_level_project_inst<CT, 1>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
-        case 2: return launch_level_project_inst<CT, 2>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
-        case 3: return launch_level_project_inst<CT, 3>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
-        default: return launch_level_project_inst<CT, 4>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+        case 1: return launch_level_project_inst<CT, 1>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc, stop);
+        case 2: return launch_level_project_inst<CT, 2>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc, stop);
+        case 3: return launch_level_project_inst<CT, 3>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc, stop);
+        default: return launch_level_project_inst<CT, 4>(st, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc, stop);
     }
 }
 // h = unit(sum of the SP parts) for the level's cells (chart rows of H, raw norms) and P = h W^T + bias; sc: the next level's
 // scoring, in the same launch
 static int launch_level_project(hipStream_t st, int SP, const float* Wfrag, int K, int ncols, int ncell, int Lc, int C, int off, const float* HP,
-                                size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm, const ScoreArgs& sc) {
+                                size_t hp_stride, int normalize, const float* bias, float* P, int ldp, float* H, float* nrm, const ScoreArgs& sc,
+                                hipEvent_t stop = nullptr) {
     const int nt = ncols / 16, nrt = (ncell + 15) / 16;
     if (g_ksplit_min_blocks < 0) { const char* e = getenv("CLIORA_KSPLIT_MIN_BLOCKS"); g_ksplit_min_blocks = e ? atoi(e) : 1000; }
     // a block's MFMA work and operand bytes are fixed by its tile: wide tiles only when the launch still covers the chip
     if (nt % 5 == 0 && nrt * (nt / 5) >= g_ksplit_min_blocks)
-        return launch_level_project_sp<5>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
-    return launch_level_project_sp<1>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc);
+        return launch_level_project_sp<5>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc, stop);
+    return launch_level_project_sp<1>(st, SP, Wfrag, K, ncols, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm, sc, stop);
+}
+
+// ---- the two passes' launches of one wavefront step as ONE grid each (level_compose_fwd2 / level_project2), on the caller's stream
+template <int CT, int K16, bool F32>
+static int launch_level_compose2_inst(hipStream_t st, const ComposeSeg& a, const ComposeSeg& b, int S, int K, int ncb, const float* Pp,
+                                      size_t hp_stride, int Dp, uint32_t* ymask, float* Y) {
+    OKR(cliora_ensure_max_lds((const void*)level_compose_fwd2<CT, K16, F32>));
+    int gx = a.gx + b.gx;
+    if (gx >= 8) gx = (gx + 7) / 8 * 8;            // padding blocks return at once; column blocks of one x share an XCD (linear id = x + y * gx)
+    hipLaunchKernelGGL((level_compose_fwd2<CT, K16, F32>), dim3(gx, ncb), dim3(512), compose_lds_bytes(CT, S, true), st, a, b, S, K, Pp, hp_stride, Dp, ymask, Y);
+    LAUNCHOK("level_compose_fwd2");
+    return CLIORA_OK;
+}
+// a.Wimg / b.Wimg: the pass's plain fp32 W2 in the exact mode, its split-bf16 image otherwise (the caller picks by split_bf16())
+static int launch_level_compose2(hipStream_t st, const ComposeSeg& a, const ComposeSeg& b, int S3, int Dp, int ct, int ncb, const float* Pp,
+                                 size_t hp_stride, uint32_t* ymask, float* Y) {
+    if (a.gx + b.gx <= 0) return CLIORA_OK;
+    const bool f32 = !split_bf16();
+    const int S = f32 ? Dp : S3;
+#define LC2_ARGS st, a, b, S, Dp, ncb, Pp, hp_stride, Dp, ymask, Y
+#define LC2_CASE(c, k16) return f32 ? launch_level_compose2_inst<c, k16, true>(LC2_ARGS) : launch_level_compose2_inst<c, k16, false>(LC2_ARGS)
+    if (ct == 5 && Dp == 400) LC2_CASE(5, 25);
+    switch (ct) {
+        case 5: LC2_CASE(5, 0);
+        case 4: LC2_CASE(4, 0);
+        case 2: LC2_CASE(2, 0);
+        default: LC2_CASE(1, 0);
+    }
+#undef LC2_CASE
+#undef LC2_ARGS
+}
+// diagnostics (timing experiments, WRONG results): CLIORA_P2_DIAG bit 0: no score blocks, bit 1: no projection blocks
+static int p2_diag() { static const int d = [] { const char* e = getenv("CLIORA_P2_DIAG"); return e ? atoi(e) : 0; }(); return d; }
+template <int SP0, int SP1>
+static int launch_level_project2_inst(hipStream_t st, const ProjSeg& a_, const ProjSeg& b_) {
+    ProjSeg a = a_, b = b_;
+    if (p2_diag() & 1) { a.sc.nscore = 0; b.sc.nscore = 0; }
+    if (p2_diag() & 2) { a.nproj = 0; b.nproj = 0; }
+    const int n = a.sc.nscore + b.sc.nscore + a.nproj + b.nproj + a.nfin + b.nfin;
+    if (n <= 0) return CLIORA_OK;
+    hipLaunchKernelGGL((level_project2<SP0, SP1>), dim3(n), dim3(256), 0, st, a, b);
+    LAUNCHOK("level_project2");
+    return CLIORA_OK;
+}
+static bool project2_parts_ok(int SP) { return SP == 1 || SP == 2 || SP == 4; }      // what plan.cpp compose_geom deals (powers of two <= HP_PARTS)
+static int launch_level_project2(hipStream_t st, int SP0, int SP1, const ProjSeg& a, const ProjSeg& b) {
+#define P2_ROW(s0) \
+    switch (SP1) { case 1: return launch_level_project2_inst<s0, 1>(st, a, b); case 2: return launch_level_project2_inst<s0, 2>(st, a, b); \
+                   default: return launch_level_project2_inst<s0, 4>(st, a, b); }
+    if (!project2_parts_ok(SP0) || !project2_parts_ok(SP1)) return fail(CLIORA_EINVAL, "level_project2: parts per level must be 1, 2 or 4");
+    switch (SP0) {
+        case 1: P2_ROW(1)
+        case 2: P2_ROW(2)
+        default: P2_ROW(4)
+    }
+#undef P2_ROW
 }
 
 // Two streams pay when a level's launches carry enough work to outweigh the event per step (3 us): measured on MI355X from
@@ -208,9 +262,25 @@ static int launch_level_project(hipStream_t st, int SP, const float* Wfrag, int 
 // cliora_set_wavefront / CLIORA_WAVEFRONT=0|1 force it off / on.
 static bool wavefront_pays(const Plan& p, int env) {
     if (p.L <= 2 || env == 0) return false;
-    if (env == 1) return true;
+    if (env >= 1) return true;
     const double row_floats_per_level = (double)(p.R_in + p.R_out) / (2.0 * (p.L - 1)) * p.Dp;
     return row_floats_per_level >= 100e3;
+}
+
+// The two chains of the wavefront on ONE queue (round 5): step k = ONE compose grid over inside level k and outside level L-k
+// (level_compose_fwd2) and ONE projection / score grid for both (level_project2), on the caller's stream.  The two-stream form pays
+// a cross-stream event per step (a barrier packet on both queues: the launch behind it starts ~5 us late, profiles/r04_timeline.txt)
+// and staggers the chains; one queue needs neither.  Same tasks, same summation order: bitwise the two-stream (and the sequential)
+// results.  Text-only DioraMLP plans; cliora_set_wavefront(CLIORA_WAVEFRONT_MERGED) / CLIORA_WAVEFRONT=2 forces it, AUTO takes it
+// wherever the two-stream wavefront would pay, ON (1) keeps the two streams.
+static bool merged_pays(const Plan& p, bool vl) {
+    if (vl || p.arch != 0 || p.L <= 2) return false;
+    if (g_cliora_wavefront != 2 && !(g_cliora_wavefront < 0 && wavefront_pays(p, -1))) return false;
+    for (size_t e = 0; e < (size_t)2 * p.L; ++e) {
+        const int sp = p.persist_levels[e * PLEVEL_INTS + 6];
+        if (p.persist_levels[e * PLEVEL_INTS + 1] > 0 && !project2_parts_ok(sp)) return false;
+    }
+    return true;
 }
 
 // The level loop as ONE persistent launch (persist_kernels.hpp) when the shape allows: text-only DioraMLP, every handed-over buffer
@@ -467,10 +537,13 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
     const bool persist = !resident && !compress && persist_pays(plan, vl);
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress && !resident;
+    // round 5: the same wavefront on ONE queue -- the two passes' launches of a step as one grid each (level_compose_fwd2 /
+    // level_project2): no side stream, no event per step (merged_pays)
+    const bool merged = run_outside && !persist && !compress && !resident && merged_pays(p, vl);
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress && !resident && !merged;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
-    auto inside_step = [&](int level) -> int {          // diora.py:295-331 for one level
+    auto inside_step = [&](int level, hipEvent_t project_stop) -> int {          // diora.py:295-331 for one level
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
         g_rs_trace_buf = reinterpret_cast<unsigned long long*>(plan->persist_status + 16);
@@ -495,7 +568,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             }
         } else if (level < L - 1) {      // norm + projection of this level, and the next level's scores in the same launch
             OKR(launch_level_project(sa, SP, ws + f.wcat3, Dp, ldpi, ncell, g.Lc, C, g.off, HPi, hp_stride, p.normalize, ws + f.bcat,
-                                     ws + f.pi, ldpi, IH, ws + f.nrmi, score_args(level + 1, false, level, SP)));
+                                     ws + f.pi, ldpi, IH, ws + f.nrmi, score_args(level + 1, false, level, SP), project_stop));
         } else {
             hipLaunchKernelGGL(level_finish, dim3(cells_grid(ncell)), dim3(256), 0, sa, ncell, g.Lc, C, g.off, Dp, HPi, hp_stride, SP,
                                p.normalize, IH, ws + f.nrmi);
@@ -602,12 +675,59 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         hipLaunchKernelGGL(resident_fwd, dim3(std::min(B, std::max(1, plan->ncu))), dim3(RES_THREADS), resident_lds_bytes(p), st, a);
         LAUNCHOK("resident_fwd");
     }
-    for (int k = 1; k <= L && !persist && !resident; ++k) {
+    if (merged) {
+        const bool f32w = !split_bf16();
+        auto compose_seg = [&](int level, bool outside_pass) {
+            ComposeSeg sg{};
+            const int32_t* e = p.persist_levels.data() + ((size_t)(outside_pass ? L : 0) + level) * PLEVEL_INTS;
+            const float* w = outside_pass ? (f32w ? ws + f.w2o : ws + f.w2o3) : (f32w ? ws + f.w2i : ws + f.w2i3);
+            sg.Wimg = reinterpret_cast<const uint32_t*>(w);
+            sg.lv = pair_level(level, outside_pass);
+            sg.PA = outside_pass ? ws + f.pi + (size_t)p.blk_plo * Dp : ws + f.pi; sg.lda = ldpi;
+            sg.PB = outside_pass ? ws + f.po : ws + f.pi + Dp; sg.ldb = outside_pass ? Dp : ldpi;
+            sg.bias = outside_pass ? ws + f.b2o : ws + f.b2i;
+            sg.TG = e[5]; sg.SP = e[6]; sg.ntask = e[7];
+            // the workgroups the level's geometry was sized for (its share of the chip in this step): both segments together fit the CUs once
+            sg.gx = std::max(1, std::min(e[7], compose_cap_share(p, outside_pass ? 1 : 0, level)));
+            sg.HP = outside_pass ? HPo : HPi;
+            return sg;
+        };
+        auto project_seg = [&](int level, bool outside_pass, int SP) {
+            ProjSeg q{};
+            const LevelArgs g = level_args(p, level, outside_pass);
+            q.ncell = B * g.Lc; q.Lc = g.Lc; q.C = C; q.off = g.off; q.K = Dp;
+            q.HP = outside_pass ? HPo : HPi; q.hp_stride = hp_stride; q.normalize = p.normalize;
+            q.H = outside_pass ? OH : IH; q.nrm = ws + (outside_pass ? f.nrmo : f.nrmi);
+            const bool projects = outside_pass ? level >= 1 : level < L - 1;      // else: chart rows only (level_finish)
+            if (!projects) { q.nfin = (int)cells_grid(q.ncell); q.SPfin = SP; return q; }
+            q.nrg = ((q.ncell + 15) / 16 + P2_RT - 1) / P2_RT;          // row groups of P2_RT sixteen-row tiles
+            q.nrgp = q.nrg >= 8 ? (q.nrg + 7) / 8 * 8 : q.nrg;
+            const int ncols = outside_pass ? Dp : ldpi;
+            const int ctb = outside_pass ? P2_CTB : P2_CTA;                // column tiles per block of this segment
+            q.ntc = ncols / 16;
+            q.nproj = q.nrgp * ((q.ntc + ctb - 1) / ctb);
+            q.Wfrag = ws + (outside_pass ? f.w1ro3 : f.wcat3);
+            q.bias = outside_pass ? nullptr : ws + f.bcat;
+            q.P = ws + (outside_pass ? f.po : f.pi); q.ldp = ncols;
+            q.sc = score_args(outside_pass ? level - 1 : level + 1, outside_pass, level, SP);      // the next level of the pass, scored in the same launch
+            return q;
+        };
+        for (int k = 1; k <= L; ++k) {
+            ComposeSeg ca{}, cb{};
+            ProjSeg qa{}, qb{};
+            if (k <= L - 1) { ca = compose_seg(k, false); qa = project_seg(k, false, ca.SP); }
+            if (k >= 2) { cb = compose_seg(L - k, true); qb = project_seg(L - k, true, cb.SP); }
+            {
+                ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
+                OKR(launch_level_compose2(st, ca, cb, f.S3, Dp, f.ct3, f.ncb3, ws + f.pp, hp_stride, YM, PH));
+            }
+            OKR(launch_level_project2(st, ca.gx ? ca.SP : 1, cb.gx ? cb.SP : 1, qa, qb));
+        }
+    }
+    for (int k = 1; k <= L && !persist && !resident && !merged; ++k) {
         if (k <= L - 1) {
             const bool by_kernel = two_streams && stop_events_on() && !vl && k < L - 1;      // the step ends with a level_project launch
-            g_project_stop_event = by_kernel ? plan->ev_level[k] : nullptr;
-            OKR(inside_step(k));
-            g_project_stop_event = nullptr;
+            OKR(inside_step(k, by_kernel ? plan->ev_level[k] : nullptr));
             if (two_streams && !by_kernel) HIPOK(hipEventRecord(plan->ev_level[k], sa));
         }
         if (run_outside && k >= 2 && !compress) {
@@ -655,7 +775,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
-    OKR(cliora_persist_check(plan));                   // the forward of this step may have run as one persistent launch
+    // the forward of this step may have run as one persistent launch: its timeout word is WAITED for here (a host sync, on the persistent
+    // path only) -- an asynchronous step enqueues this backward before the word's copy has landed, and a chart left partly written must
+    // fail this call, not the next step's forward after clip + Adam have applied its gradients
+    OKR(cliora_persist_check(plan, true));
     ForkGuard fork_guard(st);
     fork_guard.arm(1, plan->side2, plan->ev_join[1]);     // the weight-gradient stream takes work at several points of the call
     const Dev dv = dev_views(p);
@@ -720,9 +843,10 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // most pair rows, the inside levels L-1, L-2, ... the fewest cells), later the inside chain (its low levels' cells have the most
     // uses): the inside levels below `sib_split` (reached in the later steps) get their sibling sums from the outside chain, the others
     // walk the list themselves.  Measured per step at c2 (profiles/r04_notes.md): inside / outside chain 57-84 / 75-103 us in steps
-    // 0-11 with everything on the outside chain, 100 / 60-99 in steps 12-19.  CLIORA_SIB_SPLIT = 0 (never) .. L (always).
+    // 0-11 with everything on the outside chain, 100 / 60-99 in steps 12-19.  CLIORA_SIB_SPLIT = 0 (never) .. L - 1 (always).
     static const int sib_env = [] { const char* e = getenv("CLIORA_SIB_SPLIT"); return e ? atoi(e) : -1; }();
-    const int sib_split = !two_streams ? 0 : sib_env >= 0 ? std::min(sib_env, L) : (L * 2) / 5;
+    // (at most L - 1: the root level L - 1 has no sibling use, and no cell_gather_bwd_sib launch ever writes its rows)
+    const int sib_split = !two_streams ? 0 : sib_env >= 0 ? std::min(sib_env, L - 1) : (L * 2) / 5;
     auto sib_on_outside_chain = [&](int s_level) { return s_level < sib_split; };
     auto sibling_runs = [&](int s_level) { return s_level >= 0 && s_level <= L - 1 && ran_outside && sib_on_outside_chain(s_level); };
     auto sibling_gather = [&](int s_level, hipEvent_t done) -> int {
@@ -797,7 +921,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     static const bool wcat_f32 = [] { const char* e = getenv("CLIORA_WCAT_GRAD"); return e && !strcmp(e, "f32"); }();
     static const int wcat_slices = [] { const char* e = getenv("CLIORA_WCAT_SLICES"); return e ? atoi(e) : 48; }();
     auto wcat_grad = [&](hipStream_t s_, int off, int hi, int accumulate) -> int {
-        if (!wcat_f32 && tn_pairs_strided_ok(Dp) && (long long)B * hi >= 512) {
+        // (the kernel's row remap floors (r + 0.5) / hi in fp32: exact below 2^22 rows -- beyond, the element-load kernel)
+        if (!wcat_f32 && tn_pairs_strided_ok(Dp) && (long long)B * hi >= 512 && (long long)B * hi < (1LL << 22)) {
             // all projection blocks in one launch + one reduction (CLIORA_WCAT_FUSED=0: a launch and a reduction per block, 48 slices each):
             // the three launches + three reductions of the low levels' part ended the step ~120 us after the inside chain.  Slices per block
             // (x 3 column blocks x nb workgroups), c2: 8 / 12 / 16 / 20 / 24 / 28 -> 3.17 / 3.14 / 3.11 / 3.11 / 3.11 / 3.15 ms (unfused 3.195)

@@ -123,13 +123,14 @@ __device__ __forceinline__ void stage_weight_image(const uint32_t* src, uint32_t
     }
 }
 
+// The tasks bx, bx + gx, ... of one level's compose launch, by one workgroup (the whole body of level_compose_fwd; the two-segment
+// kernel level_compose_fwd2 runs it on the segment its block index falls into: same tasks, same order, same bits).
 template <int CT, int K16, bool F32>
-__global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
-                                                         const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
-                                                         const float* __restrict__ bias, const float* __restrict__ Pp,
-                                                         int TG, int SP, int ntask, float* __restrict__ HP, size_t hp_stride, int Dp,
-                                                         uint32_t* __restrict__ ymask, float* __restrict__ Y) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+__device__ __forceinline__ void compose_fwd_tasks(uint32_t* lds_img, const int bx, const int gx, const uint32_t* __restrict__ Wimg, int S_, int K_,
+                                                  const PairLevel& lv, const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
+                                                  const float* __restrict__ bias, const float* __restrict__ Pp,
+                                                  int TG, int SP, int ntask, float* __restrict__ HP, size_t hp_stride, int Dp,
+                                                  uint32_t* __restrict__ ymask, float* __restrict__ Y) {
     constexpr int WAVES = 8, T = WAVES * 64, PD = 4;
     constexpr bool KS = K16 > 0;
     constexpr int UNROLL_STEPS = KS ? 64 : 1;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restr
     };
 
     bool staged = false;
-    for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
+    for (int task = bx; task < ntask; task += gx) {
         const int gg = task / SP, s = task - gg * SP;
         const int gt = gg * TG + j;                  // this wave's cell tile
         const bool have = gt < G;
@@ -285,6 +286,49 @@ __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restr
     }
 }
 
+template <int CT, int K16, bool F32>
+__global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
+                                                         const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
+                                                         const float* __restrict__ bias, const float* __restrict__ Pp,
+                                                         int TG, int SP, int ntask, float* __restrict__ HP, size_t hp_stride, int Dp,
+                                                         uint32_t* __restrict__ ymask, float* __restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    compose_fwd_tasks<CT, K16, F32>(lds_img, blockIdx.x, gridDim.x, Wimg, S_, K_, lv, PA, lda, PB, ldb, bias, Pp, TG, SP, ntask, HP, hp_stride, Dp, ymask, Y);
+}
+
+// ---------------------------------------------------------------------------------
+// level_compose_fwd2 (round 5): the compose launches of BOTH passes of one wavefront step -- inside level k and outside level L-k
+//  -- as ONE grid on ONE queue.  grid.x = seg0.gx + seg1.gx (+ padding to a multiple of 8: the column blocks of
+// one x then share an XCD): the blocks [0, seg0.gx) run segment 0's tasks with stride seg0.gx, the next seg1.gx blocks segment 1's --
+// each segment with the geometry (TG, SP, ntask) the plan gives its level, which is sized for its share of the compose workgroups
+// (plan.cpp), so a workgroup does exactly what a workgroup of the level's own launch did and the results are the same bits.  What goes
+// away is the second queue: no cross-stream event per step (a barrier packet on both queues, ~5 us each), no staggered start.
+// ---------------------------------------------------------------------------------
+struct ComposeSeg {
+    const uint32_t* Wimg;     // the pass's W2 image (split-bf16) or plain fp32 weight (exact mode)
+    PairLevel lv;
+    const float *PA, *PB, *bias;
+    int lda, ldb;
+    int TG, SP, ntask, gx;    // gx = 0: no such segment in this step
+    float* HP;
+};
+template <int CT, int K16, bool F32>
+__global__ __launch_bounds__(512) void level_compose_fwd2(ComposeSeg s0, ComposeSeg s1, int S_, int K_, const float* __restrict__ Pp, size_t hp_stride,
+                                                          int Dp, uint32_t* __restrict__ ymask, float* __restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    const bool second = (int)blockIdx.x >= s0.gx;                  // workgroup-uniform: scalar selects
+    const int bx = (int)blockIdx.x - (second ? s0.gx : 0);
+    const int gx = second ? s1.gx : s0.gx;
+    if (bx >= gx) return;                                           // padding blocks
+#define SEG(f) (second ? s1.f : s0.f)
+    PairLevel lv;
+    lv.pa = SEG(lv.pa); lv.pb = SEG(lv.pb); lv.Lc = SEG(lv.Lc); lv.N = SEG(lv.N); lv.C = SEG(lv.C); lv.ncell = SEG(lv.ncell);
+    lv.rowbase = SEG(lv.rowbase); lv.off = SEG(lv.off); lv.tilebase = SEG(lv.tilebase);
+    compose_fwd_tasks<CT, K16, F32>(lds_img, bx, gx, SEG(Wimg), S_, K_, lv, SEG(PA), SEG(lda), SEG(PB), SEG(ldb), SEG(bias), Pp, SEG(TG), SEG(SP),
+                                    SEG(ntask), SEG(HP), hp_stride, Dp, ymask, Y);
+#undef SEG
+}
+
 // sum of the SP partial aggregates of one chart row, fixed order
 template <int SP>
 __device__ __forceinline__ float4 sum_parts(const float* hp, size_t hp_stride, int k) {
@@ -327,60 +371,114 @@ struct ScoreArgs {
 };
 
 // score + softmax of one target cell (pair_scores_fwd with the newest-level operands taken from the partial aggregates)
+//
+// Wave w scores the splits n = w, w + 4, ...  Round 5: as a pipeline instead of one split after the other -- the ISA of the first form
+// was, per split, index loads -> wait -> operand rows -> wait -> the two chart scores -> wait: three dependent global round trips x five
+// splits per wave at L = 20, 10 us for the score blocks of a launch (profiles/r05_notes.md).  Now one vector load fetches the operand
+// cells of ALL of the wave's splits (lane j: split w + 4 j), the "plain" splits (both operands final: rows of QA / HB) run SCORE_KF at a
+// time with all their rows and chart scores in flight together, and the (at most two per cell) splits with an operand on the newest
+// level follow.  Same formula per split, so the same bits.
+#ifndef CLIORA_SCORE_KF
+#define CLIORA_SCORE_KF 2
+#endif
+constexpr int SCORE_KF = CLIORA_SCORE_KF;
 __device__ __forceinline__ void score_cell(const ScoreArgs& sc, int t, float* sh_s) {
     const LevelArgs& g = sc.g;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int row0 = g.rowbase + t * g.N;
     const int Dp = g.Dp, nv = Dp >> 2;
     const bool a0 = lane < nv, a1 = lane + 64 < nv;
     const int c0 = 4 * lane, c1 = 4 * (lane + 64);
     const int bC = b * g.C;
-    for (int n0 = wave; n0 < g.N; n0 += 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 4 * j;
-            if (n >= g.N) break;                     // wave-uniform
-            const int ca = sc.pa[p * g.N + n], cb = sc.pb[p * g.N + n];
-            const int ar = bC + ca, br = bC + cb;
-            const bool a_new = sc.a_can_be_new && ca >= sc.new_lo && ca < sc.new_hi;
-            const bool b_new = cb >= sc.new_lo && cb < sc.new_hi;
-            float4 u0 = f4zero(), u1 = f4zero(), v0 = f4zero(), v1 = f4zero();
-            float den = 1.f;
-            auto newest = [&](int crow, float4& x0, float4& x1) {       // h of a newest-level cell (un-normalised) and its norm
-                if (sc.HPn) {
-                    for (int sp = 0; sp < sc.SPn; ++sp) {
-                        const float* src = sc.HPn + (size_t)sp * sc.hp_stride + (size_t)crow * Dp;
-                        if (a0) x0 = f4add(x0, ld4(src + c0));
-                        if (a1) x1 = f4add(x1, ld4(src + c1));
-                    }
-                    const float nr = sqrtf(wave_sum(f4dot(x0, x0) + f4dot(x1, x1)));
-                    den = sc.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
-                } else {
-                    const float* src = (a_new ? sc.HA : sc.HB) + (size_t)crow * Dp;
-                    if (a0) x0 = ld4(src + c0);
-                    if (a1) x1 = ld4(src + c1);
-                }
-            };
-            if (a_new) {                               // partner is a leaf: QR(leaf) = M h_b
-                newest(ar, u0, u1);
-                const float* qr = sc.QRleaf + ((size_t)b * sc.L + cb) * Dp;
-                if (a0) v0 = ld4(qr + c0);
-                if (a1) v1 = ld4(qr + c1);
-            } else {
-                const float* qa = sc.QA + (size_t)ar * sc.ldA;
-                if (a0) u0 = ld4(qa + c0);
-                if (a1) u1 = ld4(qa + c1);
-                if (b_new) newest(br, v0, v1);
-                else {
-                    const float* hb = sc.HB + (size_t)br * Dp;
-                    if (a0) v0 = ld4(hb + c0);
-                    if (a1) v1 = ld4(hb + c1);
-                }
+    int my_ca = 0, my_cb = 0;                       // operand cells of this wave's split j = lane
+    {
+        const int n = wave + 4 * lane;
+        if (n < g.N) { my_ca = sc.pa[p * g.N + n]; my_cb = sc.pb[p * g.N + n]; }
+    }
+    auto is_new = [&](int ca, int cb) { return (sc.a_can_be_new && ca >= sc.new_lo && ca < sc.new_hi) || (cb >= sc.new_lo && cb < sc.new_hi); };
+    struct Plain { float4 u0, u1, v0, v1; float sa, sb; };
+    auto fetch = [&](int ca, int cb) {
+        const int ar = bC + ca, br = bC + cb;
+        Plain o{f4zero(), f4zero(), f4zero(), f4zero(), 0.f, 0.f};
+        const float* qa = sc.QA + (size_t)ar * sc.ldA;
+        const float* hb = sc.HB + (size_t)br * Dp;
+        if (a0) { o.u0 = ld4(qa + c0); o.v0 = ld4(hb + c0); }
+        if (a1) { o.u1 = ld4(qa + c1); o.v1 = ld4(hb + c1); }
+        o.sa = sc.SA[ar]; o.sb = sc.SB[br];
+        return o;
+    };
+    auto finish = [&](int n, const Plain& o) {
+        const float s = wave_sum(f4dot(o.u0, o.v0) + f4dot(o.u1, o.v1)) / 1.f + o.sa + o.sb;
+        if (lane == 0) sh_s[n] = s;
+    };
+    {
+        // SCORE_KF plain splits in flight at a time: their rows and chart scores are all issued before the first is reduced (distinct
+        // registers, fully unrolled -- a rotating "pending" copy made hipcc wait for the loads before the copy)
+        int j = 0;
+        auto next_plain = [&](int& n, int& ca, int& cb) {             // wave-uniform walk over this wave's splits
+            while (wave + 4 * j < g.N) {
+                ca = __builtin_amdgcn_readlane(my_ca, j); cb = __builtin_amdgcn_readlane(my_cb, j);
+                n = wave + 4 * j;
+                ++j;
+                if (!is_new(ca, cb)) return true;
             }
-            const float s = wave_sum(f4dot(u0, v0) + f4dot(u1, v1)) / den + sc.SA[ar] + sc.SB[br];
-            if (lane == 0) sh_s[n] = s;
+            return false;
+        };
+        while (true) {
+            Plain o[SCORE_KF];
+            int nn[SCORE_KF];
+            bool have[SCORE_KF];
+#pragma unroll
+            for (int q = 0; q < SCORE_KF; ++q) {
+                int ca = 0, cb = 0;
+                nn[q] = 0;
+                have[q] = next_plain(nn[q], ca, cb);
+                if (have[q]) o[q] = fetch(ca, cb);
+            }
+#pragma unroll
+            for (int q = 0; q < SCORE_KF; ++q)
+                if (have[q]) finish(nn[q], o[q]);
+            if (!have[SCORE_KF - 1]) break;
         }
+    }
+    for (int j = 0, n = wave; n < g.N; ++j, n += 4) {                // the splits with an operand on the newest level
+        const int ca = __builtin_amdgcn_readlane(my_ca, j), cb = __builtin_amdgcn_readlane(my_cb, j);
+        if (!is_new(ca, cb)) continue;
+        const int ar = bC + ca, br = bC + cb;
+        const bool a_new = sc.a_can_be_new && ca >= sc.new_lo && ca < sc.new_hi;
+        float4 u0 = f4zero(), u1 = f4zero(), v0 = f4zero(), v1 = f4zero();
+        float den = 1.f;
+        auto newest = [&](int crow, float4& x0, float4& x1) {       // h of a newest-level cell (un-normalised) and its norm
+            if (sc.HPn) {
+                for (int sp = 0; sp < sc.SPn; ++sp) {
+                    const float* src = sc.HPn + (size_t)sp * sc.hp_stride + (size_t)crow * Dp;
+                    if (a0) x0 = f4add(x0, ld4(src + c0));
+                    if (a1) x1 = f4add(x1, ld4(src + c1));
+                }
+                const float nr = sqrtf(wave_sum(f4dot(x0, x0) + f4dot(x1, x1)));
+                den = sc.normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+            } else {
+                const float* src = (a_new ? sc.HA : sc.HB) + (size_t)crow * Dp;
+                if (a0) x0 = ld4(src + c0);
+                if (a1) x1 = ld4(src + c1);
+            }
+        };
+        const float sa = sc.SA[ar], sb = sc.SB[br];
+        if (a_new) {                               // partner is a leaf: QR(leaf) = M h_b
+            const float* qr = sc.QRleaf + ((size_t)b * sc.L + cb) * Dp;
+            if (a0) v0 = ld4(qr + c0);
+            if (a1) v1 = ld4(qr + c1);
+            newest(ar, u0, u1);
+        } else {
+            const float* qa = sc.QA + (size_t)ar * sc.ldA;
+            if (a0) u0 = ld4(qa + c0);
+            if (a1) u1 = ld4(qa + c1);
+            newest(br, v0, v1);
+        }
+        const float s = wave_sum(f4dot(u0, v0) + f4dot(u1, v1)) / den + sa + sb;
+        if (lane == 0) sh_s[n] = s;
     }
     __syncthreads();
     if (wave != 0) return;
@@ -399,18 +497,12 @@ static __global__ __launch_bounds__(256) void level_scores(ScoreArgs sc) {
     score_cell(sc, blockIdx.x, sh_s);
 }
 
+// one projection block (16 rows x CT*16 columns) of level_project: block `bid` of nrgp * ncolblocks
 template <int CT, int SP>
-__global__ __launch_bounds__(256) void level_project(const float* __restrict__ Wfrag, int K, int nrg, int nrgp, int ncolblocks,
-                                                     int ncell, int Lc, int C, int off, const float* __restrict__ HP, size_t hp_stride,
-                                                     int normalize, const float* __restrict__ bias, float* __restrict__ P, int ldp,
-                                                     float* __restrict__ H, float* __restrict__ nrm, ScoreArgs sc) {
-    __shared__ float4 part[4][CT][64];
-    __shared__ float sh_ss[4][16];
-    if ((int)blockIdx.x < sc.nscore) {               // the next level's scores: first in the grid, so they start at once
-        score_cell(sc, blockIdx.x, &sh_ss[0][0]);
-        return;
-    }
-    const int bid = blockIdx.x - sc.nscore;
+__device__ __forceinline__ void project_block(float4 (*part)[CT][64], float (*sh_ss)[16], const int bid, const float* __restrict__ Wfrag, int K, int nrg,
+                                              int nrgp, int ncell, int Lc, int C, int off, const float* __restrict__ HP, size_t hp_stride,
+                                              int normalize, const float* __restrict__ bias, float* __restrict__ P, int ldp,
+                                              float* __restrict__ H, float* __restrict__ nrm) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -512,12 +604,27 @@ __global__ __launch_bounds__(256) void level_project(const float* __restrict__ W
     }
 }
 
+template <int CT, int SP>
+__global__ __launch_bounds__(256) void level_project(const float* __restrict__ Wfrag, int K, int nrg, int nrgp, int ncolblocks,
+                                                     int ncell, int Lc, int C, int off, const float* __restrict__ HP, size_t hp_stride,
+                                                     int normalize, const float* __restrict__ bias, float* __restrict__ P, int ldp,
+                                                     float* __restrict__ H, float* __restrict__ nrm, ScoreArgs sc) {
+    __shared__ float4 part[4][CT][64];
+    __shared__ float sh_ss[4][16];
+    (void)ncolblocks;
+    if ((int)blockIdx.x < sc.nscore) {               // the next level's scores: first in the grid, so they start at once
+        score_cell(sc, blockIdx.x, &sh_ss[0][0]);
+        return;
+    }
+    project_block<CT, SP>(part, sh_ss, (int)blockIdx.x - sc.nscore, Wfrag, K, nrg, nrgp, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
+}
+
 // levels whose cells need no projection (inside root, outside leaves): sum the partial aggregates, unit norm, chart row.
-static __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, int off, int Dp, const float* __restrict__ HP,
-                                                    size_t hp_stride, int SP, int normalize, float* __restrict__ H,
-                                                    float* __restrict__ nrm) {
+// Four cells per block (one per wave): block `blk` of cells_grid(ncell).
+__device__ __forceinline__ void finish_cells(const int blk, int ncell, int Lc, int C, int off, int Dp, const float* __restrict__ HP,
+                                             size_t hp_stride, int SP, int normalize, float* __restrict__ H, float* __restrict__ nrm) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blk * 4 + (threadIdx.x >> 6);
     if (r >= ncell) return;
     const int b = r / Lc;
     const size_t crow = (size_t)b * C + off + (r - b * Lc);
@@ -534,6 +641,203 @@ static __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, in
     if (lane < nv) st4(h + 4 * lane, make_float4(v0.x / den, v0.y / den, v0.z / den, v0.w / den));
     if (lane + 64 < nv) st4(h + 4 * (lane + 64), make_float4(v1.x / den, v1.y / den, v1.z / den, v1.w / den));
     if (lane == 0) nrm[crow] = nr;
+}
+static __global__ __launch_bounds__(256) void level_finish(int ncell, int Lc, int C, int off, int Dp, const float* __restrict__ HP,
+                                                    size_t hp_stride, int SP, int normalize, float* __restrict__ H,
+                                                    float* __restrict__ nrm) {
+    finish_cells(blockIdx.x, ncell, Lc, C, off, Dp, HP, hp_stride, SP, normalize, H, nrm);
+}
+
+// project_block with RT x CT sixteen-wide tiles per workgroup (round 5).  The per-level projections are bound by what a block pulls through
+// L2 -- a 16 x 16 block streams 25.6 KB of rows and 25.6 KB of weight fragments for ONE tile (292 MB per launch at level 1 of c2, measured
+// 16.7 us per launch with the scores off, profiles/r05_notes.md) -- so a block of RT row tiles x CT column tiles moves (RT + CT) / (RT CT)
+// of that per tile.  Every output element is still summed in the same order (four waves split the reduction, fixed LDS tree): the
+// same bits for any tile shape.  Ragged last column block (ntc column tiles in all); sh_ss: [4][RT * 16].
+template <int RT, int CT, int SP, int PD>
+__device__ __forceinline__ void project_tile(float4 (*part)[RT * CT][64], float (*sh_ss)[RT * 16], const int bid, const float* __restrict__ Wfrag, int K,
+                                             int nrg, int nrgp, int ntc, int ncell, int Lc, int C, int off, const float* __restrict__ HP,
+                                             size_t hp_stride, int normalize, const float* __restrict__ bias, float* __restrict__ P, int ldp,
+                                             float* __restrict__ H, float* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int cb = bid / nrgp, rg = bid - cb * nrgp;
+    if (rg >= nrg) return;
+    const int ct0 = cb * CT;                               // first column tile of the block
+    const int nct = min(CT, ntc - ct0);                    // ragged last block (workgroup-uniform)
+    const int nchunks = K >> 4;
+    const int cbase = nchunks / 4, crem = nchunks % 4;
+    const int ch0 = wave * cbase + min(wave, crem);
+    const int nch = cbase + (wave < crem ? 1 : 0);
+    auto crow_of = [&](int r) { const int rc = min(r, ncell - 1); const int b = rc / Lc; return (size_t)b * C + off + (rc - b * Lc); };
+    const float* hp[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) hp[r] = HP + crow_of((rg * RT + r) * 16 + li) * K;
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[PD][RT];
+    float4 rw[PD][CT];
+    auto load = [&](int slot, int ch) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) ra[slot][r] = sum_parts<SP>(hp[r], hp_stride, 16 * (ch0 + ch) + 4 * lq);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (c < nct) rw[slot][c] = reinterpret_cast<const float4*>(Wfrag)[((size_t)(ct0 + c) * nchunks + ch0 + ch) * 64 + lane];
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl)
+        if (sl < nch) load(sl, sl);
+    float ss[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) ss[r] = 0.f;
+    for (int base = 0; base < nch; base += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+            if (base + sl < nch) {
+                float4 a[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) { ss[r] += f4dot(ra[sl][r], ra[sl][r]); a[r] = to_mfma_lanes(psrc, ra[sl][r]); }
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma16(rw[sl][c].x, a[r].x, acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma16(rw[sl][c].y, a[r].y, acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma16(rw[sl][c].z, a[r].z, acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma16(rw[sl][c].w, a[r].w, acc[r][c]);
+                if (base + sl + PD < nch) load(sl, base + sl + PD);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) part[wave][r * CT + c][lane] = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
+        float s_ = ss[r];
+        s_ += __shfl_xor(s_, 1);                 // the four fetch lanes of a row
+        s_ += __shfl_xor(s_, 2);
+        if (lq == 0) sh_ss[wave][r * 16 + li] = s_;
+    }
+    __syncthreads();
+    auto den_of = [&](int r16, float* raw) {
+        const float nr = sqrtf(((sh_ss[0][r16] + sh_ss[1][r16]) + sh_ss[2][r16]) + sh_ss[3][r16]);
+        if (raw) *raw = nr;
+        return normalize ? fmaxf(nr, UNIT_EPS) : 1.f;
+    };
+    for (int t = wave; t < RT * CT; t += 4) {
+        const int r = t / CT, c = t - r * CT;
+        if (c >= nct) continue;
+        const float den = den_of(r * 16 + i, nullptr);
+        const int row = (rg * RT + r) * 16 + i;
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                               ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        v = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+        const int col = (ct0 + c) * 16 + 4 * q;
+        if (bias) v = f4add(v, ld4(bias + col));
+        if (row < ncell) st4(P + crow_of(row) * ldp + col, v);
+    }
+    if (cb == 0 && H) {                       // chart output of the level (see project_block): wave w writes rows w, w+4, ... of each row tile
+        const int nv = K >> 2;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            float4 a[4][2];
+            size_t crow[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = (rg * RT + r) * 16 + wave + 4 * k;
+                crow[k] = crow_of(rr);
+                const float* src = HP + crow[k] * K;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int v4 = lane + 64 * it;
+                    a[k][it] = (rr < ncell && v4 < nv) ? sum_parts<SP>(src, hp_stride, 4 * v4) : f4zero();
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r16 = wave + 4 * k, rr = (rg * RT + r) * 16 + r16;
+                if (rr >= ncell) break;
+                float nr;
+                const float d = den_of(r * 16 + r16, &nr);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int v4 = lane + 64 * it;
+                    if (v4 < nv) st4(H + crow[k] * K + 4 * v4, make_float4(a[k][it].x / d, a[k][it].y / d, a[k][it].z / d, a[k][it].w / d));
+                }
+                if (lane == 0) nrm[crow[k]] = nr;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// level_project2 (round 5): the second launch of a wavefront step for BOTH passes -- norm + projection of inside level k and of outside
+// level L-k, the chart rows of a level that needs no projection (level_finish: inside root, outside leaves), and the split scores +
+// softmax of the next level of either pass -- as ONE grid on one queue.  Block order: the scores first (they are the latency chains of
+// the launch), then segment 0's projection blocks, segment 1's, then the finish blocks.  16 x 16 tiles (CT = 1: the variant every
+// sweep of the block size preferred, profiles/r04_notes.md); SP0 / SP1 = parts of the two levels' partial aggregates.  Every block runs
+// the code of level_project / level_finish on its own segment: the same bits as the per-pass launches.
+// ---------------------------------------------------------------------------------
+struct ProjSeg {
+    const float* Wfrag; int K, nrg, nrgp, ntc, ncell, Lc, C, off;      // nrg row groups of P2_RT row tiles (nrgp: padded to 8), ntc column tiles
+    const float* HP; size_t hp_stride; int normalize; const float* bias; float* P; int ldp; float* H; float* nrm;
+    int nproj;            // projection blocks (nrgp * ceil(ntc / column tiles per block)); 0: none
+    int nfin, SPfin;      // level_finish blocks (cells_grid(ncell)) and the level's parts; 0: none
+    ScoreArgs sc;         // sc.nscore = 0: no scoring
+};
+// tile shape of level_project2's projection blocks: RT row tiles x CTA (segment 0: inside, 75 column tiles at d 400) / CTB (segment 1:
+// outside, 25) column tiles, PD chunks of the reduction in flight per wave.  Build-time (tools/ab: -DCLIORA_P2_RT=.. etc.)
+#ifndef CLIORA_P2_RT
+#define CLIORA_P2_RT 1
+#endif
+#ifndef CLIORA_P2_CTA
+#define CLIORA_P2_CTA 1
+#endif
+#ifndef CLIORA_P2_CTB
+#define CLIORA_P2_CTB 1
+#endif
+#ifndef CLIORA_P2_PD
+#define CLIORA_P2_PD 4
+#endif
+constexpr int P2_RT = CLIORA_P2_RT, P2_CTA = CLIORA_P2_CTA, P2_CTB = CLIORA_P2_CTB, P2_PD = CLIORA_P2_PD;
+constexpr int P2_CTM = P2_CTA > P2_CTB ? P2_CTA : P2_CTB;
+template <int SP0, int SP1>
+__global__ __launch_bounds__(256) void level_project2(ProjSeg a, ProjSeg b) {
+    __shared__ float4 part[4][P2_RT * P2_CTM][64];
+    __shared__ float sh_ss[4][P2_RT * 16];
+    int bid = blockIdx.x;
+    if (bid < a.sc.nscore) { score_cell(a.sc, bid, &sh_ss[0][0]); return; }
+    bid -= a.sc.nscore;
+    if (bid < b.sc.nscore) { score_cell(b.sc, bid, &sh_ss[0][0]); return; }
+    bid -= b.sc.nscore;
+    if (bid < a.nproj) {
+        project_tile<P2_RT, P2_CTA, SP0, P2_PD>(reinterpret_cast<float4 (*)[P2_RT * P2_CTA][64]>(&part[0][0][0]), sh_ss, bid, a.Wfrag, a.K, a.nrg, a.nrgp, a.ntc,
+                                                a.ncell, a.Lc, a.C, a.off, a.HP, a.hp_stride, a.normalize, a.bias, a.P, a.ldp, a.H, a.nrm);
+        return;
+    }
+    bid -= a.nproj;
+    if (bid < b.nproj) {
+        project_tile<P2_RT, P2_CTB, SP1, P2_PD>(reinterpret_cast<float4 (*)[P2_RT * P2_CTB][64]>(&part[0][0][0]), sh_ss, bid, b.Wfrag, b.K, b.nrg, b.nrgp, b.ntc,
+                                                b.ncell, b.Lc, b.C, b.off, b.HP, b.hp_stride, b.normalize, b.bias, b.P, b.ldp, b.H, b.nrm);
+        return;
+    }
+    bid -= b.nproj;
+    if (bid < a.nfin) { finish_cells(bid, a.ncell, a.Lc, a.C, a.off, a.K, a.HP, a.hp_stride, a.SPfin, a.normalize, a.H, a.nrm); return; }
+    bid -= a.nfin;
+    if (bid < b.nfin) finish_cells(bid, b.ncell, b.Lc, b.C, b.off, b.K, b.HP, b.hp_stride, b.SPfin, b.normalize, b.H, b.nrm);
 }
 
 // ---------------------------------------------------------------------------------

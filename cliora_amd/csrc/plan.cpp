@@ -47,6 +47,25 @@ ComposeGeom compose_geom_rs(int ncell, int N) {
     return best;
 }
 
+// Compose workgroups per column block that level `lv` of a pass (0 inside, 1 outside) may count on: step k of the forward composes
+// inside level k and outside level L-k side by side, so each gets its share of compose_cap -- by pair rows
+// (shared weights: any workgroup serves either pass), or the half that holds its weight image (unshared).
+int compose_cap_share(const Plan& p, int pass, int lv) {
+    const int L = p.L;
+    const int k = pass ? L - lv : lv;                      // the step this level runs in
+    const bool has_in = k >= 1 && k <= L - 1, has_out = k >= 2 && k <= L;
+    int cap = p.compose_cap;
+    if (has_in && has_out && cap >= 2) {
+        if (!p.share) cap = cap / 2;
+        else {
+            const double rows_in = (double)(L - k) * k, rows_out = (double)k * (k - 1);
+            const int cap_in = std::min(cap - 1, std::max(1, (int)(cap * rows_in / (rows_in + rows_out) + 0.5)));
+            cap = pass ? cap - cap_in : cap_in;
+        }
+    }
+    return cap;
+}
+
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch) {
     if (B < 1 || L < 1 || D < 1) return "B, L, D must be positive";
     if (D > 512) return "D > 512 is not supported by the weight-stationary kernels";
@@ -281,18 +300,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
             e[0] = Lc; e[1] = N; e[2] = p.level_offset[lv];
             e[3] = (int32_t)(pass ? p.row_base_out(lv) : p.row_base_in(lv));
             e[4] = pass ? p.lvl_base_out[lv] : p.lvl_base_in[lv];
-            const int k = pass ? L - lv : lv;                      // the step this level runs in
-            const bool has_in = k >= 1 && k <= L - 1, has_out = k >= 2 && k <= L;
-            int cap = p.compose_cap;
-            if (has_in && has_out && cap >= 2) {
-                if (!p.share) cap = cap / 2;
-                else {
-                    const double rows_in = (double)(L - k) * k, rows_out = (double)k * (k - 1);
-                    const int cap_in = std::min(cap - 1, std::max(1, (int)(cap * rows_in / (rows_in + rows_out) + 0.5)));
-                    cap = pass ? cap - cap_in : cap_in;
-                }
-            }
-            const ComposeGeom q = compose_geom(B * Lc, N, cap);
+            const ComposeGeom q = compose_geom(B * Lc, N, compose_cap_share(p, pass, lv));
             e[5] = q.TG; e[6] = q.SP; e[7] = q.ntask;
         }
     return "";

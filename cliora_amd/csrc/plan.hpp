@@ -132,6 +132,7 @@ struct Plan {
 // each), the split range cut in SP parts, ntask = ceil(G / TG) * SP workgroup tasks; `cap` workgroups per column block.
 struct ComposeGeom { int TG, SP, ntask; };
 ComposeGeom compose_geom(int ncell, int N, int cap);
+int compose_cap_share(const Plan& p, int pass, int lv);   // the cap a level's geometry is sized for: its share of Plan::compose_cap in its wavefront step
 // Geometry of the rows-stationary compose kernel (compose_rs_kernels.hpp): every wave takes ONE split, so a task covers
 // SP x (8 / TG) split slots >= N; the fullest slot table wins, fewer parts on a tie.  TG = 0: no such geometry (N > 32).
 ComposeGeom compose_geom_rs(int ncell, int N);

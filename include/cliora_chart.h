@@ -310,6 +310,11 @@ int cliora_set_mfma_mode(int mode);
 #define CLIORA_WAVEFRONT_AUTO (-1)
 #define CLIORA_WAVEFRONT_OFF 0
 #define CLIORA_WAVEFRONT_ON 1
+/* MERGED (round 5; text-only DioraMLP plans): the same wavefront on ONE queue -- step k runs ONE compose grid over inside level k and
+ * outside level L-k and ONE projection / score grid for both, on the caller's stream: no side stream and no cross-stream event per
+ * step.  AUTO takes it wherever the two-stream form would pay; ON keeps the two streams; other plans treat MERGED as ON.  Bitwise the
+ * same results again (CLIORA_WAVEFRONT=2). */
+#define CLIORA_WAVEFRONT_MERGED 2
 int cliora_set_wavefront(int mode);
 
 /* The level loop as one launch.  By default (CLIORA_PERSISTENT_AUTO; the environment variable CLIORA_PERSISTENT=0|1 sets the
@@ -326,8 +331,10 @@ int cliora_set_wavefront(int mode);
 int cliora_set_persistent(int mode);
 int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
 /* A persistent launch that gives up on a barrier leaves its charts partly written.  The library does not let that pass silently:
- * the timeout word follows every persistent launch to pinned host memory, and the next cliora_chart_forward /
- * cliora_chart_backward on the device (normally the backward of the same step) returns CLIORA_EHIP once the word has moved.
+ * the timeout word follows every persistent launch to pinned host memory.  cliora_chart_backward WAITS for the word of the last
+ * persistent launch on the device (a host synchronisation, on the persistent path only) and returns CLIORA_EHIP if it has moved --
+ * so the backward of the same step fails before any gradient is produced; cliora_chart_forward looks at it without waiting
+ * (an inference loop sees the failure at its next call).
  * cliora_persistent_inject_timeout (diagnostics, tests) counts one such give-up in the device word without any launch failing. */
 int cliora_persistent_inject_timeout(cliora_plan* plan, void* stream);
 

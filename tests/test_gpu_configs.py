@@ -340,9 +340,11 @@ def test_c2_full_size_gradients_vs_fp64(mfma_mode):
         if dt not in _FP64_CASE:                 # the same two CPU runs serve both arithmetic modes of the GPU path (25 s each)
             Pd = {k: v.detach().to(dt).requires_grad_(True) for k, v in P.items()}
             xd = x.detach().to(dt).requires_grad_(True)
-            o = R.diora_forward(Pd, xd, xd, training=True)
+            o = R.diora_forward(Pd, xd, xd, training=True, keep_pairs=(dt == torch.float32))
             sum((o[k] * cot[k].to(dt)).sum() for k in keys).backward()
             _FP64_CASE[dt] = (Pd, xd, {k: o[k].detach() for k in keys})
+            if dt == torch.float32:              # the reference's trees of all 64 sentences (analysis/cky.py:31-99 on the oracle's split scores)
+                _FP64_CASE['trees'] = [str(t) for t in R.cky_trees(o['pair_s_in'], B, L)]
         return _FP64_CASE[dt]
     P64, x64, o64 = oracle(torch.float64)
     P32, x32, o32 = oracle(torch.float32)
@@ -357,6 +359,14 @@ def test_c2_full_size_gradients_vs_fp64(mfma_mode):
         report['out.' + k] = dict(hip=_dist(getattr(m, k), o64[k].detach()), fp32_oracle=_dist(o32[k], o64[k].detach()))
         # every chart of all 64 sentences against the fp32 oracle (the reference's arithmetic): the north-star 1e-4
         assert _err(getattr(m, k), o32[k]) <= 1e-4 * _scale(o32[k]), (k, _err(getattr(m, k), o32[k]))
+    # "trees identical to reference" on the headline configuration itself: all 64 sentences, in this arithmetic mode (eval forward + GPU CKY)
+    m.eval()
+    with torch.no_grad():
+        xe = x.clone().cuda()
+        m(xe, xe)
+        got = [str(t) for t in m.cky()]
+    m.train()
+    assert got == _FP64_CASE['trees'], [b for b in range(B) if got[b] != _FP64_CASE['trees'][b]]
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'accuracy_fp64_%s.json' % mfma_mode), 'w') as f:
         json.dump(dict(mode=mfma_mode, D=D, B=B, L=L, unit='error / max|fp64 value| of the tensor', tensors=report), f, indent=1)

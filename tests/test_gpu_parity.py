@@ -192,7 +192,7 @@ def test_full_size_c2_properties(mfma_mode):
         assert _err(p.grad, 2.0 * g1[n]) <= 1e-4 * _scale(g1[n]), n
 
 
-@pytest.mark.parametrize('D,B,L,share', [(400, 64, 20, True), (96, 16, 12, False), (48, 5, 9, True)])
+@pytest.mark.parametrize('D,B,L,share', [(400, 64, 20, True), (96, 16, 12, False), (48, 5, 9, True), (400, 3, 33, True), (64, 7, 3, True)])
 def test_wavefront_is_bitwise_the_sequential_order(D, B, L, share, mfma_mode):
     """The two passes on two streams (include/cliora_chart.h: cliora_set_wavefront) against the reference's order on one stream:
     the same kernels on the same data, only scheduled differently -- every output and gradient bit must agree, run after run
@@ -205,17 +205,19 @@ def test_wavefront_is_bitwise_the_sequential_order(D, B, L, share, mfma_mode):
     try:
         outs0, xg0 = _run_gpu(m, x, cot)
         g0 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
-        _lib.set_wavefront('on')
-        for rep in range(3):
-            for p_ in m.parameters():
-                p_.grad = None
-            outs1, xg1 = _run_gpu(m, x, cot)
-            for k in CHARTS:
-                assert torch.equal(outs0[k], outs1[k]), (k, rep)
-            for n, p_ in m.named_parameters():
-                if p_.grad is not None:
-                    assert torch.equal(g0[n], p_.grad), (n, rep)
-            assert torch.equal(xg0.grad, xg1.grad), rep
+        # 'on': two chains on two streams; 'merged' (round 5): the two passes' launches of a step as ONE grid on the caller's stream
+        for mode in ('on', 'merged'):
+            _lib.set_wavefront(mode)
+            for rep in range(3):
+                for p_ in m.parameters():
+                    p_.grad = None
+                outs1, xg1 = _run_gpu(m, x, cot)
+                for k in CHARTS:
+                    assert torch.equal(outs0[k], outs1[k]), (mode, k, rep)
+                for n, p_ in m.named_parameters():
+                    if p_.grad is not None:
+                        assert torch.equal(g0[n], p_.grad), (mode, n, rep)
+                assert torch.equal(xg0.grad, xg1.grad), (mode, rep)
     finally:
         _lib.set_wavefront(prev)
 

@@ -27,3 +27,22 @@ def test_bench_force_dist_runs_rccl_at_world_size_one():
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0
     ge = d['config'].get('gradient_exchange', '')
     assert ge.startswith('RCCL') and '; 0 of ' in ge, d['config']        # every gradient written in place by the chart backward
+
+
+def test_bench_c3_force_dist_runs_the_cliora_step_through_rccl():
+    """BASELINE configs[3] is `bench.py --gpus 8 --workload c3`; its per-rank step (CLIORA training step: Embed, ImageEncoder, chart with
+    regions, three losses, backward, ONE flat all-reduce of chart + head + ImageEncoder gradients, clip + Adam; trainer.py:437-501, 572-574)
+    runs here at world size 1 through RCCL, as a child process: the CLIORA parameter set goes through the flat buffer on the GPU."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--workload', 'c3', '--force-dist', '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert lines, r.stdout[-2000:]
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0
+    assert 'configs[2]' in d['config']['workload'] and d['config']['global_batch'] == 64
+    ge = d['config'].get('gradient_exchange', '')
+    assert ge.startswith('RCCL') and '; 0 of ' in ge, d['config']        # chart, head and ImageEncoder gradients all written in place

@@ -14,6 +14,7 @@ ap.add_argument('--length', type=int, default=20)
 ap.add_argument('--dim', type=int, default=400)
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=30)
+ap.add_argument('--only', default='', help="'fwd': the training-mode forward alone (for kernel traces)")
 a = ap.parse_args()
 torch.manual_seed(1234)
 m = DioraMLP(a.dim).cuda()
@@ -50,4 +51,7 @@ def step():
     torch.autograd.backward([getattr(m, k) for k in keys], cots)
 
 
+if a.only == 'fwd':
+    print('forward (training) %.3f ms' % timeit(fwd_grad, a.steps))
+    sys.exit(0)
 print('forward (no_grad) %.3f ms | forward (training) %.3f ms | forward+backward %.3f ms' % (timeit(fwd_nograd, a.steps), timeit(fwd_grad, a.steps), timeit(step, a.steps)))

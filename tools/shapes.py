@@ -63,6 +63,8 @@ if __name__ == '__main__':
              ('DioraMLP len 40', lambda: DioraMLP(400), 64, 40, 400, 0, 8, 2),
              ('c5 DioraTreeLSTM len 20', lambda: DioraTreeLSTM(400), 64, 20, 400, 0, 20, 5),
              ('c5 DioraTreeLSTM len 40', lambda: DioraTreeLSTM(400), 64, 40, 400, 0, 8, 2)]
+    # SHAPES_STEPS / SHAPES_WARMUP: short runs for the --pmc passes (tools/pmc_shape.sh counts steps + warmup launches of every kernel)
+    ovs, ovw = os.environ.get('SHAPES_STEPS'), os.environ.get('SHAPES_WARMUP')
     for name, make, B, L, D, R, steps, warmup in cases:
         if only in name:
-            run(name, make, B, L, D, R=R, steps=steps, warmup=warmup)
+            run(name, make, B, L, D, R=R, steps=int(ovs) if ovs else steps, warmup=int(ovw) if ovw else warmup)
