@@ -126,6 +126,65 @@ def cpu_baseline(L, D, B, budget_s=25.0):
                 host=host_cpu(), one_thread=one, port_vs_reference=port_vs_reference())
 
 
+def cpu_baseline_c3(L, D, B, budget_s=20.0):
+    """The CPU oracle's CLIORA training step (oracle/diora_ref.py: Embed, ImageEncoder, chart with regions, reconstruction + VG + contrastive
+    losses, backward; the reference's op sequence incl. its B x B region attention, cliora.py:35-42) on this host: a BOUNDED sample at a
+    reduced batch -- the reference's cost per sentence grows with the batch (every text-image pair of the batch is scored), so the sample's
+    batch is stated; clip + Adam are left out (negligible beside the step)."""
+    import torch
+    from oracle import diora_ref as R
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    V, E, K, Rg = 10000, 1024, 100, 36
+    g = torch.Generator().manual_seed(1234)
+    P = R.init_params(D, share=True, seed=1234)
+    rn = lambda *s, std=1.0: (torch.randn(*s, generator=g) * std).requires_grad_(True)
+    emb_w, mat, mat1, rmat = rn(V, E), rn(D, E), rn(D, E), rn(D, E)
+    Wf, bf, Wv, bv = rn(D, 2048, std=0.02), rn(D, std=0.02), rn(D, 2048, std=0.02), rn(D, std=0.02)
+    for v in P.values():
+        v.requires_grad_(True)
+
+    def step(b):
+        sentences = torch.randint(0, V, (b, L), generator=g)
+        neg = torch.randperm(V, generator=g)[:K]
+        obj = torch.relu(torch.randn(b, Rg, 2048, generator=g))
+        t0 = time.perf_counter()
+        xs, xw = R.embed_forward(emb_w, mat, mat1, sentences)
+        os_, ow = R.image_encoder_forward(Wf, bf, Wv, bv, obj)
+        ref = R.diora_forward(P, xs, xw, os_, ow, training=True)
+        loss = (R.reconstruction_loss(emb_w, rmat, sentences, neg, ref['outside_h']) + R.vg_loss(ref['vg_atten_score'], 1.0)
+                + R.contrastive_loss(ref['inside_s'], ref['outside_s'], ref['all_atten_score'], 0.2, 1.0))
+        loss.backward()
+        return time.perf_counter() - t0
+
+    step(2)
+    t8 = step(8)
+    b = 16 if t8 * 2.5 < budget_s / 2 else 8
+    times = [step(b) for _ in range(2 if t8 * (b / 8.0) * 2 < budget_s else 1)]
+    med = sorted(times)[len(times) // 2]
+    return dict(value=b / med, unit='sentences/s', cores=threads, kind='port',
+                sample='%d step(s) of %d sentences (L=%d, d=%d, 36 regions x 2048-d, V 10000, k_neg 100): oracle Net forward + three losses + backward, '
+                       'torch %s, %d threads, %.2f s/step (the GPU line runs 64 per rank)' % (len(times), b, L, D, torch.__version__, threads, med),
+                host=host_cpu(), port_vs_reference=port_vs_reference())
+
+
+def shape_traffic(label):
+    """Committed PMC traffic per step of one of the other workloads (tools/pmc_shape.sh: 2 x FETCH_SIZE + WRITE_SIZE over every kernel of a
+    3-step run, own --pmc passes), or None."""
+    fp = os.path.join(ROOT, 'profiles', 'r05_traffic_shapes.json')
+    if not os.path.exists(fp):
+        return None
+    try:
+        j = json.load(open(fp)).get(label)
+    except (OSError, ValueError):
+        return None
+    if not j:
+        return None
+    return dict(bytes_per_step=j['total_bytes_per_step'], file='profiles/r05_traffic_shapes.json', commit=j.get('commit', 'not recorded'),
+                kind='committed rocprofv3 PMC figure (2 x FETCH_SIZE + WRITE_SIZE over every kernel of the step), not collected in this run',
+                top_kernels=dict(list(j.get('by_kernel', {}).items())[:5]))
+
+
 def algorithmic_bytes(plan, B, D, cell_floats=None):
     """forward bytes per level = (unique chart cells read + cells written) x (D + 1) x 4, from the
     plan's own index tables (the reference's tables, tests/test_plan_tables.py); backward = 2 x forward.  Returns
@@ -189,7 +248,7 @@ def other_measurements(torch, dev, budget_steps=12):
     from cliora_amd.treelstm import DioraTreeLSTM
     out = {}
 
-    def chart(make, B, L, D, R=0, steps=budget_steps, warmup=3, arch=0):
+    def chart(make, B, L, D, R=0, steps=budget_steps, warmup=3, arch=0, tag=None):
         torch.manual_seed(0)
         m = make().to(dev).train()
         for p in m.parameters():
@@ -222,7 +281,7 @@ def other_measurements(torch, dev, budget_steps=12):
             plan = _lib.get_plan(B, L, D, True, 'unit', R, dev.index or 0, arch=arch)
             step_bytes, _ = algorithmic_bytes(plan, B, D, cell_floats=(2 * D + 1) if arch == 1 else None)
             res['roofline'] = dict(bound='hbm', algorithmic_bytes=round(step_bytes), achieved_GBs=round(step_bytes / dt / 1e9, 1), peak_GBs=PEAK_HBM_GBS,
-                                   frac=round(step_bytes / dt / 1e9 / PEAK_HBM_GBS, 4))
+                                   frac=round(step_bytes / dt / 1e9 / PEAK_HBM_GBS, 4), traffic=shape_traffic(tag) if tag else None)
         except Exception as e:                                # noqa: BLE001
             res['roofline'] = 'failed: %s' % str(e)[:120]
         return res
@@ -277,10 +336,10 @@ def other_measurements(torch, dev, budget_steps=12):
         return dict(B=B, L=L, D=D, ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1),
                     ms_per_step_without_per_step_item=round(res[False] * 1e3, 3))
 
-    cases = (('c1 DioraMLP d50 B8 L10', lambda: chart(lambda: DioraMLP(50), 8, 10, 50)),
-             ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36)),
-             ('DioraMLP d400 B64 L40', lambda: chart(lambda: DioraMLP(400), 64, 40, 400, steps=6, warmup=2)),
-             ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2, arch=1)),
+    cases = (('c1 DioraMLP d50 B8 L10', lambda: chart(lambda: DioraMLP(50), 8, 10, 50, tag='c1')),
+             ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36, tag='c3')),
+             ('DioraMLP d400 B64 L40', lambda: chart(lambda: DioraMLP(400), 64, 40, 400, steps=6, warmup=2, tag='l40')),
+             ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2, arch=1, tag='c5')),
              ('parse c2 (eval forward + CKY trees on the GPU, trees copied to the host)', parse),
              ('whole step DIORA c2 (Embed, chart, reconstruction loss, clip, Adam)', lambda: whole(False)),
              ('whole step CLIORA c3 (+ ImageEncoder, VG and contrastive losses)', lambda: whole(True)))
@@ -355,9 +414,9 @@ def cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, u
                             note='per-step device time from HIP event pairs on the launch stream inside the timed region (rank 0)'),
             'roofline': dict(bound='hbm', kernel='whole step (no single dominant kernel is timed for this workload; see --workload c2)',
                              achieved=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                             frac=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4), traffic=None,
+                             frac=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4), traffic=shape_traffic('c3_step'),
                              model='SURVEY.md section 8(d) chart bytes (%d per step) + the (B, B, C, 36) scorer tensor three times (%d)' % (step_bytes, scorer_bytes)),
-            'cpu_baseline': None,
+            'cpu_baseline': cpu_baseline_c3(L, D, B) if (world == 1 and not args.no_cpu_baseline) else None,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

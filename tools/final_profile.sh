@@ -3,16 +3,17 @@
 # Every rocprofv3 run is its own pass (kernel-trace only next to --pmc); summaries are copied to profiles/ by hand.
 #   gpurun -- "GRAFT_COMMIT=$(git rev-parse --short HEAD) bash tools/final_profile.sh"      (the box has no .git)
 set -x
+# every long command under its own `timeout` (a hung profiler run once cost a whole gpurun call)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
-python tools/shapes.py > $O/shapes.jsonl 2>&1
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
+timeout 600 python tools/shapes.py > $O/shapes.jsonl 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-events --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ks -- $B --steps 10 --warmup 3 > $O/prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o fetch -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc -o write -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc -o mfma -- $B --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ks -- $B --steps 10 --warmup 3 > $O/prof.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o fetch -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc -o write -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc -o mfma -- $B --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
 cd $R
 python tools/timeline.py $O/prof/ks_kernel_trace.csv > $O/timeline.txt 2>&1
 python tools/summarize_pmc.py $O/pmc/fetch_counter_collection.csv $O/pmc_fetch_by_kernel.csv
@@ -24,4 +25,14 @@ for c in "c1 DioraMLP" "c3 CLIORA" "DioraMLP len 40" "c5 DioraTreeLSTM len 40"; 
   t=$(echo $c | tr -d ' ' | tr 'A-Z' 'a-z'); bash tools/prof_shape.sh fin_$t "$c" > $O/stats_$t.txt 2>&1; cp gpurun_out/prof/fin_${t}_kernel_stats.csv $O/ 2>/dev/null
 done
 rm -f gpurun_out/prof/fin_*_kernel_trace.csv
+# PMC passes of the other workloads (round 5: traffic per step of the throughput-bound shapes and of the CLIORA training step)
+export SHAPES_STEPS=2 SHAPES_WARMUP=1
+bash tools/pmc_shape.sh l40 3 python3 tools/shapes.py "DioraMLP len 40" > $O/pmc_l40.txt 2>&1
+bash tools/pmc_shape.sh c5 3 python3 tools/shapes.py "c5 DioraTreeLSTM len 40" > $O/pmc_c5.txt 2>&1
+bash tools/pmc_shape.sh c3 3 python3 tools/shapes.py "c3 CLIORA" > $O/pmc_c3.txt 2>&1
+bash tools/pmc_shape.sh c1 3 python3 tools/shapes.py "c1 DioraMLP" > $O/pmc_c1.txt 2>&1
+bash tools/pmc_shape.sh c3_step 3 python3 bench.py --workload c3 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_c3_step.txt 2>&1
+unset SHAPES_STEPS SHAPES_WARMUP
+cp gpurun_out/traffic_shapes.json gpurun_out/pmc_*_by_kernel.csv gpurun_out/pmc_*_mfma_busy.csv $O/ 2>/dev/null
+timeout 900 python tools/wavefront_sweep.py > $O/wavefront_sweep.txt 2>&1
 ls -la $O $O/prof

@@ -11,7 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cliora_amd.diora import DioraMLP                       # noqa: E402
 
 dev = torch.device('cuda:0')
-for B, L, D in ((64, 40, 400), (128, 20, 400), (256, 20, 400), (32, 40, 400), (64, 20, 48), (8, 10, 50), (128, 30, 400)):
+SHAPES = ((16, 20, 400), (32, 20, 400), (64, 20, 400), (128, 20, 400), (256, 20, 400), (64, 40, 400), (32, 40, 400), (128, 30, 400), (64, 20, 48), (8, 10, 50))
+series = []
+for B, L, D in SHAPES:
     torch.manual_seed(0)
     m = DioraMLP(D).to(dev).train()
     for p in m.parameters():
@@ -36,6 +38,18 @@ for B, L, D in ((64, 40, 400), (128, 20, 400), (256, 20, 400), (32, 40, 400), (6
         step()
     torch.cuda.synchronize()
     R = B * (L - 1) * L * (L + 1) // 2
+    if L == 20 and D == 400:
+        series.append((B, (time.perf_counter() - t0) / n * 1e3))
     print('wavefront=%s B %3d L %2d D %3d: %8.3f ms/step   (%d pair rows, %.0f per level)' % (os.environ.get('CLIORA_WAVEFRONT', '1'), B, L, D, (time.perf_counter() - t0) / n * 1e3, R, R / (2 * (L - 1))), flush=True)
     del m, x, cot
     torch.cuda.empty_cache()
+
+# the one figure that says which half of the step an idea can touch: a least-squares line ms(B) = latency + per_sentence * B over the L 20 / d 400 runs
+if len(series) >= 2:
+    nB = len(series)
+    sx, sy = sum(b for b, _ in series), sum(t for _, t in series)
+    sxx, sxy = sum(b * b for b, _ in series), sum(b * t for b, t in series)
+    slope = (nB * sxy - sx * sy) / (nB * sxx - sx * sx)
+    icpt = (sy - slope * sx) / nB
+    print('L 20 / d 400: step ms = %.3f (dependent latency) + %.4f x B (throughput-bound work per sentence); at B 64: %.2f + %.2f ms'
+          % (icpt, slope, icpt, slope * 64))
