@@ -294,11 +294,13 @@ def other_measurements(torch, dev, budget_steps=12):
             torch.nn.init.normal_(p)
         x = torch.randn(B, L, D, device=dev)
         res = {}
-        for with_cky in (False, True):
+        for what in ('forward', 'spans', 'trees'):
             def step():
                 with torch.no_grad():
                     m(x, x)
-                    return m.cky() if with_cky else None
+                    if what == 'spans':
+                        return m.cky_spans()              # (B, L-1, 2) ints on the host: what the F1 evaluation consumes (scripts/train.py:184-204)
+                    return m.cky() if what == 'trees' else None
             for _ in range(warmup):
                 step()
             torch.cuda.synchronize()
@@ -306,9 +308,10 @@ def other_measurements(torch, dev, budget_steps=12):
             for _ in range(steps):
                 step()
             torch.cuda.synchronize()
-            res[with_cky] = (time.perf_counter() - t0) / steps
-        return dict(B=B, L=L, D=D, ms_forward=round(res[False] * 1e3, 3), ms_forward_and_trees=round(res[True] * 1e3, 3),
-                    sentences_per_s=round(B / res[True], 1))
+            res[what] = (time.perf_counter() - t0) / steps
+        return dict(B=B, L=L, D=D, ms_forward=round(res['forward'] * 1e3, 3), ms_forward_and_spans=round(res['spans'] * 1e3, 3),
+                    ms_forward_and_trees=round(res['trees'] * 1e3, 3), sentences_per_s=round(B / res['spans'], 1),
+                    note='spans: the device-built constituent span lists, one D2H copy (cliora_cky_spans); trees: nested tuples built from them on the host')
 
     def whole(vl, B=64, L=20, D=400, V=10000, E=1024, K=100, steps=budget_steps, warmup=3):
         from cliora_amd import harness as H
@@ -340,7 +343,7 @@ def other_measurements(torch, dev, budget_steps=12):
              ('c3 CLIORA d400 B64 L20 R36 (chart + scorers as the losses take them: region max, word-region scores)', lambda: chart(lambda: CDioraMLP(400), 64, 20, 400, R=36, tag='c3')),
              ('DioraMLP d400 B64 L40', lambda: chart(lambda: DioraMLP(400), 64, 40, 400, steps=6, warmup=2, tag='l40')),
              ('c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)', lambda: chart(lambda: DioraTreeLSTM(400), 64, 40, 400, steps=6, warmup=2, arch=1, tag='c5')),
-             ('parse c2 (eval forward + CKY trees on the GPU, trees copied to the host)', parse),
+             ('parse c2 (eval forward + CKY decode and span lists on the GPU, spans copied to the host)', parse),
              ('whole step DIORA c2 (Embed, chart, reconstruction loss, clip, Adam)', lambda: whole(False)),
              ('whole step CLIORA c3 (+ ImageEncoder, VG and contrastive losses)', lambda: whole(True)))
     impl_note = {'c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)':

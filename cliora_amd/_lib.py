@@ -113,6 +113,8 @@ def lib():
     L.cliora_clip_adam.restype = i32
     L.cliora_cky_decode.argtypes = [vp, vp, vp, vp]
     L.cliora_cky_decode.restype = i32
+    L.cliora_cky_spans.argtypes = [vp, vp, vp, vp, vp]
+    L.cliora_cky_spans.restype = i32
     L.cliora_prof_enable.argtypes = [i32, i32]
     L.cliora_prof_enable.restype = i32
     L.cliora_prof_read.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), vp]

@@ -286,12 +286,13 @@ extern "C" int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_ws,
 // order (cky.py:83, utils.py:89-90); argmax keeps the first maximum (cky.py:86).
 __global__ __launch_bounds__(64) void cky_kernel(int L, int C, const int32_t* __restrict__ level_off_tab_a, const int32_t* __restrict__ pair_a,
                                                  const int32_t* __restrict__ pair_b, const int32_t* __restrict__ lvl_base, int B,
-                                                 const float* __restrict__ Sp, int32_t* __restrict__ split) {
-    extern __shared__ float val[];
+                                                 const float* __restrict__ Sp, int32_t* __restrict__ split, int32_t* __restrict__ spans) {
+    extern __shared__ float val[];                 // C best scores, then C chosen splits
+    int32_t* bsp = reinterpret_cast<int32_t*>(val + C);
     (void)level_off_tab_a;
     const int b = blockIdx.x, lane = threadIdx.x;
     for (int c = lane; c < C; c += 64) val[c] = 1.f;
-    for (int c = lane; c < L; c += 64) split[(size_t)b * C + c] = -1;
+    for (int c = lane; c < L; c += 64) { bsp[c] = -1; if (split) split[(size_t)b * C + c] = -1; }
     __syncthreads();
     int off = L;   // cell id of (level 1, pos 0)
     for (int level = 1; level < L; ++level) {
@@ -311,24 +312,53 @@ __global__ __launch_bounds__(64) void cky_kernel(int L, int C, const int32_t* __
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
             __syncthreads();
-            if (lane == 0) { val[off + pos] = best; split[(size_t)b * C + off + pos] = bi; }
+            if (lane == 0) { val[off + pos] = best; bsp[off + pos] = bi; if (split) split[(size_t)b * C + off + pos] = bi; }
             __syncthreads();
         }
         off += Lc;
     }
+    // The tree's constituent spans (start, end), children before parents, left subtree first: the order of the REDUCE actions, i.e. what
+    // the reference gets from get_spans(get_actions(tree)) (cliora/analysis/utils.py:3-49) -- L - 1 spans per sentence, the root last.
+    // One lane walks the L - 1 internal nodes with an explicit stack (level, pos, phase) in LDS.
+    if (spans && lane == 0 && L > 1) {
+        int32_t* stk = bsp + C;                     // 3 * L ints
+        auto cell = [&](int level, int pos) { const int rem = L - level; return C - rem * (rem + 1) / 2 + pos; };
+        int sp = 0, cnt = 0;
+        stk[0] = L - 1; stk[1] = 0; stk[2] = 0;
+        int32_t* out = spans + (size_t)b * (L - 1) * 2;
+        while (sp >= 0) {
+            const int level = stk[3 * sp], pos = stk[3 * sp + 1], phase = stk[3 * sp + 2];
+            if (level == 0) { --sp; continue; }
+            const int n = bsp[cell(level, pos)];
+            if (phase == 0) { stk[3 * sp + 2] = 1; ++sp; stk[3 * sp] = n; stk[3 * sp + 1] = pos; stk[3 * sp + 2] = 0; }
+            else if (phase == 1) { stk[3 * sp + 2] = 2; ++sp; stk[3 * sp] = level - n - 1; stk[3 * sp + 1] = pos + n + 1; stk[3 * sp + 2] = 0; }
+            else { out[2 * cnt] = pos; out[2 * cnt + 1] = pos + level; ++cnt; --sp; }
+        }
+    }
 }
 
-extern "C" int cliora_cky_decode(cliora_plan* plan, void* fwd_ws, int32_t* split_out, void* stream) {
-    if (!plan || !fwd_ws || !split_out) return fail(CLIORA_EINVAL, "NULL argument");
-    if (!plan->uploaded) return fail(CLIORA_EINVAL, "cky called before forward");
+static int launch_cky(cliora_plan* plan, void* fwd_ws, int32_t* split_out, int32_t* spans_out, void* stream, const char* who) {
+    if (!plan || !fwd_ws) return fail(CLIORA_EINVAL, "NULL argument");
+    if (!plan->uploaded) return fail(CLIORA_EINVAL, std::string(who) + " called before forward");
     OKR(cliora_plan_ready(plan, (hipStream_t)stream));
     Plan& p = plan->p;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cky_kernel, dim3(p.B), dim3(64), p.C * sizeof(float), st, p.L, p.C, (const int32_t*)nullptr,
+    const size_t lds = (size_t)p.C * (sizeof(float) + sizeof(int32_t)) + (size_t)3 * (p.L + 1) * sizeof(int32_t);
+    hipLaunchKernelGGL(cky_kernel, dim3(p.B), dim3(64), lds, st, p.L, p.C, (const int32_t*)nullptr,
                        p.d_tables + p.dev.pair_a_in, p.d_tables + p.dev.pair_b_in, p.d_tables + p.dev.lvl_base_in, p.B,
-                       (const float*)fwd_ws + p.fwd.sp, split_out);
+                       (const float*)fwd_ws + p.fwd.sp, split_out, spans_out);
     LAUNCHOK("cky_kernel");
     return CLIORA_OK;
+}
+
+extern "C" int cliora_cky_decode(cliora_plan* plan, void* fwd_ws, int32_t* split_out, void* stream) {
+    if (!split_out) return fail(CLIORA_EINVAL, "NULL argument");
+    return launch_cky(plan, fwd_ws, split_out, nullptr, stream, "cky");
+}
+
+extern "C" int cliora_cky_spans(cliora_plan* plan, void* fwd_ws, int32_t* split_out, int32_t* spans_out, void* stream) {
+    if (!spans_out) return fail(CLIORA_EINVAL, "NULL argument");
+    return launch_cky(plan, fwd_ws, split_out, spans_out, stream, "cky_spans");
 }
 
 extern "C" const char* cliora_last_error(void) { return g_cliora_err.c_str(); }

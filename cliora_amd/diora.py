@@ -350,26 +350,51 @@ class DioraBase(nn.Module):
                 h, s = self.pair_states_out(level)
                 self.outside_hook(level, h, torch.zeros_like(h), s)
 
+    def cky_spans(self):
+        """Constituent spans of the best binary tree per sentence (analysis/cky.py:31-99 decoded on the GPU, cliora_cky_spans): an int32
+        array (B, L-1, 2) of (start, end) word positions, children before parents, the root last -- what the reference derives on the
+        host with ``get_spans(get_actions(tree))`` (analysis/utils.py:3-49) and scores F1 on (scripts/train.py:184-204).  One
+        device-to-host copy, no recursion."""
+        plan = self._plan
+        parts = []
+        if plan.L < 2:                                   # one word: no constituent
+            import numpy as np
+            return np.zeros((plan.B * len(self._wss), 0, 2), dtype=np.int32)
+        for ws in self._wss:
+            with torch.cuda.device(ws.device):
+                spans = torch.empty((plan.B, plan.L - 1, 2), device=ws.device, dtype=torch.int32)
+                _lib.check(_lib.lib().cliora_cky_spans(plan.handle, _ptr(ws), None, _ptr(spans), _stream()), 'cliora_cky_spans')
+            parts.append(spans)
+        return (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).cpu().numpy()
+
+    @staticmethod
+    def trees_from_spans(spans):
+        """Nested tuples of word positions (what ``ParsePredictor.parse_batch`` returns, e.g. ``(0, ((1, 2), 3))``) from the
+        children-before-parents span lists of cky_spans: a stack per sentence, no recursion."""
+        trees = []
+        for sent in spans.tolist():
+            if not sent:
+                trees.append(0)
+                continue
+            stack = []                                   # (start, end, tree) of the finished constituents
+            for s, e in sent:
+                if stack and stack[-1][1] == e and stack[-1][0] > s:
+                    rs, _, right = stack.pop()
+                else:
+                    rs, right = e, e                     # the right child is the word e itself
+                if stack and stack[-1][0] == s and stack[-1][1] == rs - 1:
+                    left = stack.pop()[2]
+                else:
+                    left = s
+                stack.append((s, e, (left, right)))
+            trees.append(stack[-1][2])
+        return trees
+
     def cky(self):
         """Best binary tree per sentence (analysis/cky.py:31-99) decoded on the GPU.
 
-        Returns nested tuples of word positions, e.g. ``(0, ((1, 2), 3))``."""
-        plan = self._plan
-        parts = []
-        for ws in self._wss:
-            with torch.cuda.device(ws.device):
-                split = torch.empty((plan.B, plan.C), device=ws.device, dtype=torch.int32)
-                _lib.check(_lib.lib().cliora_cky_decode(plan.handle, _ptr(ws), _ptr(split), _stream()), 'cliora_cky_decode')
-            parts.append(split)
-        sp = torch.cat(parts, 0).cpu().numpy()
-        off = self.index.get_offset(plan.L)
-
-        def build(b, level, pos):
-            if level == 0:
-                return pos
-            n = int(sp[b, off[level] + pos])
-            return (build(b, n, pos), build(b, level - n - 1, pos + n + 1))
-        return [build(b, plan.L - 1, 0) for b in range(sp.shape[0])]
+        Returns nested tuples of word positions, e.g. ``(0, ((1, 2), 3))`` -- a view of the device-built span lists (cky_spans)."""
+        return self.trees_from_spans(self.cky_spans())
 
 
 class DioraMLP(DioraBase):

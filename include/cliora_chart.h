@@ -276,6 +276,11 @@ int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_workspace, int
  * maximum wins.  split_out (B, C) int32 device: chosen split n per cell (leaves -1);
  * the tree is rebuilt from it on the host. */
 int cliora_cky_decode(cliora_plan* plan, void* fwd_workspace, int32_t* split_out, void* stream);
+/* The same decode, with the tree's constituent spans emitted on the device: spans_out (B, L-1, 2) int32 device = (start, end) word
+ * positions, children before parents, left subtree first, the root last -- the list the reference builds on the host with
+ * get_spans(get_actions(tree)) (cliora/analysis/utils.py:3-49; what scripts/train.py:184-204 scores F1 on): evaluation needs ONE
+ * device-to-host copy of B*(L-1)*2 ints and no recursion over a split table.  split_out: as cliora_cky_decode, or NULL. */
+int cliora_cky_spans(cliora_plan* plan, void* fwd_workspace, int32_t* split_out, int32_t* spans_out, void* stream);
 
 /* Optional HIP-event timing of one kernel class (used by bench.py for the roofline
  * line): enable, run steps, then read the accumulated device time and launch count. */

@@ -122,6 +122,9 @@ def test_hook_scores_and_trees(name, mfma_mode):
     trees = m.cky()
     assert [str(t) for t in trees] == meta['trees']
     assert [[list(s) for s in R.tree_spans(t)] for t in trees] == meta['spans']
+    # the span lists as the device emits them (cliora_cky_spans: children before parents, the root last) are the reference's own
+    # get_spans(get_actions(tree)) lists (analysis/utils.py:3-49) of the fixture
+    assert m.cky_spans().tolist() == meta['spans']
 
 
 def test_c2_shape_against_oracle_and_golden(mfma_mode):
