@@ -286,6 +286,231 @@ __device__ __forceinline__ void compose_fwd_tasks(uint32_t* lds_img, const int b
     }
 }
 
+// ---------------------------------------------------------------------------------
+// compose_fwd_tasks_dual (round 5): the same tasks with TWO splits of a cell tile in flight per wave.
+//
+// What bounds level_compose_fwd on the big levels is the CU's LDS pipe, not the MFMA or the VALU: per 32-deep k-step a wave reads the
+// column block's weight fragments (ten ds_read_b128 = 10 KB) and moves its operand rows to the MFMA lanes (eight ds_bpermute = 2 KB) for
+// fifteen MFMAs; eight waves x 12 KB = 96 KB per k-step at 128 B / clock = 750 of the ~1 150 clocks a k-step takes (profiles/r05_notes.md).
+// A wave's splits n, n + WPG, n + 2 WPG, ... of one cell tile share the block's weights: here the wave takes them TWO at a time, reads
+// each weight fragment once per k-step and feeds it to both splits' accumulators (30 MFMAs per 10 KB of weights).  Each accumulator still
+// sees its products in the order (w_lo x_hi, w_hi x_lo, w_hi x_hi) per k-step and the weighted sum g += p_n y_n still runs in the
+// wave's split order (A = n before B = n + WPG), so the results are bitwise those of compose_fwd_tasks; an odd last split runs alone.
+// The bias sits in LDS behind the reduction slots (20 registers the second accumulator set needs); PD ring slots per split.
+// ---------------------------------------------------------------------------------
+template <int CT, bool F32>
+__device__ __forceinline__ void kstep_mfma2(const uint32_t* wimg, int i, int g, int S, int half, int st, bool second, const StepOperand& xa,
+                                            const StepOperand& xb, f32x4 (&acca)[CT], f32x4 (&accb)[CT]) {
+    if constexpr (F32) {
+        kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, xa, acca);
+        kstep_mfma<CT, F32>(wimg, i, g, S, half, st, second, xb, accb);
+    } else {
+        const uint32_t* wfrag = wimg + i * S + 4 * g;
+        u32x4 wh[CT], wl[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            wh[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st);
+            wl[c] = *reinterpret_cast<const u32x4*>(wfrag + c * 16 * S + 16 * st + half);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { acca[c] = mfma32bf(wl[c], xa.h, acca[c]); accb[c] = mfma32bf(wl[c], xb.h, accb[c]); }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { acca[c] = mfma32bf(wh[c], xa.l, acca[c]); accb[c] = mfma32bf(wh[c], xb.l, accb[c]); }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { acca[c] = mfma32bf(wh[c], xa.h, acca[c]); accb[c] = mfma32bf(wh[c], xb.h, accb[c]); }
+    }
+}
+
+template <int CT, int K16, bool F32, int PD>
+__device__ __forceinline__ void compose_fwd_tasks_dual(uint32_t* lds_img, const int bx, const int gx, const uint32_t* __restrict__ Wimg, int S_, int K_,
+                                                       const PairLevel& lv, const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
+                                                       const float* __restrict__ bias, const float* __restrict__ Pp,
+                                                       int TG, int SP, int ntask, float* __restrict__ HP, size_t hp_stride, int Dp,
+                                                       uint32_t* __restrict__ ymask, float* __restrict__ Y) {
+    constexpr int WAVES = 8, T = WAVES * 64;
+    constexpr bool KS = K16 > 0;
+    constexpr int UNROLL_STEPS = KS ? 64 : 1;
+    const int K = KS ? K16 * 16 : K_;
+    const int S = F32 ? K : (KS ? (K16 + 1) / 2 * 32 + WS3_PAD : S_);     // row stride of the LDS image in dwords
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int Kp = F32 ? (K + 31) / 32 * 32 : S - WS3_PAD, half = Kp >> 1;
+    const int by = blockIdx.y, gy = gridDim.y;
+    const int col0 = by * (CT * 16);
+    stage_weight_image(Wimg + (size_t)col0 * S, lds_img, CT * 16 * S, wave, lane, T);
+    float4* red = reinterpret_cast<float4*>(lds_img + CT * 16 * S);      // [LC_SLOTS][CT][64]
+    float* b2s = reinterpret_cast<float*>(red + LC_SLOTS * CT * 64);     // the block's bias (CT * 16 floats), read in the tile epilogues
+    for (int c = threadIdx.x; c < CT * 16; c += T) b2s[c] = bias[col0 + c];
+    const int nsteps = Kp >> 5;
+    const int nsteps_p = (nsteps + PD - 1) / PD * PD;
+    int wimg_off = 0;
+    const int WPG = WAVES / TG;
+    const int j = wave / WPG, r = wave - j * WPG;
+    const int G = (lv.ncell + 15) >> 4;
+    const int Ns = (lv.N + SP - 1) / SP;
+
+    struct Ctx { const float *pa, *pb; };
+    auto rowctx = [&](int gt, int n) {
+        const int t = min(gt * 16 + li, lv.ncell - 1);
+        const int b = t / lv.Lc, p = t - b * lv.Lc;
+        const int idx = p * lv.N + n;
+        const size_t ca = (size_t)b * lv.C + lv.pa[idx], cb = (size_t)b * lv.C + lv.pb[idx];
+        return Ctx{PA + ca * lda, PB + cb * ldb};
+    };
+    Raw2 raA[PD][2], raB[PD][2];
+    auto issue = [&](Raw2 (&ra)[PD][2], int slot, const Ctx& c, int s) {
+        const int k = 32 * s + 4 * lg;
+        const int k2 = k + (32 * s + 16 < K ? 16 : 0);
+        ra[slot][0] = Raw2{ld4(c.pa + k), ld4(c.pb + k)};
+        ra[slot][1] = Raw2{ld4(c.pa + k2), ld4(c.pb + k2)};
+    };
+    auto relu_add = [](const Raw2& q) {
+        return make_float4(fmaxf(q.u.x + q.v.x, 0.f), fmaxf(q.u.y + q.v.y, 0.f), fmaxf(q.u.z + q.v.z, 0.f), fmaxf(q.u.w + q.v.w, 0.f));
+    };
+
+    bool staged = false;
+    for (int task = bx; task < ntask; task += gx) {
+        const int gg = task / SP, s = task - gg * SP;
+        const int gt = gg * TG + j;
+        const bool have = gt < G;
+        const int n0 = s * Ns, n1 = min(lv.N, n0 + Ns);
+        f32x4 hacc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) hacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool work = have && n0 + r < n1;
+        const int gtc = min(gt, G - 1);
+        int n = work ? n0 + r : n0;
+        Ctx ctxA = rowctx(gtc, n);
+        Ctx ctxB = rowctx(gtc, (work && n + WPG < n1) ? n + WPG : n);
+        if (!staged) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            staged = true;
+        }
+        if (work) {
+#pragma unroll
+            for (int sl = 0; sl < PD; ++sl) { issue(raA, sl, ctxA, sl < nsteps ? sl : 0); issue(raB, sl, ctxB, sl < nsteps ? sl : 0); }
+            // epilogue of one (tile, split): y = relu(acc + b2); g += p_n y; ReLU bits; optional y rows
+            auto epilogue = [&](int nn_, f32x4 (&acc)[CT]) {
+                const int ti = gt * 16 + i;
+                const bool ok = ti < lv.ncell;
+                const size_t prow = (size_t)lv.rowbase + (size_t)min(ti, lv.ncell - 1) * lv.N + nn_;
+                const float pn = ok ? Pp[prow] : 0.f;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const float4 bvc = *reinterpret_cast<const float4*>(b2s + c * 16 + 4 * g);
+                    const float y0 = fmaxf(acc[c][0] + bvc.x, 0.f), y1 = fmaxf(acc[c][1] + bvc.y, 0.f);
+                    const float y2 = fmaxf(acc[c][2] + bvc.z, 0.f), y3 = fmaxf(acc[c][3] + bvc.w, 0.f);
+                    hacc[c][0] = fmaf(pn, y0, hacc[c][0]); hacc[c][1] = fmaf(pn, y1, hacc[c][1]);
+                    hacc[c][2] = fmaf(pn, y2, hacc[c][2]); hacc[c][3] = fmaf(pn, y3, hacc[c][3]);
+                    bits |= ((y0 > 0.f ? 1u : 0u) | (y1 > 0.f ? 2u : 0u) | (y2 > 0.f ? 4u : 0u) | (y3 > 0.f ? 8u : 0u)) << (4 * c);
+                    if (Y && ok) st4(Y + prow * Dp + col0 + c * 16 + 4 * g, make_float4(y0, y1, y2, y3));
+                }
+                if (ymask && ok) ymask[(prow * gy + by) * 4 + g] = bits;
+            };
+            while (true) {
+                const bool dual = n + WPG < n1;                          // wave-uniform
+                const int nB = n + WPG;
+                const int nnA = n + (dual ? 2 : 1) * WPG;                // the wave's next split(s)
+                const bool nextA = nnA < n1, nextB = nnA + WPG < n1;
+                const Ctx ctxnA = rowctx(gt, nextA ? nnA : n);
+                const Ctx ctxnB = rowctx(gt, nextB ? nnA + WPG : n);
+                asm volatile("" : "+v"(wimg_off));
+                const uint32_t* wimg = lds_img + wimg_off;
+                f32x4 accA[CT], accB[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) { accA[c] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (dual) {
+                    StepOperand curA = make_operand<F32>(psrc, relu_add(raA[0][0]), relu_add(raA[0][1]));
+                    StepOperand curB = make_operand<F32>(psrc, relu_add(raB[0][0]), relu_add(raB[0][1]));
+#pragma unroll UNROLL_STEPS
+                    for (int base = 0; base < nsteps_p; base += PD) {
+#pragma unroll
+                        for (int sl = 0; sl < PD; ++sl) {
+                            const int st = base + sl;
+                            if (st < nsteps) {
+                                StepOperand nxtA = curA, nxtB = curB;
+                                if (st + 1 < nsteps) {
+                                    nxtA = make_operand<F32>(psrc, relu_add(raA[(sl + 1) % PD][0]), relu_add(raA[(sl + 1) % PD][1]));
+                                    nxtB = make_operand<F32>(psrc, relu_add(raB[(sl + 1) % PD][0]), relu_add(raB[(sl + 1) % PD][1]));
+                                }
+                                kstep_mfma2<CT, F32>(wimg, i, g, S, half, st, 32 * st + 16 < K, curA, curB, accA, accB);
+                                const int nst = st + PD;
+                                const bool in_cur = nst < nsteps;
+                                const int step = in_cur ? nst : (sl < nsteps ? sl : 0);
+                                issue(raA, sl, pick_pod(in_cur, ctxA, ctxnA), step);
+                                issue(raB, sl, pick_pod(in_cur, ctxB, ctxnB), step);
+                                __builtin_amdgcn_sched_barrier(0);
+                                curA = nxtA; curB = nxtB;
+                            }
+                        }
+                    }
+                    epilogue(n, accA);
+                    epilogue(nB, accB);
+                } else {
+                    StepOperand cur = make_operand<F32>(psrc, relu_add(raA[0][0]), relu_add(raA[0][1]));
+#pragma unroll UNROLL_STEPS
+                    for (int base = 0; base < nsteps_p; base += PD) {
+#pragma unroll
+                        for (int sl = 0; sl < PD; ++sl) {
+                            const int st = base + sl;
+                            if (st < nsteps) {
+                                StepOperand nxt = cur;
+                                if (st + 1 < nsteps) nxt = make_operand<F32>(psrc, relu_add(raA[(sl + 1) % PD][0]), relu_add(raA[(sl + 1) % PD][1]));
+                                kstep_mfma<CT, F32>(wimg, i, g, S, half, st, 32 * st + 16 < K, cur, accA);
+                                const int nst = st + PD;
+                                const bool in_cur = nst < nsteps;
+                                issue(raA, sl, pick_pod(in_cur, ctxA, ctxnA), in_cur ? nst : (sl < nsteps ? sl : 0));
+                                __builtin_amdgcn_sched_barrier(0);
+                                cur = nxt;
+                            }
+                        }
+                    }
+                    epilogue(n, accA);
+                }
+                if (!nextA) break;
+                ctxA = ctxnA; ctxB = ctxnB;
+                n = nnA;
+            }
+        }
+        // ---- sum over the WPG waves of a cell tile: the fixed tree of compose_fwd_tasks
+#pragma unroll
+        for (int stride = 4; stride >= 1; stride >>= 1) {
+            if (WPG >= 2 * stride) {
+                const bool holding = r < 2 * stride;
+                const bool writer = holding && r >= stride;
+                if (writer) {
+                    const int slot = j * stride + (r - stride);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) red[(slot * CT + c) * 64 + lane] = make_float4(hacc[c][0], hacc[c][1], hacc[c][2], hacc[c][3]);
+                }
+                __syncthreads();
+                if (holding && !writer) {
+                    const int slot = j * stride + r;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const float4 v = red[(slot * CT + c) * 64 + lane];
+                        hacc[c][0] += v.x; hacc[c][1] += v.y; hacc[c][2] += v.z; hacc[c][3] += v.w;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (have && r == 0) {
+            const int ti = gt * 16 + i;
+            if (ti < lv.ncell) {
+                const int b = ti / lv.Lc, p = ti - b * lv.Lc;
+                float* o = HP + (size_t)s * hp_stride + ((size_t)b * lv.C + lv.off + p) * Dp + col0 + 4 * g;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) st4(o + c * 16, make_float4(hacc[c][0], hacc[c][1], hacc[c][2], hacc[c][3]));
+            }
+        }
+    }
+}
+
 template <int CT, int K16, bool F32>
 __global__ __launch_bounds__(512) void level_compose_fwd(const uint32_t* __restrict__ Wimg, int S_, int K_, PairLevel lv,
                                                          const float* __restrict__ PA, int lda, const float* __restrict__ PB, int ldb,
@@ -312,7 +537,8 @@ struct ComposeSeg {
     int TG, SP, ntask, gx;    // gx = 0: no such segment in this step
     float* HP;
 };
-template <int CT, int K16, bool F32>
+// DUALPD > 0: compose_fwd_tasks_dual with that ring depth (two splits of a cell tile in flight per wave); 0: compose_fwd_tasks
+template <int CT, int K16, bool F32, int DUALPD = 0>
 __global__ __launch_bounds__(512) void level_compose_fwd2(ComposeSeg s0, ComposeSeg s1, int S_, int K_, const float* __restrict__ Pp, size_t hp_stride,
                                                           int Dp, uint32_t* __restrict__ ymask, float* __restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
@@ -324,8 +550,12 @@ __global__ __launch_bounds__(512) void level_compose_fwd2(ComposeSeg s0, Compose
     PairLevel lv;
     lv.pa = SEG(lv.pa); lv.pb = SEG(lv.pb); lv.Lc = SEG(lv.Lc); lv.N = SEG(lv.N); lv.C = SEG(lv.C); lv.ncell = SEG(lv.ncell);
     lv.rowbase = SEG(lv.rowbase); lv.off = SEG(lv.off); lv.tilebase = SEG(lv.tilebase);
-    compose_fwd_tasks<CT, K16, F32>(lds_img, bx, gx, SEG(Wimg), S_, K_, lv, SEG(PA), SEG(lda), SEG(PB), SEG(ldb), SEG(bias), Pp, SEG(TG), SEG(SP),
-                                    SEG(ntask), SEG(HP), hp_stride, Dp, ymask, Y);
+    if constexpr (DUALPD > 0)
+        compose_fwd_tasks_dual<CT, K16, F32, DUALPD>(lds_img, bx, gx, SEG(Wimg), S_, K_, lv, SEG(PA), SEG(lda), SEG(PB), SEG(ldb), SEG(bias), Pp, SEG(TG),
+                                                     SEG(SP), SEG(ntask), SEG(HP), hp_stride, Dp, ymask, Y);
+    else
+        compose_fwd_tasks<CT, K16, F32>(lds_img, bx, gx, SEG(Wimg), S_, K_, lv, SEG(PA), SEG(lda), SEG(PB), SEG(ldb), SEG(bias), Pp, SEG(TG), SEG(SP),
+                                        SEG(ntask), SEG(HP), hp_stride, Dp, ymask, Y);
 #undef SEG
 }
 
@@ -815,10 +1045,15 @@ struct ProjSeg {
 constexpr int P2_RT = CLIORA_P2_RT, P2_CTA = CLIORA_P2_CTA, P2_CTB = CLIORA_P2_CTB, P2_PD = CLIORA_P2_PD;
 constexpr int P2_CTM = P2_CTA > P2_CTB ? P2_CTA : P2_CTB;
 template <int SP0, int SP1>
-__global__ __launch_bounds__(256) void level_project2(ProjSeg a, ProjSeg b) {
+__global__ __launch_bounds__(256) void level_project2(ProjSeg a, ProjSeg b, int order) {
     __shared__ float4 part[4][P2_RT * P2_CTM][64];
     __shared__ float sh_ss[4][P2_RT * 16];
     int bid = blockIdx.x;
+    {   // order 1: the projection blocks first, the score blocks behind them (order 0: scores first); 2: scores in the middle
+        const int ns = a.sc.nscore + b.sc.nscore, np = a.nproj + b.nproj;
+        if (order == 1 && bid < ns + np) bid = bid < np ? bid + ns : bid - np;
+        else if (order == 2 && bid < ns + np) { const int h = np / 2; bid = bid < h ? bid + ns : (bid < h + ns ? bid - h : bid); }
+    }
     if (bid < a.sc.nscore) { score_cell(a.sc, bid, &sh_ss[0][0]); return; }
     bid -= a.sc.nscore;
     if (bid < b.sc.nscore) { score_cell(b.sc, bid, &sh_ss[0][0]); return; }
