@@ -596,7 +596,7 @@ def main():
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command, so that
             # frac can be reproduced from profiles/ alone (the two clocks agree within a few per cent)
             rocprof = None
-            for cand in ('r04_kernel_stats.csv', 'r03_kernel_stats.csv', 'r02_kernel_stats.csv'):
+            for cand in ('r05_kernel_stats.csv', 'r04_kernel_stats.csv', 'r03_kernel_stats.csv', 'r02_kernel_stats.csv'):
                 kp = os.path.join(ROOT, 'profiles', cand)
                 if os.path.exists(kp):
                     import csv

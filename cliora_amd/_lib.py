@@ -265,6 +265,12 @@ def set_persistent(mode):
 RS_MODES = {'auto': -1, 'off': 0, 'on': 1, 'geometry': 2}
 
 
+def has_persistent():
+    """True when the library was built with the optional one-launch (persistent) forward (include/cliora_chart.h)."""
+    L = lib()
+    return bool(hasattr(L, 'cliora_built_with_persistent') and L.cliora_built_with_persistent())
+
+
 def has_rows_stationary():
     """True when the library was built with the optional rows-stationary compose kernel (include/cliora_chart.h)."""
     L = lib()

@@ -385,6 +385,13 @@ extern "C" int cliora_built_with_rows_stationary(void) {
     return 0;
 #endif
 }
+extern "C" int cliora_built_with_persistent(void) {
+#ifdef CLIORA_WITH_PERSISTENT
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int cliora_set_rows_stationary(int mode) {
     const int prev = g_cliora_rows_stationary;
     g_cliora_rows_stationary = mode < 0 ? -1 : std::min(mode, 2);

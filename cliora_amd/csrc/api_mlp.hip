@@ -6,7 +6,9 @@
 #ifdef CLIORA_WITH_ROWS_STATIONARY      // the rows-stationary forward compose (measured: no level of any shape selects it) is an optional build
 #include "compose_rs_kernels.hpp"
 #endif
+#ifdef CLIORA_WITH_PERSISTENT          // the one-launch forward (measured: AUTO selects it for no BASELINE configuration) is an optional build
 #include "persist_kernels.hpp"
+#endif
 #include "resident_kernels.hpp"
 #include "vl_kernels.hpp"
 
@@ -290,10 +292,11 @@ static bool wavefront_pays(const Plan& p, int env) {
 // (level_compose_fwd2) and ONE projection / score grid for both (level_project2), on the caller's stream.  The two-stream form pays
 // a cross-stream event per step (a barrier packet on both queues: the launch behind it starts ~5 us late, profiles/r04_timeline.txt)
 // and staggers the chains; one queue needs neither.  Same tasks, same summation order: bitwise the two-stream (and the sequential)
-// results.  Text-only DioraMLP plans; cliora_set_wavefront(CLIORA_WAVEFRONT_MERGED) / CLIORA_WAVEFRONT=2 forces it, AUTO takes it
+// results.  DioraMLP and CLIORA plans; cliora_set_wavefront(CLIORA_WAVEFRONT_MERGED) / CLIORA_WAVEFRONT=2 forces it, AUTO takes it
 // wherever the two-stream wavefront would pay, ON (1) keeps the two streams.
 static bool merged_pays(const Plan& p, bool vl) {
-    if (vl || p.arch != 0 || p.L <= 2) return false;
+    (void)vl;                 // CLIORA plans too: the attention residual of the inside cells sits between the two grids (cliora.py:140-157)
+    if (p.arch != 0 || p.L <= 2) return false;
     if (g_cliora_wavefront != 2 && !(g_cliora_wavefront < 0 && wavefront_pays(p, -1))) return false;
     for (size_t e = 0; e < (size_t)2 * p.L; ++e) {
         const int sp = p.persist_levels[e * PLEVEL_INTS + 6];
@@ -310,6 +313,10 @@ static bool merged_pays(const Plan& p, bool vl) {
 // kernels hide with 32 waves per CU.  AUTO therefore takes it for Dp <= 64; cliora_set_persistent / CLIORA_PERSISTENT=0|1 force
 // it off / on (on is still refused for shapes the kernel does not cover).
 static bool persist_pays(const cliora_plan* plan, bool vl) {
+#ifndef CLIORA_WITH_PERSISTENT
+    (void)plan; (void)vl;
+    return false;
+#else
     const Plan& p = plan->p;
     if (g_cliora_persistent == 0 || vl || p.arch != 0 || p.L < 2) return false;
     if (plan_has_rows_stationary_levels(p)) return false;       // their geometry is not the plan's (the kernel's level table)
@@ -322,6 +329,7 @@ static bool persist_pays(const cliora_plan* plan, bool vl) {
     const size_t image = (size_t)p.fwd.ct3 * 16 * (split_bf16() ? p.fwd.S3 : p.Dp) * sizeof(uint32_t);
     if (image + PK_LDS_EXTRA > 160 * 1024) return false;
     return true;
+#endif
 }
 
 // One workgroup per sentence for every level of both passes (resident_kernels.hpp) when a row fits a wavefront: text-only DioraMLP,
@@ -649,6 +657,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         return CLIORA_OK;
     };
     if (!compress) OKR(init_root());
+#ifdef CLIORA_WITH_PERSISTENT
     if (persist) {
         // ---- every level of both passes in one launch (persist_kernels.hpp): the first scores of both chains included ----
         PersistFwd a{};
@@ -681,6 +690,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         HIPOK(hipEventRecord(plan->ev_persist, st));
         OKR(cliora_persist_note(plan, st));
     }
+#endif
     if (resident) {
         // ---- one workgroup per sentence, every level of both passes (resident_kernels.hpp) ----
         ResArgs a = resident_args(plan, ws, IH, OH, IS, OS, run_outside);
@@ -718,7 +728,12 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             q.HP = outside_pass ? HPo : HPi; q.hp_stride = hp_stride; q.normalize = p.normalize;
             q.H = outside_pass ? OH : IH; q.nrm = ws + (outside_pass ? f.nrmo : f.nrmi);
             const bool projects = outside_pass ? level >= 1 : level < L - 1;      // else: chart rows only (level_finish)
-            if (!projects) { q.nfin = (int)cells_grid(q.ncell); q.SPfin = SP; return q; }
+            const bool attended = vl && !outside_pass;     // CLIORA inside cells: cell_attend_fwd has written the final rows of H and their norms
+            if (attended) { q.HP = IH; q.hp_stride = 0; q.normalize = 0; q.H = nullptr; q.nrm = nullptr; }
+            if (!projects) {
+                if (!attended) { q.nfin = (int)cells_grid(q.ncell); q.SPfin = SP; }
+                return q;
+            }
             q.nrg = ((q.ncell + 15) / 16 + P2_RT - 1) / P2_RT;          // row groups of P2_RT sixteen-row tiles
             q.nrgp = q.nrg >= 8 ? (q.nrg + 7) / 8 * 8 : q.nrg;
             const int ncols = outside_pass ? Dp : ldpi;
@@ -728,7 +743,8 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             q.Wfrag = ws + (outside_pass ? f.w1ro3 : f.wcat3);
             q.bias = outside_pass ? nullptr : ws + f.bcat;
             q.P = ws + (outside_pass ? f.po : f.pi); q.ldp = ncols;
-            q.sc = score_args(outside_pass ? level - 1 : level + 1, outside_pass, level, SP);      // the next level of the pass, scored in the same launch
+            q.sc = score_args(outside_pass ? level - 1 : level + 1, outside_pass, level, attended ? 1 : SP);   // the next level of the pass, scored in the same launch
+            if (attended) q.sc.HPn = nullptr;              // the newest operands are final rows of H already
             return q;
         };
         for (int k = 1; k <= L; ++k) {
@@ -740,7 +756,13 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
                 OKR(launch_level_compose2(st, ca, cb, f.S3, Dp, f.ct3, f.ncb3, ws + f.pp, hp_stride, YM, PH));
             }
-            OKR(launch_level_project2(st, ca.gx ? ca.SP : 1, cb.gx ? cb.SP : 1, qa, qb));
+            if (vl && k <= L - 1) {   // cliora.py:140-157: the attention residual between the aggregate and the second unit norm (inside cells only)
+                const LevelArgs g = level_args(p, k, false);
+                ATTEND_LAUNCH(cell_attend_fwd, p.R, dim3(B * g.Lc), st, g, L, HPi, hp_stride, ca.SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
+                                   ws + f.nrmi, ws + f.att_u, ws + f.att_nrmu, ws + f.att_pk, (float*)nullptr, D, IS);
+                LAUNCHOK("cell_attend_fwd");
+            }
+            OKR(launch_level_project2(st, (ca.gx && !vl) ? ca.SP : 1, cb.gx ? cb.SP : 1, qa, qb));
         }
     }
     for (int k = 1; k <= L && !persist && !resident && !merged; ++k) {

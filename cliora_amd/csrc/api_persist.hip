@@ -1,6 +1,9 @@
 // C ABI, persistent unit: instantiations and launch of the level-loop kernels (persist_kernels.hpp).
 // A translation unit of its own: the kernels are large and the units compile in parallel.
+// Round 5: an OPTIONAL part of the build (-DCLIORA_WITH_PERSISTENT): AUTO selected it for no BASELINE configuration (d = 400: the launches
+// win; configs[0]: the sentence-resident kernels come first), so the default library carries only code a default run can reach.
 #include "api_common.hpp"
+#ifdef CLIORA_WITH_PERSISTENT
 #include "level_kernels.hpp"
 #include "persist_kernels.hpp"
 
@@ -30,3 +33,9 @@ int cliora_launch_persist_fwd(hipStream_t st, const PersistFwd& a, int ct, int n
     }
 #undef PF_CASE
 }
+#else
+namespace cliora { struct PersistFwd; }
+int cliora_launch_persist_fwd(hipStream_t, const cliora::PersistFwd&, int, int) {
+    return fail(CLIORA_EINVAL, "the persistent level-loop kernel is not part of this build (-DCLIORA_WITH_PERSISTENT)");
+}
+#endif

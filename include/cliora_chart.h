@@ -335,6 +335,11 @@ int cliora_set_wavefront(int mode);
 #define CLIORA_PERSISTENT_ON 1
 int cliora_set_persistent(int mode);
 int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
+/* Round 5: AUTO selects this kernel for no BASELINE configuration (d = 400: the launches win, profiles/r03_persist_ab.txt; configs[0]:
+ * the sentence-resident kernels come first), so it is an OPTIONAL part of the build: csrc compiled with -DCLIORA_WITH_PERSISTENT
+ * (`CLIORA_BUILD_EXTRA=-DCLIORA_WITH_PERSISTENT python -m cliora_amd.build --force`).  Without it cliora_set_persistent still records
+ * the mode but every forward runs the launch-per-level (or sentence-resident) path.  1 if built in. */
+int cliora_built_with_persistent(void);
 /* A persistent launch that gives up on a barrier leaves its charts partly written.  The library does not let that pass silently:
  * the timeout word follows every persistent launch to pinned host memory.  cliora_chart_backward WAITS for the word of the last
  * persistent launch on the device (a host synchronisation, on the persistent path only) and returns CLIORA_EHIP if it has moved --

@@ -185,7 +185,8 @@ def test_region_max_scorer_is_the_dense_scorer_then_max(B, L, D, R, mfma_mode):
 
 @pytest.mark.parametrize('B,L,D,R,share', [(16, 12, 400, 36, True), (6, 3, 48, 5, False), (64, 20, 400, 36, True)])
 def test_cliora_wavefront_is_bitwise_the_sequential_order(B, L, D, R, share, mfma_mode):
-    """The CLIORA levels (attention between the aggregate and the projection) on two streams against one stream: bit for bit."""
+    """The CLIORA levels (attention between the aggregate and the projection) on two streams, and as merged launches on one queue, against
+    the sequential order on one stream: bit for bit."""
     from cliora_amd import _lib
     from cliora_amd.cliora import DioraMLP
     torch.manual_seed(3)
@@ -201,7 +202,7 @@ def test_cliora_wavefront_is_bitwise_the_sequential_order(B, L, D, R, share, mfm
     res = {}
     prev = _lib.set_wavefront('off')
     try:
-        for mode in ('off', 'on', 'on'):
+        for mode in ('off', 'on', 'on', 'merged', 'merged'):       # merged (round 5): the forward's two chains as one grid per phase on one queue
             _lib.set_wavefront(mode)
             for p in m.parameters():
                 p.grad = None

@@ -11,7 +11,12 @@ import torch
 
 from test_gpu_parity import CHARTS, _module_from_params, _run_gpu
 
-pytestmark = pytest.mark.gpu
+from cliora_amd import _lib as _lib_for_skip
+
+# round 5: the persistent forward is an optional part of the build (AUTO selects it for no BASELINE configuration): these tests run
+# when the library was built with -DCLIORA_WITH_PERSISTENT
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _lib_for_skip.has_persistent(), reason='library built without -DCLIORA_WITH_PERSISTENT')]
 
 SHAPES = [
     # D, B, L, share, normalize
