@@ -16,7 +16,7 @@ from collections import defaultdict
 CLASSES = {
     'compose_fwd': ('level_compose_fwd',),
     'compose_bwd': ('level_compose_bwd',),
-    'wgrad': ('tn_gemm_dma',),
+    'wgrad': ('tn_gemm_tiles',),          # the pair rows' dW2 (round 4: the tiled split-bf16 operands; the projections' gradients stay on tn_gemm_dma3x)
 }
 
 
