@@ -284,20 +284,23 @@ extern "C" int cliora_outside_pair_states(const cliora_plan* plan, void* fwd_ws,
 // One wavefront per sentence.  val[] (chart of best scores) lives in LDS; leaves start at 1
 // (analysis/cky.py:24-25, 39).  Candidate = (val_l + val_r) + (s_n - max_n s) in fp32, in that
 // order (cky.py:83, utils.py:89-90); argmax keeps the first maximum (cky.py:86).
-__global__ __launch_bounds__(64) void cky_kernel(int L, int C, const int32_t* __restrict__ level_off_tab_a, const int32_t* __restrict__ pair_a,
+// One workgroup of CKY_WAVES wavefronts per sentence (round 5: was one wavefront walking every cell in turn -- 190 dependent steps at
+// L 20; the cells of a level are independent, so wave w takes the positions w, w + CKY_WAVES, ... and the level ends with one barrier).
+constexpr int CKY_WAVES = 4;
+__global__ __launch_bounds__(CKY_WAVES * 64) void cky_kernel(int L, int C, const int32_t* __restrict__ level_off_tab_a, const int32_t* __restrict__ pair_a,
                                                  const int32_t* __restrict__ pair_b, const int32_t* __restrict__ lvl_base, int B,
                                                  const float* __restrict__ Sp, int32_t* __restrict__ split, int32_t* __restrict__ spans) {
     extern __shared__ float val[];                 // C best scores, then C chosen splits
     int32_t* bsp = reinterpret_cast<int32_t*>(val + C);
     (void)level_off_tab_a;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    for (int c = lane; c < C; c += 64) val[c] = 1.f;
-    for (int c = lane; c < L; c += 64) { bsp[c] = -1; if (split) split[(size_t)b * C + c] = -1; }
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < C; c += CKY_WAVES * 64) val[c] = 1.f;
+    for (int c = threadIdx.x; c < L; c += CKY_WAVES * 64) { bsp[c] = -1; if (split) split[(size_t)b * C + c] = -1; }
     __syncthreads();
     int off = L;   // cell id of (level 1, pos 0)
     for (int level = 1; level < L; ++level) {
         const int Lc = L - level, N = level;
-        for (int pos = 0; pos < Lc; ++pos) {
+        for (int pos = wave; pos < Lc; pos += CKY_WAVES) {          // operands live on lower levels: final since the last barrier
             const int loc = lvl_base[level] + pos * N;
             const size_t row0 = (size_t)B * lvl_base[level] + ((size_t)b * Lc + pos) * N;
             const bool an = lane < N;
@@ -311,16 +314,15 @@ __global__ __launch_bounds__(64) void cky_kernel(int L, int C, const int32_t* __
                 const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            __syncthreads();
             if (lane == 0) { val[off + pos] = best; bsp[off + pos] = bi; if (split) split[(size_t)b * C + off + pos] = bi; }
-            __syncthreads();
         }
+        __syncthreads();
         off += Lc;
     }
     // The tree's constituent spans (start, end), children before parents, left subtree first: the order of the REDUCE actions, i.e. what
     // the reference gets from get_spans(get_actions(tree)) (cliora/analysis/utils.py:3-49) -- L - 1 spans per sentence, the root last.
     // One lane walks the L - 1 internal nodes with an explicit stack (level, pos, phase) in LDS.
-    if (spans && lane == 0 && L > 1) {
+    if (spans && threadIdx.x == 0 && L > 1) {
         int32_t* stk = bsp + C;                     // 3 * L ints
         auto cell = [&](int level, int pos) { const int rem = L - level; return C - rem * (rem + 1) / 2 + pos; };
         int sp = 0, cnt = 0;
@@ -344,7 +346,7 @@ static int launch_cky(cliora_plan* plan, void* fwd_ws, int32_t* split_out, int32
     Plan& p = plan->p;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)p.C * (sizeof(float) + sizeof(int32_t)) + (size_t)3 * (p.L + 1) * sizeof(int32_t);
-    hipLaunchKernelGGL(cky_kernel, dim3(p.B), dim3(64), lds, st, p.L, p.C, (const int32_t*)nullptr,
+    hipLaunchKernelGGL(cky_kernel, dim3(p.B), dim3(CKY_WAVES * 64), lds, st, p.L, p.C, (const int32_t*)nullptr,
                        p.d_tables + p.dev.pair_a_in, p.d_tables + p.dev.pair_b_in, p.d_tables + p.dev.lvl_base_in, p.B,
                        (const float*)fwd_ws + p.fwd.sp, split_out, spans_out);
     LAUNCHOK("cky_kernel");
