@@ -636,8 +636,11 @@ static Dev dev_views(const Plan& p) {
     return d;
 }
 
+// sentence-affine block order of the one-workgroup-per-cell kernels (chart_kernels.hpp: cell_of_block); CLIORA_XCD_AFFINE=0: off
+static int xcd_affine() { static const int v = [] { const char* e = getenv("CLIORA_XCD_AFFINE"); return e ? atoi(e) : 1; }(); return v; }
 static LevelArgs level_args(const Plan& p, int level, bool outside_pass) {
     LevelArgs g;
+    g.affine = xcd_affine();
     g.B = p.B; g.C = p.C; g.Dp = p.Dp; g.Lc = p.L - level;
     g.N = outside_pass ? p.Nout(level) : p.Nin(level);
     g.off = p.level_offset[level];

@@ -19,9 +19,23 @@ namespace cliora {
 
 constexpr float UNIT_EPS = 1e-8f;   // cliora/net/utils.py:10
 
+// Block index -> target cell t = b * Lc + p of a level, sentence-affine (round 5): workgroups are dealt round-robin over the 8 XCDs by
+// linear block id, and a cell's operand / partner rows all belong to its own sentence -- with t = block id, the cells of one sentence
+// spread over all eight L2s and each of them fetches the sentence's rows; here the blocks with id = x (mod 8) take the sentences
+// b = x (mod 8), so a sentence's chart rows are fetched by ONE L2.  A permutation of the blocks only: the results are the same bits.
+// CLIORA_XCD_AFFINE=0 (api_common.hpp: xcd_affine()) restores t = block id.
+__device__ __forceinline__ int cell_of_block(int bid, int B, int Lc, int affine) {
+    const int n8 = (B >> 3) * 8 * Lc;                  // blocks of the sentences below the last multiple of 8
+    if (!affine || bid >= n8) return bid;
+    const int x = bid & 7, q = bid >> 3;
+    const int bb = q / Lc, p = q - bb * Lc;
+    return (bb * 8 + x) * Lc + p;
+}
+
 struct LevelArgs {
     int B, C, Dp, Lc, N, off;   // target cells of this level: chart row b*C + off + p, p < Lc; N splits each
     int rowbase;                // first global pair row of the level; row = rowbase + (b*Lc + p)*N + n
+    int affine;                 // one-workgroup-per-cell kernels: sentence-affine block order (cell_of_block)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -100,7 +114,7 @@ static __global__ __launch_bounds__(256) void pair_scores_fwd(LevelArgs g, const
     // in flight together for L <= 16, four at a time beyond), wave 0 then does the softmax
     __shared__ float sh_s[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int row0 = g.rowbase + t * g.N;
     const int nv = g.Dp >> 2;
@@ -238,7 +252,7 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
     __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4], sh_s2[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
@@ -328,7 +342,7 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_sib(LevelArgs g, U
     __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
@@ -360,7 +374,7 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_out(LevelArgs g, i
     __shared__ float4 sh[2][GATHER_SLOTS][64];
     __shared__ float sh_s[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;

@@ -724,7 +724,7 @@ __device__ __forceinline__ void score_cell(const ScoreArgs& sc, int t, float* sh
 // the scoring alone (first level of a pass: every operand is already final)
 static __global__ __launch_bounds__(256) void level_scores(ScoreArgs sc) {
     __shared__ float sh_s[64];
-    score_cell(sc, blockIdx.x, sh_s);
+    score_cell(sc, cell_of_block(blockIdx.x, sc.g.B, sc.g.Lc, sc.g.affine), sh_s);
 }
 
 // one projection block (16 rows x CT*16 columns) of level_project: block `bid` of nrgp * ncolblocks
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void level_project(const float* __restrict__ W
     __shared__ float sh_ss[4][16];
     (void)ncolblocks;
     if ((int)blockIdx.x < sc.nscore) {               // the next level's scores: first in the grid, so they start at once
-        score_cell(sc, blockIdx.x, &sh_ss[0][0]);
+        score_cell(sc, cell_of_block(blockIdx.x, sc.g.B, sc.g.Lc, sc.g.affine), &sh_ss[0][0]);
         return;
     }
     project_block<CT, SP>(part, sh_ss, (int)blockIdx.x - sc.nscore, Wfrag, K, nrg, nrgp, ncell, Lc, C, off, HP, hp_stride, normalize, bias, P, ldp, H, nrm);
@@ -1054,9 +1054,9 @@ __global__ __launch_bounds__(256) void level_project2(ProjSeg a, ProjSeg b, int 
         if (order == 1 && bid < ns + np) bid = bid < np ? bid + ns : bid - np;
         else if (order == 2 && bid < ns + np) { const int h = np / 2; bid = bid < h ? bid + ns : (bid < h + ns ? bid - h : bid); }
     }
-    if (bid < a.sc.nscore) { score_cell(a.sc, bid, &sh_ss[0][0]); return; }
+    if (bid < a.sc.nscore) { score_cell(a.sc, cell_of_block(bid, a.sc.g.B, a.sc.g.Lc, a.sc.g.affine), &sh_ss[0][0]); return; }
     bid -= a.sc.nscore;
-    if (bid < b.sc.nscore) { score_cell(b.sc, bid, &sh_ss[0][0]); return; }
+    if (bid < b.sc.nscore) { score_cell(b.sc, cell_of_block(bid, b.sc.g.B, b.sc.g.Lc, b.sc.g.affine), &sh_ss[0][0]); return; }
     bid -= b.sc.nscore;
     if (bid < a.nproj) {
         project_tile<P2_RT, P2_CTA, SP0, P2_PD>(reinterpret_cast<float4 (*)[P2_RT * P2_CTA][64]>(&part[0][0][0]), sh_ss, bid, a.Wfrag, a.K, a.nrg, a.nrgp, a.ntc,
@@ -1097,7 +1097,10 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
                                                          float* __restrict__ DA, float* __restrict__ DZ, float* __restrict__ X,
                                                          float* __restrict__ DPP, float* __restrict__ DPB) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
-    constexpr int WAVES = 8, T = WAVES * 64, PD = 4;
+#ifndef CLIORA_CB_PD
+#define CLIORA_CB_PD 4
+#endif
+    constexpr int WAVES = 8, T = WAVES * 64, PD = CLIORA_CB_PD;       // k-steps of operand rows in flight per wave
     constexpr bool KS = K16 > 0;
     constexpr int UNROLL_STEPS = KS ? 64 : 1;
     const int K = KS ? K16 * 16 : K_;

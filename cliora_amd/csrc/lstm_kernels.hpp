@@ -187,7 +187,7 @@ static __global__ __launch_bounds__(512) void lstm_cell_bwd_in(LevelArgs g, int 
                                                         const float* __restrict__ OC, const float* __restrict__ dGi, const float* __restrict__ dGci,
                                                         const float* __restrict__ dGo, const float* __restrict__ dGco, float* __restrict__ dPI,
                                                         float* __restrict__ VH, float* __restrict__ VC, float* __restrict__ dStot) {
-    const int t = blockIdx.x, v = threadIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine), v = threadIdx.x;      // sentence-affine block order (chart_kernels.hpp)
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
@@ -245,7 +245,7 @@ static __global__ __launch_bounds__(512) void lstm_cell_bwd_out(LevelArgs g, int
                                                          const float* __restrict__ OC, const float* __restrict__ dGo, const float* __restrict__ dGco,
                                                          float* __restrict__ dPO, float* __restrict__ VH, float* __restrict__ VC,
                                                          float* __restrict__ dStot) {
-    const int t = blockIdx.x, v = threadIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine), v = threadIdx.x;      // sentence-affine block order (chart_kernels.hpp)
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int c = g.off + p;
     const size_t crow = (size_t)b * g.C + c;
@@ -284,7 +284,7 @@ static __global__ __launch_bounds__(512) void lstm_cell_fwd(LevelArgs g, const i
                                                      float* __restrict__ H, float* __restrict__ Cc, float* __restrict__ nrmH,
                                                      float* __restrict__ nrmC) {
     __shared__ float sh_n[2][8];
-    const int t = blockIdx.x, v = threadIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine), v = threadIdx.x;      // sentence-affine block order (chart_kernels.hpp)
     const int b = t / g.Lc, p = t - b * g.Lc;
     const int Dp = g.Dp, nv = Dp / W;
     const bool act = v < nv;
@@ -369,7 +369,7 @@ static __global__ __launch_bounds__(256) void lstm_scores_bwd(LevelArgs g, const
                                                        float* __restrict__ dGh, float* __restrict__ dGc, float* __restrict__ DS) {
     __shared__ float sh_dp[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);      // sentence-affine block order (chart_kernels.hpp)
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const int Dp = g.Dp, nv = Dp >> 2;

@@ -40,7 +40,7 @@ static __global__ __launch_bounds__(256) void cell_attend_fwd(LevelArgs g, int L
     __shared__ float4 sh_v[4][128];
     __shared__ float sh_sc[VL_MAXR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);      // sentence-affine block order (chart_kernels.hpp)
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const int Dp = g.Dp, nv = Dp >> 2;
@@ -151,7 +151,7 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
     __shared__ float4 sh_v[4][128];
     __shared__ float sh_d[VL_MAXR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
+    const int t = cell_of_block(blockIdx.x, g.B, g.Lc, g.affine);      // sentence-affine block order (chart_kernels.hpp)
     const int b = t / g.Lc, p = t - b * g.Lc;
     const size_t crow = (size_t)b * g.C + g.off + p;
     const int Dp = g.Dp, nv = Dp >> 2;
