@@ -45,6 +45,8 @@ for case in range(n_cases):
         arch, D = 'mlp', rnd.choice([5, 16, 20, 33, 48, 50, 64])
     L = rnd.randint(1, 22 if D <= 128 else 18)
     B = rnd.randint(1, 5)
+    if rnd.random() < 0.35 and D <= 200 and L <= 12:
+        B = rnd.choice([8, 9, 12, 16, 19, 24])      # round 5: batches of eight and more take the sentence-affine block order (chart_kernels.hpp: cell_of_block), with and without a remainder
     share = rnd.random() < 0.6
     normalize = 'unit' if rnd.random() < 0.8 else 'none'
     if arch == 'treelstm':
@@ -52,7 +54,7 @@ for case in range(n_cases):
     compress = arch != 'treelstm' and rnd.random() < 0.25
     Rr = rnd.randint(1, 40)
     mode = rnd.choice(['f32', 'bf16x3'])
-    wf, ps = rnd.choice(['auto', 'off', 'on']), rnd.choice(['auto', 'off', 'on'])
+    wf, ps = rnd.choice(['auto', 'off', 'on', 'merged']), rnd.choice(['auto', 'off', 'on'])
     rs = rnd.choice(['auto', 'on', 'geometry']) if D == 400 else 'auto'
     rd = rnd.choice(['auto', 'off', 'on']) if D <= 64 else 'auto'
     seed = rnd.randint(0, 10 ** 6)
