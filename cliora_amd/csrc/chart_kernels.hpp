@@ -272,9 +272,14 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
     if (sib && act1) { sp1 = ld4(sib_pl + crow * Dp + col1); sq1 = ld4(sib_ql + crow * Dp + col1); }
     const float ss = (with_outside == 1 && wave == 0) ? sib_s[crow] : 0.f;
     // right-child uses: partner = left child; dH += ds * QL(left);  dPR += DA
+    // (CLIORA_DIAG_GATHER: wrong-result timing builds of tools/ab/anatomy.sh -- 1: no list, 2: the right-child list only, 3: no list, no dots)
+#if !defined(CLIORA_DIAG_GATHER) || CLIORA_DIAG_GATHER == 2
     gather_uses(inb, c, b, bC, wave, DA, DS, Dp, PI + 2 * Dp, ldpi, col0, col1, act0, act1, v[4], v[5], v[0], v[1], vS);
+#endif
     // left-child uses: partner = right child; dQL += ds * H(right);  dPL += DA
+#if !defined(CLIORA_DIAG_GATHER)
     gather_uses(ina, c, b, bC, wave, DA, DS, Dp, IH, Dp, col0, col1, act0, act1, v[2], v[3], v[6], v[7], vS);
+#endif
     wg_sum_pairs(sh, wave, lane, 8, v);
     if (with_outside == 2) {           // sibling uses in the outside pass, walked here: partner = parent (outside chart); own reduction round
         float4 w[4] = {f4zero(), f4zero(), f4zero(), f4zero()};
@@ -307,6 +312,9 @@ static __global__ __launch_bounds__(256) void cell_gather_bwd_in(LevelArgs g, in
         st4(VH + crow * Dp + col1, f4add(v[1], e));
     }
     if (lane == 0) dStot[crow] = vs;
+#if defined(CLIORA_DIAG_GATHER) && CLIORA_DIAG_GATHER == 3
+    dots = nullptr;
+#endif
     if (dots) {      // H . vH of the cell without the finished vH (NormBwdLevelE): H . vHg + dP . (P - bias) over the cell's projection blocks
         float d = 0.f;
         const float* hr = IH + crow * Dp;
