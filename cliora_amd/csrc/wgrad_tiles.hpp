@@ -36,8 +36,13 @@ __device__ __forceinline__ void store_split_tile(uint32_t* dst, const float4 v) 
     const uint32_t h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
     const uint32_t l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
     const uint32_t l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
-    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(dst + 128) = make_uint2(l0, l1);
+    // Non-temporal: the tiles (0.82 GB per c2 step, 13 GB at L 40) are read once, by the weight-gradient GEMM, after most of the backward --
+    // written with the default policy they pass through the 256 MB Infinity Cache and push out the rows the next launches gather (DA, the
+    // projections, dG).  c2 3.03-3.08 -> 2.97-3.01 ms, L 40 17.0 -> 16.6 (profiles/r05_notes.md section 13; the same hint on DA, HP, P and
+    // the gathers' outputs -- all read by one of the next launches -- loses 0.5-2 %).
+    typedef uint32_t v2u_ __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(v2u_{h0, h1}, reinterpret_cast<v2u_*>(dst));
+    __builtin_nontemporal_store(v2u_{l0, l1}, reinterpret_cast<v2u_*>(dst + 128));
 }
 
 // ds_read_b64_tr_b16 at LDS byte address `addr` (every lane of the wave must be active: the read gathers across lanes)
