@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int li = fetch_row_of(lane), lg = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int fsrc = 4 * (li + 16 * lg);             // ds_bpermute address of the MFMA lane (row li, piece lg) for the fetch lane 4 li + lg
     const int Kp = F32 ? (K + 31) / 32 * 32 : S - WS3_PAD, half = Kp >> 1;
     const int by = blockIdx.y, gy = gridDim.y;
     const int col0 = by * (CT * 16);
@@ -1164,16 +1165,20 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
         const int ntile = tile + stride;
         const bool has_next = ntile < ntiles;
         const Ctx ctxn = rowctx(has_next ? ntile : tile);
-        // MFMA-lane view: row i = target cell ti; its operand cells for the epilogue re-gather of xs = PL(a) + PR(b)
+        // The epilogue runs in the FETCH-lane view (lane = 4 li + lg: row li = target cell ti, columns 4 lg .. of each column tile), like
+        // the operand ring: its re-gather of xs = PL(a) + PR(b), the DA row stores and the X tile stores are then 64 contiguous bytes per
+        // four lanes (the X tile: lane-linear) where the MFMA-lane view (row = lane & 15) made every one of them 64 separate requests per
+        // instruction -- the re-gather alone was 4.7 us of the c2 launch's 31 (tools/ab/anatomy.sh).  The accumulators come over with
+        // five ds_bpermute quadruples per tile (the k-loop has 26).
         const int gt = tile / lv.N, n = tile - gt * lv.N;
-        const int ti = gt * 16 + i;
+        const int ti = gt * 16 + li;
         const bool ok = ti < lv.ncell;
         const int tc = min(ti, lv.ncell - 1);
         const int eb = tc / lv.Lc, ep = tc - eb * lv.Lc;
         const size_t prow = (size_t)lv.rowbase + (size_t)tc * lv.N + n;
         const float pn = Pp[prow];
-        const float* xa = PA + ((size_t)eb * lv.C + lv.pa[ep * lv.N + n]) * lda + col0 + 4 * g;
-        const float* xb = PB + ((size_t)eb * lv.C + lv.pb[ep * lv.N + n]) * ldb + col0 + 4 * g;
+        const float* xa = PA + ((size_t)eb * lv.C + lv.pa[ep * lv.N + n]) * lda + col0 + 4 * lg;
+        const float* xb = PB + ((size_t)eb * lv.C + lv.pb[ep * lv.N + n]) * ldb + col0 + 4 * lg;
         float4 ea[CT], ebv[CT];                     // the epilogue's operands, on their way while the K loop runs
 #pragma unroll
         for (int c = 0; c < CT; ++c) { ea[c] = ld4(xa + c * 16); ebv[c] = ld4(xb + c * 16); }
@@ -1234,23 +1239,25 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
         float dp = 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
+            // u for (row li, columns 4 lg ..): MFMA lane li + 16 lg holds it
+            const float4 u = to_mfma_lanes(fsrc, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
             const float4 pa4 = ea[c], pb4 = ebv[c];
             const float xs0 = pa4.x + pb4.x, xs1 = pa4.y + pb4.y, xs2 = pa4.z + pb4.z, xs3 = pa4.w + pb4.w;
             const float4 x = make_float4(fmaxf(xs0, 0.f), fmaxf(xs1, 0.f), fmaxf(xs2, 0.f), fmaxf(xs3, 0.f));
-            dp = fmaf(acc[c][0], x.x, dp); dp = fmaf(acc[c][1], x.y, dp); dp = fmaf(acc[c][2], x.z, dp); dp = fmaf(acc[c][3], x.w, dp);
+            dp = fmaf(u.x, x.x, dp); dp = fmaf(u.y, x.y, dp); dp = fmaf(u.z, x.z, dp); dp = fmaf(u.w, x.w, dp);
             if (ok) {
-                const size_t o = prow * Dp + col0 + c * 16 + 4 * g;
-                st4(DA + o, make_float4(x.x > 0.f ? pn * acc[c][0] : 0.f, x.y > 0.f ? pn * acc[c][1] : 0.f,
-                                        x.z > 0.f ? pn * acc[c][2] : 0.f, x.w > 0.f ? pn * acc[c][3] : 0.f));
+                const size_t o = prow * Dp + col0 + c * 16 + 4 * lg;
+                st4(DA + o, make_float4(x.x > 0.f ? pn * u.x : 0.f, x.y > 0.f ? pn * u.y : 0.f,
+                                        x.z > 0.f ? pn * u.z : 0.f, x.w > 0.f ? pn * u.w : 0.f));
                 if (!TILED) st4(X + o, x);
             }
-            if (TILED)
-                store_split_tile(reinterpret_cast<uint32_t*>(X) + ((size_t)(lv.tilebase + tile) * NT + by * CT + c) * 256 + 8 * i + 2 * g,
+            if (TILED)          // the tile's lane slot 8 (row) + 2 (piece) = 2 lane: lane-linear
+                store_split_tile(reinterpret_cast<uint32_t*>(X) + ((size_t)(lv.tilebase + tile) * NT + by * CT + c) * 256 + 2 * lane,
                                  ok ? x : f4zero());
         }
-        dp += __shfl_xor(dp, 16);
-        dp += __shfl_xor(dp, 32);
-        if (ok && g == 0) DPP[prow * gy + by] = dp;
+        dp += __shfl_xor(dp, 1);                    // the four lanes of a row: (g0 + g1) + (g2 + g3), the order the MFMA-lane view summed in
+        dp += __shfl_xor(dp, 2);
+        if (ok && lg == 0) DPP[prow * gy + by] = dp;
         if (!has_next) break;
         ctx = ctxn;
         tile = ntile;
