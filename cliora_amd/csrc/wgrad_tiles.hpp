@@ -133,7 +133,11 @@ static __global__ __launch_bounds__(512) void tn_gemm_tiles(const uint32_t* __re
             const int c = e - h * per;
             const uint32_t* src = (isA ? Ab : Bb) + ((size_t)(t0 + h) * NT + (isA ? c : jt0 + c)) * 256 + lane * 4;
             uint32_t* dst = buf + (isA ? (h * NT + c) * 256 : xpart + (h * NJT + c) * 256);
-            __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            // an X piece is read by ONE column block of ONE slice: non-temporal (aux 2), so that the stream does not take L2 / Infinity Cache
+            // lines from the chains this GEMM runs beside; a DZ piece is read by all the column blocks of its slice: default policy
+            // (c2 2.93-2.96 -> 2.92-2.93 ms, L 40 16.59 -> 16.54; nt on both: L 40 16.87 -- profiles/r05_notes.md section 13)
+            if (isA) __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
         }
     };
 
