@@ -507,7 +507,11 @@ static __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __re
     const int nchunks = K >> 4;
     const int cbase = nchunks / 4, crem = nchunks % 4;
     const int ch0 = wave * cbase + min(wave, crem);
+#ifdef CLIORA_DIAG_GEMMK                               // wrong-result timing diagnostic (tools/ab/anatomy.sh): 1/N of each wave's chunks
+    const int nch = max(1, (cbase + (wave < crem ? 1 : 0)) / CLIORA_DIAG_GEMMK);
+#else
     const int nch = cbase + (wave < crem ? 1 : 0);
+#endif
     using Raw = typename AProd::Raw;
     using Ctx = decltype(ap.row(0));
     Ctx ctx[RT];

@@ -899,7 +899,11 @@ __device__ __forceinline__ void project_tile(float4 (*part)[RT * CT][64], float 
     const int nchunks = K >> 4;
     const int cbase = nchunks / 4, crem = nchunks % 4;
     const int ch0 = wave * cbase + min(wave, crem);
+#ifdef CLIORA_DIAG_GEMMK                               // wrong-result timing diagnostic (tools/ab/anatomy.sh): 1/N of each wave's chunks
+    const int nch = max(1, (cbase + (wave < crem ? 1 : 0)) / CLIORA_DIAG_GEMMK);
+#else
     const int nch = cbase + (wave < crem ? 1 : 0);
+#endif
     auto crow_of = [&](int r) { const int rc = min(r, ncell - 1); const int b = rc / Lc; return (size_t)b * C + off + (rc - b * Lc); };
     const float* hp[RT];
 #pragma unroll
