@@ -598,6 +598,27 @@ static int launch_rows_direct3(hipStream_t st, const float* img3, int K, int nco
     LAUNCHOK("rows_gemm_ksplit3");
     return CLIORA_OK;
 }
+// the RT x CT form (rows_gemm_ksplit3x): shape = 10 RT + CT
+template <class AP, class EP>
+static int launch_rows_direct3x(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep, int shape) {
+    if (nrows <= 0 || ncols <= 0) return CLIORA_OK;
+    const int nt = ncols / 16, nrt = (nrows + 15) / 16;
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(img3);
+#define R3X_CASE(rt, ct)                                                                                                             \
+    case 10 * rt + ct: {                                                                                                             \
+        const int nrg = (nrt + rt - 1) / rt, nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;                                              \
+        hipLaunchKernelGGL((rows_gemm_ksplit3x<rt, ct, AP, EP>), dim3(nrgp * ((nt + ct - 1) / ct)), dim3(256), 0, st, I, K, nrg, nrgp, nt, nrows, ap, ep); \
+        break;                                                                                                                       \
+    }
+    switch (shape) {
+        R3X_CASE(1, 1) R3X_CASE(2, 1) R3X_CASE(2, 2) R3X_CASE(3, 2) R3X_CASE(4, 2) R3X_CASE(2, 3) R3X_CASE(3, 3) R3X_CASE(2, 5)
+        R3X_CASE(1, 3) R3X_CASE(1, 5) R3X_CASE(2, 4) R3X_CASE(1, 2) R3X_CASE(1, 4)
+        default: return CLIORA_EINVAL;
+    }
+#undef R3X_CASE
+    LAUNCHOK("rows_gemm_ksplit3x");
+    return CLIORA_OK;
+}
 static int build_frag_images(hipStream_t st, const ImageList& l) {
     if (l.n == 0) return CLIORA_OK;
     hipLaunchKernelGGL(frag_weight_image, dim3(256, 1, l.n), dim3(256), 0, st, l.tab);

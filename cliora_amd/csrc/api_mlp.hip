@@ -395,6 +395,11 @@ static int build_chart_images(const cliora_plan* plan, float* ws, bool compress,
     if (compress) { pj.add(ws + f.rootw, ws + f.rootw3, Dp, Dp, Dp); pj.add(ws + f.rootwT, ws + f.rootwT3, Dp, Dp, Dp); }
     OKR(build_weight_images(st, im));
     OKR(build_frag_images(st, pj));
+    if (p.arch == 0) {          // split-bf16 fragment images of the projection transposes (rows_gemm_ksplit3x: the backward's per-level GEMMs)
+        ImageList p3;
+        p3.add(ws + f.wcatT, ws + f.wcatT3s, Dp, ldpi, ldpi); p3.add(ws + f.w1roT, ws + f.w1roT3s, Dp, Dp, Dp);
+        OKR(build_frag_images3(st, p3));
+    }
     return CLIORA_OK;
 }
 
@@ -872,6 +877,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     static const bool fuse_off = [] { const char* e = getenv("CLIORA_FUSE_DNORM"); return e && atoi(e) == 0; }();
     // (the OUTSIDE chart has no attention residual: its chain keeps the fusion in CLIORA plans too -- round 4, c3 chart step)
     const bool fuse_dnorm = !fuse_off && !compress && !resident;
+    // the projection-backward GEMMs on split-bf16 products with RT x CT tiles (rows_gemm_ksplit3x): CLIORA_BWD_GEMM3 = 10 RT + CT
+    // Round 5: these GEMMs sat on two limits at once -- what a CU pulls from L2 (a 16 x 16 block streams 150 KB for one tile) and the
+    // fp32-input MFMA (16 x 16 x 4 in 32 cycles) -- and each remedy alone lost (profiles/r05_notes.md section 14); split-bf16 products on
+    // 32 x 48 tiles take both: c2 3.005 -> 2.905 ms, L 40 16.37 -> 16.19.  Shapes 22 / 32 / 24: 2.95-2.96; 42 / 33 / 25 / 13 / 15: 3.0-3.14.
+    // CLIORA_BWD_GEMM3=0: the fp32 16 x 16 kernel (always in the exact-fp32 arithmetic mode).
+    static const int bwd_gemm3 = [] { const char* e = getenv("CLIORA_BWD_GEMM3"); return e ? atoi(e) : 23; }();
+    static const int bwd_gemm3_min = [] { const char* e = getenv("CLIORA_BWD_GEMM3_MIN"); return e ? atoi(e) : 0; }();     // 0 / 128 / 256 / 512 / 768 cells: 2.905 / 2.91 / 2.92 / 2.92 / 2.94
+    auto gemm3_pays = [&](int ncell) { return bwd_gemm3 > 0 && split_bf16() && ncell >= bwd_gemm3_min; };
     // X / DZ of the pair rows as tiled split-bf16 operands (wgrad_tiles.hpp) instead of fp32 rows.  CLIORA_PAIR_TILES=0: off.
     const bool tiled = pair_tiles_ok(Dp) && !resident;
 
@@ -908,9 +921,15 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
                            level == L - 1 ? nullptr : d_outside_s, dv.use[ROLE_OUTB], DA, DS, PI, ldpi, p.blk_qlo, dPO, VHo, dStoto,
                            OH, ws + f.po, fused_norm ? wb + bw.dots_o : nullptr);
         LAUNCHOK("cell_gather_bwd_out");
-        if (fused_norm)
+        if (fused_norm && gemm3_pays(ncell))
+            OKR(launch_rows_direct3x(sb, ws + f.w1roT3s, Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                              NormBwdLevelE{dGo, VHo, OH, ws + f.nrmo, wb + bw.dots_o, Dp, C, g.off, g.Lc, p.normalize}, bwd_gemm3));
+        else if (fused_norm)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                             NormBwdLevelE{dGo, VHo, OH, ws + f.nrmo, wb + bw.dots_o, Dp, C, g.off, g.Lc, p.normalize}));
+        else if (level >= 1 && gemm3_pays(ncell))
+            OKR(launch_rows_direct3x(sb, ws + f.w1roT3s, Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
+                              StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}, bwd_gemm3));
         else if (level >= 1)
             OKR(launch_rows_direct(sb, ws + f.w1roT, PROJ_IMG(f.w1roT3), Dp, Dp, ncell, LevelRowsA{dPO, Dp, C, g.off, g.Lc},
                             StoreLevelE{VHo, Dp, C, g.off, g.Lc, nullptr, 1}));
@@ -994,9 +1013,15 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             dpi_done_recorded = true;
         }
-        if (fused_norm)
+        if (fused_norm && gemm3_pays(ncell))
+            OKR(launch_rows_direct3x(sa, ws + f.wcatT3s, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                              NormBwdLevelE{dG, VH, IH, ws + f.nrmi, wb + bw.dots, Dp, C, g.off, g.Lc, p.normalize}, bwd_gemm3));
+        else if (fused_norm)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             NormBwdLevelE{dG, VH, IH, ws + f.nrmi, wb + bw.dots, Dp, C, g.off, g.Lc, p.normalize}));
+        else if (level <= L - 2 && gemm3_pays(ncell))
+            OKR(launch_rows_direct3x(sa, ws + f.wcatT3s, ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
+                              StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}, bwd_gemm3));
         else if (level <= L - 2)
             OKR(launch_rows_direct(sa, ws + f.wcatT, PROJ_IMG(f.wcatT3), ldpi, Dp, ncell, LevelRowsA{dPI, ldpi, C, g.off, g.Lc},
                             StoreLevelE{VH, Dp, C, g.off, g.Lc, nullptr, 1}));

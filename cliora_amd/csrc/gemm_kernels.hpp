@@ -685,6 +685,98 @@ static __global__ __launch_bounds__(256) void rows_gemm_ksplit3(const uint32_t* 
     }
 }
 
+// rows_gemm_ksplit3x (round 5): rows_gemm_ksplit3 with RT x CT sixteen-wide tiles per workgroup -- the form for DioraMLP's per-level
+// projection GEMMs, which sit on two limits at once (profiles/r05_notes.md section 14): what a CU can pull from L2 (a 16 x 16 block streams
+// 150 KB of rows and fragments for one tile) and the fp32-input MFMA (16 x 16 x 4 in 32 cycles).  Split-bf16 products take the MFMA limit
+// away (3 x 16 cycles per 16 x 16 x 32), a square tile halves the bytes per output; each alone lost.  Ragged last column block (nt column
+// tiles in all); every output element is summed in the same order for any tile shape (four k-slices, fixed tree).
+template <int RT, int CT, class AProd, class Epi>
+static __global__ __launch_bounds__(256) void rows_gemm_ksplit3x(const uint32_t* __restrict__ Wimg, int K, int nrg, int nrgp, int nt, int nrows,
+                                                          AProd ap, Epi epi) {
+    __shared__ float4 part[4][RT * CT][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int li = fetch_row_of(lane), lq = fetch_piece_of(lane), psrc = mfma_src_addr(lane);
+    const int cb = blockIdx.x / nrgp, rg = blockIdx.x - cb * nrgp;   // row group fastest (XCD L2 reuse of the rows)
+    if (rg >= nrg) return;
+    const int ct0 = cb * CT;
+    const int nct = min(CT, nt - ct0);                    // workgroup-uniform
+    const int nst = (K + 31) >> 5;
+    const int sbase = nst / 4, srem = nst % 4;
+    const int s0 = wave * sbase + min(wave, srem);
+    const int ns = sbase + (wave < srem ? 1 : 0);
+    using Ctx = decltype(ap.row(0));
+    Ctx ctx[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) ctx[r] = ap.row(min((rg * RT + r) * 16 + li, nrows - 1));
+    const u32x4* wfrag = reinterpret_cast<const u32x4*>(Wimg) + ((size_t)ct0 * nst) * 128 + lane;
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int PD = RT * CT > 4 ? 2 : 3;
+    float4 ra[PD][RT][2];
+    u32x4 rh[PD][CT], rl[PD][CT];
+    auto load = [&](int slot, int s) {
+        const int st = s0 + s;
+        const int k = 32 * st + 4 * lq;
+        const bool second = 32 * st + 16 < K;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            ra[slot][r][0] = ap.finish(ctx[r], ap.fetch(ctx[r], k));
+            ra[slot][r][1] = second ? ap.finish(ctx[r], ap.fetch(ctx[r], k + 16)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (c < nct) {
+                rh[slot][c] = wfrag[((size_t)c * nst + st) * 128];
+                rl[slot][c] = wfrag[((size_t)c * nst + st) * 128 + 64];
+            }
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl)
+        if (sl < ns) load(sl, sl);
+    for (int base = 0; base < ns; base += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+            if (base + sl < ns) {
+                u32x4 xh[RT], xl[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) split_bf16x8(to_mfma_lanes(psrc, ra[sl][r][0]), to_mfma_lanes(psrc, ra[sl][r][1]), xh[r], xl[r]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma32bf(rl[sl][c], xh[r], acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma32bf(rh[sl][c], xl[r], acc[r][c]);
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) if (c < nct) acc[r][c] = mfma32bf(rh[sl][c], xh[r], acc[r][c]);
+                if (base + sl + PD < ns) load(sl, base + sl + PD);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) part[wave][r * CT + c][lane] = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
+    __syncthreads();
+    for (int t = wave; t < RT * CT; t += 4) {            // fixed summation order over the four k-slices
+        const int r = t / CT, c = t - r * CT;
+        if (c >= nct) continue;
+        const float4 p0 = part[0][t][lane], p1 = part[1][t][lane], p2 = part[2][t][lane], p3 = part[3][t][lane];
+        const float4 v = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                     ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        const int row = (rg * RT + r) * 16 + i;
+        if (row < nrows) epi.store4(epi.row(row), (ct0 + c) * 16 + 4 * q, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // tn_gemm:  C[i][j] = sum_r A(r,i) B(r,j),  i < Mi, j < Nj  (both multiples of 16*T)
 //   grid.x = (Mi/(TI*16)) * (Nj/(TJ*16)) blocks of C; grid.y*4 + wave = row slice.

@@ -190,7 +190,7 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.wcat3 = img(nb * Dp, Dp); f.wcatT3 = img(Dp, nb * Dp);
         f.w1ro3 = img(npo * Dp, Dp); f.w1roT3 = img(Dp, npo * Dp);
         {   // frag_weight_image3: output columns x roundup32(K) dwords (TreeLSTM plans only)
-            auto img3 = [&](size_t cols, size_t K) { return take(arch == 1 ? cols * ((K + 31) / 32 * 32) : 0); };
+            auto img3 = [&](size_t cols, size_t K) { return take(cols * ((K + 31) / 32 * 32)); };     // (DioraMLP: rows_gemm_ksplit3x)
             f.wcat3s = img3(nb * Dp, Dp); f.wcatT3s = img3(Dp, nb * Dp); f.w1ro3s = img3(npo * Dp, Dp); f.w1roT3s = img3(Dp, npo * Dp);
         }
         f.rootp = take(Dp);
