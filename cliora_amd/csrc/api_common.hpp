@@ -581,23 +581,6 @@ static int build_frag_images3(hipStream_t st, const ImageList& l) {       // spl
     LAUNCHOK("frag_weight_image3");
     return CLIORA_OK;
 }
-// out = A W^T on split-bf16 products, W as its frag_weight_image3 (ncols a multiple of 16 output columns, the image's first `ncols`;
-// K any multiple of 16): the TreeLSTM's gate projections and their backward in the default arithmetic mode
-template <class AP, class EP>
-static int launch_rows_direct3(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep) {
-    if (nrows <= 0 || ncols <= 0) return CLIORA_OK;
-    const int nt = ncols / 16, nrg = (nrows + 15) / 16;
-    const uint32_t* I = reinterpret_cast<const uint32_t*>(img3);
-    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
-#define R3_CASE(ct) hipLaunchKernelGGL((rows_gemm_ksplit3<ct, AP, EP>), dim3(nrgp * (nt / ct)), dim3(256), 0, st, I, K, nrg, nrgp, nrows, ap, ep)
-    if (nt % 5 == 0) R3_CASE(5);
-    else if (nt % 4 == 0) R3_CASE(4);
-    else if (nt % 2 == 0) R3_CASE(2);
-    else R3_CASE(1);
-#undef R3_CASE
-    LAUNCHOK("rows_gemm_ksplit3");
-    return CLIORA_OK;
-}
 // the RT x CT form (rows_gemm_ksplit3x): shape = 10 RT + CT
 template <class AP, class EP>
 static int launch_rows_direct3x(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep, int shape) {
@@ -617,6 +600,26 @@ static int launch_rows_direct3x(hipStream_t st, const float* img3, int K, int nc
     }
 #undef R3X_CASE
     LAUNCHOK("rows_gemm_ksplit3x");
+    return CLIORA_OK;
+}
+// out = A W^T on split-bf16 products, W as its frag_weight_image3 (ncols a multiple of 16 output columns, the image's first `ncols`;
+// K any multiple of 16): the TreeLSTM's gate projections and their backward in the default arithmetic mode
+template <class AP, class EP>
+static int launch_rows_direct3(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep) {
+    if (nrows <= 0 || ncols <= 0) return CLIORA_OK;
+    const int nt = ncols / 16, nrg = (nrows + 15) / 16;
+    const uint32_t* I = reinterpret_cast<const uint32_t*>(img3);
+    // RT x CT tiles (rows_gemm_ksplit3x) where the level has rows for them: CLIORA_GEMM3_SHAPE = 10 RT + CT, 0 = the 16 x 80 kernel below
+    static const int shape3 = [] { const char* e = getenv("CLIORA_GEMM3_SHAPE"); return e ? atoi(e) : 23; }();       // c5 L 20 / L 40: 5.54 / 30.56 ms (16 x 80) -> 5.38 / 29.21 (32 x 48); 2 x 2: 5.44 / 29.90, 2 x 5: 5.60 / 29.37
+    if (shape3 > 0 && nrows >= 256) return launch_rows_direct3x(st, img3, K, ncols, nrows, ap, ep, shape3);
+    const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
+#define R3_CASE(ct) hipLaunchKernelGGL((rows_gemm_ksplit3<ct, AP, EP>), dim3(nrgp * (nt / ct)), dim3(256), 0, st, I, K, nrg, nrgp, nrows, ap, ep)
+    if (nt % 5 == 0) R3_CASE(5);
+    else if (nt % 4 == 0) R3_CASE(4);
+    else if (nt % 2 == 0) R3_CASE(2);
+    else R3_CASE(1);
+#undef R3_CASE
+    LAUNCHOK("rows_gemm_ksplit3");
     return CLIORA_OK;
 }
 static int build_frag_images(hipStream_t st, const ImageList& l) {
