@@ -581,6 +581,13 @@ static int build_frag_images3(hipStream_t st, const ImageList& l) {       // spl
     LAUNCHOK("frag_weight_image3");
     return CLIORA_OK;
 }
+static int build_all_images(hipStream_t st, const ImageList& split, const ImageList& frag, const ImageList& frag3) {      // one launch for all three kinds
+    const int n = split.n + frag.n + frag3.n;
+    if (n == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(weight_images_all, dim3(256, 1, n), dim3(256), 0, st, split.tab, split.n, frag.tab, frag.n, frag3.tab);
+    LAUNCHOK("weight_images_all");
+    return CLIORA_OK;
+}
 // the RT x CT form (rows_gemm_ksplit3x): shape = 10 RT + CT
 template <class AP, class EP>
 static int launch_rows_direct3x(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep, int shape) {

@@ -96,11 +96,10 @@ extern "C" int cliora_lstm_forward(cliora_plan* plan, const cliora_params* P, co
             pj.add(ws + f.wl, ws + f.wl3, 3 * Dp, Dp, Dp); pj.add(ws + f.wlT, ws + f.wlT3, Dp, 3 * Dp, 3 * Dp);
             pj.add(ws + f.wcat, ws + f.wcat3, ldpi, Dp, Dp); pj.add(ws + f.wcatT, ws + f.wcatT3, Dp, ldpi, ldpi);
             pj.add(ws + f.w1ro, ws + f.w1ro3, ldpo, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, ldpo, ldpo);
-            OKR(build_frag_images(st, pj));
             ImageList p3;       // built in either mode: the backward call may run under the other one
             p3.add(ws + f.wcat, ws + f.wcat3s, ldpi, Dp, Dp); p3.add(ws + f.wcatT, ws + f.wcatT3s, Dp, ldpi, ldpi);
             p3.add(ws + f.w1ro, ws + f.w1ro3s, ldpo, Dp, Dp); p3.add(ws + f.w1roT, ws + f.w1roT3s, Dp, ldpo, ldpo);
-            OKR(build_frag_images3(st, p3));
+            OKR(build_all_images(st, ImageList{}, pj, p3));      // one launch
         }
     }
     const bool proj3 = lstm_proj_split();

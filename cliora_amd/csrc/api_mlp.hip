@@ -393,13 +393,9 @@ static int build_chart_images(const cliora_plan* plan, float* ws, bool compress,
     pj.add(ws + f.w1ro, ws + f.w1ro3, Dp, Dp, Dp); pj.add(ws + f.w1roT, ws + f.w1roT3, Dp, Dp, Dp);
     pj.add(ws + f.matp, ws + f.matq3, Dp, Dp, Dp);
     if (compress) { pj.add(ws + f.rootw, ws + f.rootw3, Dp, Dp, Dp); pj.add(ws + f.rootwT, ws + f.rootwT3, Dp, Dp, Dp); }
-    OKR(build_weight_images(st, im));
-    OKR(build_frag_images(st, pj));
-    if (p.arch == 0) {          // split-bf16 fragment images of the projection transposes (rows_gemm_ksplit3x: the backward's per-level GEMMs)
-        ImageList p3;
-        p3.add(ws + f.wcatT, ws + f.wcatT3s, Dp, ldpi, ldpi); p3.add(ws + f.w1roT, ws + f.w1roT3s, Dp, Dp, Dp);
-        OKR(build_frag_images3(st, p3));
-    }
+    ImageList p3;               // split-bf16 fragment images of the projection transposes (rows_gemm_ksplit3x: the backward's per-level GEMMs)
+    if (p.arch == 0) { p3.add(ws + f.wcatT, ws + f.wcatT3s, Dp, ldpi, ldpi); p3.add(ws + f.w1roT, ws + f.w1roT3s, Dp, Dp, Dp); }
+    OKR(build_all_images(st, im, pj, p3));
     return CLIORA_OK;
 }
 

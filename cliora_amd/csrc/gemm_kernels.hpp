@@ -299,14 +299,11 @@ __device__ __forceinline__ void split_bf16x8(const float4 a, const float4 b, u32
 constexpr int MAX_IMAGES = 12;
 struct SplitImageTab { const float* src[MAX_IMAGES]; uint32_t* dst[MAX_IMAGES]; int nrows[MAX_IMAGES], ldw[MAX_IMAGES], K[MAX_IMAGES]; };
 // grid = (ceil(max S / 256), max nrows, nmat); image m: row stride S = roundup32(K[m]) + WS3_PAD dwords
-static __global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
-    const int m = blockIdx.z;
+// one dword of the image: row `row`, dword p < S of image m
+__device__ __forceinline__ void split_image_dword(const SplitImageTab& tab, int m, int row, int p) {
     const int K = tab.K[m], Kp = (K + 31) / 32 * 32, S = Kp + WS3_PAD;
-    if ((int)blockIdx.y >= tab.nrows[m]) return;
-    const float* W = tab.src[m] + (size_t)blockIdx.y * tab.ldw[m];
-    uint32_t* img = tab.dst[m] + (size_t)blockIdx.y * S;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= S) return;
+    const float* W = tab.src[m] + (size_t)row * tab.ldw[m];
+    uint32_t* img = tab.dst[m] + (size_t)row * S;
     const int half = Kp >> 1;
     if (p >= Kp) { img[p] = 0u; return; }
     // operand dword pr of the row = k-step pr/16, lane group g = (pr%16)/4, register q = pr%4, holding the k pair
@@ -319,11 +316,18 @@ static __global__ __launch_bounds__(256) void split_weight_image(SplitImageTab t
     const uint32_t h = pack_bf16(v0, v1);
     img[p] = p < half ? h : pack_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
 }
+static __global__ __launch_bounds__(256) void split_weight_image(SplitImageTab tab) {
+    const int m = blockIdx.z;
+    const int S = (tab.K[m] + 31) / 32 * 32 + WS3_PAD;
+    if ((int)blockIdx.y >= tab.nrows[m]) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= S) return;
+    split_image_dword(tab, m, blockIdx.y, p);
+}
 
 // fp32 fragment image for rows_gemm_ksplit<.., FRAG = true>: float4 index ((ct * K/16 + ch) * 64 + lane) holds
 // W[ct*16 + (lane & 15)][ch*16 + 4*(lane >> 4) .. +3].  Same table as split_weight_image; grid = (ceil(max nrows*K/4 / 256), 1, nmat).
-static __global__ __launch_bounds__(256) void frag_weight_image(SplitImageTab tab) {
-    const int m = blockIdx.z;
+__device__ __forceinline__ void frag_image_body(const SplitImageTab& tab, int m) {
     const int K = tab.K[m], nch = K >> 4;
     const size_t n4 = (size_t)tab.nrows[m] * K / 4;
     float4* img = reinterpret_cast<float4*>(tab.dst[m]);
@@ -335,6 +339,7 @@ static __global__ __launch_bounds__(256) void frag_weight_image(SplitImageTab ta
         img[e] = *reinterpret_cast<const float4*>(src);
     }
 }
+static __global__ __launch_bounds__(256) void frag_weight_image(SplitImageTab tab) { frag_image_body(tab, blockIdx.z); }
 
 // per-lane select of a small POD (row context) on a wave-uniform condition: v_cndmask, no branch
 template <class T>
@@ -601,8 +606,7 @@ static __global__ __launch_bounds__(256) void rows_gemm_ksplit(const float* __re
 // operand order of split_weight_image, zero beyond K.  (Measured NOT to pay for DioraMLP's K = 1200 backward GEMM, which is
 // ingest-bound at its size: profiles/r04_notes.md.)  Score projections (QL) stay on exact fp32 products.
 // ---------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void frag_weight_image3(SplitImageTab tab) {
-    const int m = blockIdx.z;
+__device__ __forceinline__ void frag_image3_body(const SplitImageTab& tab, int m) {
     const int K = tab.K[m], nst = (K + 31) >> 5;
     const size_t n = (size_t)(tab.nrows[m] >> 4) * nst * 512;      // dwords: 16 columns x 32 k per (tile, step)
     uint32_t* img = tab.dst[m];
@@ -617,6 +621,21 @@ static __global__ __launch_bounds__(256) void frag_weight_image3(SplitImageTab t
         const uint32_t h = pack_bf16(v0, v1);
         img[e] = plane == 0 ? h : pack_bf16(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
     }
+}
+static __global__ __launch_bounds__(256) void frag_weight_image3(SplitImageTab tab) { frag_image3_body(tab, blockIdx.z); }
+// every weight image of a call in ONE launch (three launches in a row opened the forward: 17 us): blockIdx.z runs over the split images,
+// then the fp32 fragment images, then the bf16 fragment images; grid = (256, 1, ns + nf + n3)
+static __global__ __launch_bounds__(256) void weight_images_all(SplitImageTab split, int ns, SplitImageTab frag, int nf, SplitImageTab frag3) {
+    int m = blockIdx.z;
+    if (m < ns) {
+        const int S = (split.K[m] + 31) / 32 * 32 + WS3_PAD;
+        const size_t n = (size_t)split.nrows[m] * S;
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) split_image_dword(split, m, (int)(e / S), (int)(e % S));
+        return;
+    }
+    m -= ns;
+    if (m < nf) { frag_image_body(frag, m); return; }
+    frag_image3_body(frag3, m - nf);
 }
 
 template <int CT, class AProd, class Epi>
