@@ -82,7 +82,7 @@ for case in range(n_cases):
             P = R.init_params(D, share=share, seed=seed, compress=compress)
             m = load(DioraMLP(D, share=share, normalize=normalize, compress=compress), P, share)
             m.lazy_region_scores = False
-            mask = torch.nn.functional.dropout(torch.ones(B, C, Rr), 0.1, True)
+            mask = torch.bernoulli(torch.full((B, C, Rr), 0.9), generator=g) / 0.9        # dropout(p = 0.1) mask from the case's own generator: a re-run draws the same one
             m.dropout_mask = mask.cuda()
             xw = torch.randn(B, L, D, generator=g); ob = 0.3 * torch.randn(B, Rr, D, generator=g); ow = 0.3 * torch.randn(B, Rr, D, generator=g)
             tg = [t.clone().cuda().requires_grad_(True) for t in (x, xw, ob, ow)]
