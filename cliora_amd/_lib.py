@@ -125,21 +125,10 @@ def lib():
     L.cliora_set_mfma_mode.restype = i32
     L.cliora_set_wavefront.argtypes = [i32]
     L.cliora_set_wavefront.restype = i32
-    if hasattr(L, 'cliora_built_with_rows_stationary'):
-        L.cliora_built_with_rows_stationary.restype = i32
-    L.cliora_set_rows_stationary.argtypes = [i32]
-    L.cliora_set_rows_stationary.restype = i32
     L.cliora_set_resident.argtypes = [i32]
     L.cliora_set_resident.restype = i32
-    L.cliora_set_persistent.argtypes = [i32]
-    L.cliora_set_persistent.restype = i32
-    L.cliora_persistent_status.argtypes = [vp, C.POINTER(C.c_uint), vp]
-    L.cliora_persistent_status.restype = i32
-    if hasattr(L, 'cliora_persistent_inject_timeout'):      # diagnostics entry point (absent from older builds loaded through CLIORA_CHART_LIB)
-        L.cliora_persistent_inject_timeout.argtypes = [vp, vp]
-        L.cliora_persistent_inject_timeout.restype = i32
-    L.cliora_persistent_trace.argtypes = [vp, vp, sz, vp]
-    L.cliora_persistent_trace.restype = i32
+    L.cliora_resident_trace.argtypes = [vp, vp, sz, vp]
+    L.cliora_resident_trace.restype = i32
     _lib = L
     return L
 
@@ -252,43 +241,6 @@ def set_resident(mode):
     'auto' (default), 'off', 'on'.  Returns the previous mode's name."""
     prev = lib().cliora_set_resident(WAVEFRONT_MODES[mode])
     return {v: k for k, v in WAVEFRONT_MODES.items()}[prev]
-
-
-def set_persistent(mode):
-    """The level loop of the forward as one persistent launch (include/cliora_chart.h: cliora_set_persistent): 'auto' (default:
-    on where the kernel covers the plan), 'off' (two launches per level) or 'on'.  Results are bitwise identical.  Returns the
-    previous mode."""
-    prev = lib().cliora_set_persistent(WAVEFRONT_MODES[mode])
-    return {-1: 'auto', 0: 'off', 1: 'on'}[prev]
-
-
-RS_MODES = {'auto': -1, 'off': 0, 'on': 1, 'geometry': 2}
-
-
-def has_persistent():
-    """True when the library was built with the optional one-launch (persistent) forward (include/cliora_chart.h)."""
-    L = lib()
-    return bool(hasattr(L, 'cliora_built_with_persistent') and L.cliora_built_with_persistent())
-
-
-def has_rows_stationary():
-    """True when the library was built with the optional rows-stationary compose kernel (include/cliora_chart.h)."""
-    L = lib()
-    return bool(hasattr(L, 'cliora_built_with_rows_stationary') and L.cliora_built_with_rows_stationary())
-
-
-def set_rows_stationary(mode):
-    """Rows-stationary forward compose for big levels (include/cliora_chart.h: cliora_set_rows_stationary): 'auto', 'off', 'on'
-    or 'geometry' (its tasks on the weight-stationary kernel: bitwise the same results as 'on').  Returns the previous mode."""
-    prev = lib().cliora_set_rows_stationary(RS_MODES[mode])
-    return {v: k for k, v in RS_MODES.items()}[prev]
-
-
-def persistent_timeouts(plan, stream=0):
-    """Barrier waits of the persistent kernels that ever gave up on this plan's device (0 in normal operation); synchronises."""
-    n = C.c_uint()
-    check(lib().cliora_persistent_status(plan.handle, C.byref(n), C.c_void_p(stream)), 'cliora_persistent_status')
-    return n.value
 
 
 def set_mfma_mode(mode):

@@ -35,10 +35,7 @@ struct cliora_plan {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     const hipEvent_t* ev_level = nullptr;   // one per chart level: "this chain has finished level k" for the other chain
     std::mutex* lanes_mu = nullptr;
-    // persistent level-loop kernels (persist_kernels.hpp): one workgroup per CU that spins on grid-wide counters, so two of them
-    // must never share the device: every such launch waits for the previous one's event (device-wide chain, under lanes_mu)
     int ncu = 0;
-    hipEvent_t ev_persist = nullptr;
     // forward workspaces whose weight images were NOT built (resident forward; the last eight): a launch-path backward on one of them
     // builds them first.  Only a mode switch between a forward and its backward gets there (tests do that).
     const void* imageless_ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -51,10 +48,7 @@ struct cliora_plan {
         for (const void*& w : imageless_ws) if (w == ws && ws) { w = nullptr; return true; }
         return false;
     }
-    unsigned* persist_status = nullptr;     // device words: [0] barrier timeouts since the process started
-    // the timeout word as the host last saw it: after every persistent launch it is copied (async) to pinned host memory, and the next
-    // library call on the device looks at it (cliora_persist_check): a launch that gave up on a barrier left its chart partly written
-    struct PersistWatch* watch = nullptr;
+    unsigned long long* trace_words = nullptr;   // device words for diagnostic stamps (the device's, api_core.hip: DeviceLanes::trace)
     std::mutex upload_mu;                   // first-use upload of the tables (plans are shared between host threads)
 };
 
@@ -93,14 +87,7 @@ int cliora_ensure_max_lds(const void* fn);
 // uploads the plan's index tables on first use (current device) and checks that later calls run on that device
 int cliora_plan_ready(cliora_plan* plan, hipStream_t st);
 
-constexpr size_t PERSIST_TRACE_BYTES = (size_t)256 * 4 * (CLIORA_MAX_L + 1) * 10 * 8;   // [workgroup][phase][2] stamps behind the status words
-// device-wide watch of the persistent kernels' timeout word (api_core.hip)
-struct PersistWatch { unsigned* host = nullptr; hipEvent_t ev = nullptr; unsigned seen = 0; bool pending = false; };
-int cliora_persist_note(cliora_plan* plan, hipStream_t st);      // after a persistent launch on st
-int cliora_persist_check(cliora_plan* plan, bool wait = false);  // entry of a library call; wait: block until the last copy has landed
-// persistent level-loop kernels (api_persist.hip)
-namespace cliora { struct PersistFwd; }
-int cliora_launch_persist_fwd(hipStream_t st, const cliora::PersistFwd& a, int ct, int nwg);
+constexpr size_t TRACE_BYTES = (size_t)256 * 4 * (CLIORA_MAX_L + 1) * 10 * 8;   // diagnostic stamp words per device
 
 // ------------------------------------------------------------------ profiling (HIP events)
 struct ProfClass {
@@ -134,9 +121,6 @@ struct ProfScope {
 // Arithmetic of the pair-level GEMMs: 1 = split-bf16 (three bf16 MFMAs per product, fp32 accumulate; see
 // gemm_kernels.hpp), 0 = fp32-input MFMA (exact fp32 products).  CLIORA_MFMA=f32 selects the latter.
 extern int g_cliora_wavefront;      // -1 auto, 0 off, 1 two streams, 2 merged: one queue (include/cliora_chart.h: cliora_set_wavefront)
-extern int g_cliora_rows_stationary; // -1 auto, 0 off, 1 every eligible level, 2 the rows-stationary geometry on the weight-stationary kernel (tests)
-extern int g_cliora_rs_min_rows;      // auto: levels with at least this many pair rows (CLIORA_RS_MIN_ROWS)
-extern int g_cliora_persistent;     // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_persistent)
 extern int g_cliora_resident;       // -1 auto, 0 off, 1 on (include/cliora_chart.h: cliora_set_resident)
 extern int g_cliora_resident_max_pairs;   // auto: span pairs per sentence (both passes) up to which the sentence-resident kernels are taken
 extern int g_cliora_split_bf16;
@@ -589,6 +573,19 @@ static int build_all_images(hipStream_t st, const ImageList& split, const ImageL
     return CLIORA_OK;
 }
 // the RT x CT form (rows_gemm_ksplit3x): shape = 10 RT + CT
+static constexpr int GEMM3_SHAPES[] = {11, 21, 22, 32, 42, 23, 33, 25, 13, 15, 24, 12, 14};
+// a shape code from the environment, validated ONCE where it is read: an unknown code would otherwise fail every backward much later
+// with a bare CLIORA_EINVAL.  0 (where allowed) = the kernel the variable replaces; anything else not in GEMM3_SHAPES falls back to 23.
+static int gemm3_shape_env(const char* var, bool zero_ok) {
+    const char* e = getenv(var);
+    if (!e) return 23;
+    const int v = atoi(e);
+    if (v == 0 && zero_ok) return 0;
+    for (int s : GEMM3_SHAPES) if (s == v) return v;
+    fprintf(stderr, "cliora: %s=%s is not a tile shape of rows_gemm_ksplit3x (10 RT + CT in {11 21 22 32 42 23 33 25 13 15 24 12 14}%s); using 23\n", var, e,
+            zero_ok ? ", or 0" : "");
+    return 23;
+}
 template <class AP, class EP>
 static int launch_rows_direct3x(hipStream_t st, const float* img3, int K, int ncols, int nrows, AP ap, EP ep, int shape) {
     if (nrows <= 0 || ncols <= 0) return CLIORA_OK;
@@ -603,7 +600,7 @@ static int launch_rows_direct3x(hipStream_t st, const float* img3, int K, int nc
     switch (shape) {
         R3X_CASE(1, 1) R3X_CASE(2, 1) R3X_CASE(2, 2) R3X_CASE(3, 2) R3X_CASE(4, 2) R3X_CASE(2, 3) R3X_CASE(3, 3) R3X_CASE(2, 5)
         R3X_CASE(1, 3) R3X_CASE(1, 5) R3X_CASE(2, 4) R3X_CASE(1, 2) R3X_CASE(1, 4)
-        default: return CLIORA_EINVAL;
+        default: return fail(CLIORA_EINVAL, "rows_gemm_ksplit3x: tile shape code " + std::to_string(shape) + " is not instantiated (CLIORA_BWD_GEMM3 / CLIORA_GEMM3_SHAPE)");
     }
 #undef R3X_CASE
     LAUNCHOK("rows_gemm_ksplit3x");
@@ -617,7 +614,7 @@ static int launch_rows_direct3(hipStream_t st, const float* img3, int K, int nco
     const int nt = ncols / 16, nrg = (nrows + 15) / 16;
     const uint32_t* I = reinterpret_cast<const uint32_t*>(img3);
     // RT x CT tiles (rows_gemm_ksplit3x) where the level has rows for them: CLIORA_GEMM3_SHAPE = 10 RT + CT, 0 = the 16 x 80 kernel below
-    static const int shape3 = [] { const char* e = getenv("CLIORA_GEMM3_SHAPE"); return e ? atoi(e) : 23; }();       // c5 L 20 / L 40: 5.54 / 30.56 ms (16 x 80) -> 5.38 / 29.21 (32 x 48); 2 x 2: 5.44 / 29.90, 2 x 5: 5.60 / 29.37
+    static const int shape3 = gemm3_shape_env("CLIORA_GEMM3_SHAPE", true);       // c5 L 20 / L 40: 5.54 / 30.56 ms (16 x 80) -> 5.38 / 29.21 (32 x 48); 2 x 2: 5.44 / 29.90, 2 x 5: 5.60 / 29.37
     if (shape3 > 0 && nrows >= 256) return launch_rows_direct3x(st, img3, K, ncols, nrows, ap, ep, shape3);
     const int nrgp = nrg >= 8 ? (nrg + 7) / 8 * 8 : nrg;
 #define R3_CASE(ct) hipLaunchKernelGGL((rows_gemm_ksplit3<ct, AP, EP>), dim3(nrgp * (nt / ct)), dim3(256), 0, st, I, K, nrg, nrgp, nrows, ap, ep)

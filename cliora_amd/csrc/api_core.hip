@@ -105,7 +105,6 @@ extern "C" size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* na
     if (n == "nrmi") return f.nrmi;
     if (n == "nrmo") return f.nrmo;
     if (n == "qrleaf") return f.qrleaf;
-    if (n == "sync") return f.sync;
     if (n == "total") return f.total;
     return (size_t)-1;
 }
@@ -113,7 +112,7 @@ extern "C" size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* na
 extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
     if (!plan) return 0;
     const Plan& p = plan->p;
-    size_t n = p.pair_a_in.size() + p.pair_b_in.size() + p.pair_a_out.size() + p.pair_b_out.size() + p.lvl_base_in.size() + p.persist_levels.size() +
+    size_t n = p.pair_a_in.size() + p.pair_b_in.size() + p.pair_a_out.size() + p.pair_b_out.size() + p.lvl_base_in.size() + p.level_geom.size() +
                (p.arch == 1 ? 3 * (size_t)(p.R_in + p.R_out) : 0);     // the batch-expanded row maps: TreeLSTM plans only
     for (int r = 0; r < N_ROLES; ++r) n += p.uses[r].off.size() + 3 * p.uses[r].row.size();
     return n * sizeof(int32_t);
@@ -123,11 +122,9 @@ extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
 struct DeviceLanes {
     hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t fork[3], join[3], level[CLIORA_MAX_L + 1];
-    hipEvent_t persist = nullptr;       // end of the last persistent launch on this device
-    unsigned* status = nullptr;         // 16 device words, zeroed once
+    unsigned long long* trace = nullptr;    // TRACE_BYTES of device words for the diagnostic stamps of the resident kernels (CLIORA_RES_TRACE)
     int ncu = 0;
     std::mutex mu;
-    PersistWatch watch;
 };
 // Holds one workgroup for `ticks` of the 100 MHz wall clock: the probe of pick_concurrent_stream.
 static __global__ void lane_probe(long long ticks) {
@@ -209,14 +206,9 @@ static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
             HIPOK(hipEventCreateWithFlags(&ln->join[k], ev_flags));
         }
         for (int k = 0; k <= CLIORA_MAX_L; ++k) HIPOK(hipEventCreateWithFlags(&ln->level[k], ev_flags));
-        HIPOK(hipEventCreateWithFlags(&ln->persist, hipEventDisableTiming));
-        HIPOK(hipEventRecord(ln->persist, st));
-        HIPOK(hipMalloc((void**)&ln->status, 64 + PERSIST_TRACE_BYTES));
-        HIPOK(hipMemsetAsync(ln->status, 0, 64 + PERSIST_TRACE_BYTES, st));
+        HIPOK(hipMalloc((void**)&ln->trace, TRACE_BYTES));
+        HIPOK(hipMemsetAsync(ln->trace, 0, TRACE_BYTES, st));
         HIPOK(hipDeviceGetAttribute(&ln->ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        HIPOK(hipHostMalloc((void**)&ln->watch.host, 64, hipHostMallocDefault));
-        ln->watch.host[0] = 0;
-        HIPOK(hipEventCreateWithFlags(&ln->watch.ev, hipEventDisableTiming));
         g_lanes[dev] = ln;
     }
     *out = g_lanes[dev];
@@ -248,7 +240,7 @@ int cliora_plan_ready(cliora_plan* plan, hipStream_t st) {
     for (int k = 0; k < 3; ++k) { plan->ev_fork[k] = ln->fork[k]; plan->ev_join[k] = ln->join[k]; }
     plan->ev_level = ln->level;
     plan->lanes_mu = &ln->mu;
-    plan->ncu = ln->ncu; plan->ev_persist = ln->persist; plan->persist_status = ln->status; plan->watch = &ln->watch;
+    plan->ncu = ln->ncu; plan->trace_words = ln->trace;
     plan->device = dev;
     __atomic_store_n(&plan->uploaded, true, __ATOMIC_RELEASE);
     return CLIORA_OK;
@@ -377,28 +369,6 @@ extern "C" int cliora_set_wavefront(int mode) {
     return prev;
 }
 
-int g_cliora_persistent = [] { const char* e = getenv("CLIORA_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-int g_cliora_rows_stationary = [] { const char* e = getenv("CLIORA_ROWS_STATIONARY"); return e ? atoi(e) : -1; }();
-int g_cliora_rs_min_rows = [] { const char* e = getenv("CLIORA_RS_MIN_ROWS"); return e ? atoi(e) : 0x7fffffff; }();
-extern "C" int cliora_built_with_rows_stationary(void) {
-#ifdef CLIORA_WITH_ROWS_STATIONARY
-    return 1;
-#else
-    return 0;
-#endif
-}
-extern "C" int cliora_built_with_persistent(void) {
-#ifdef CLIORA_WITH_PERSISTENT
-    return 1;
-#else
-    return 0;
-#endif
-}
-extern "C" int cliora_set_rows_stationary(int mode) {
-    const int prev = g_cliora_rows_stationary;
-    g_cliora_rows_stationary = mode < 0 ? -1 : std::min(mode, 2);
-    return prev;
-}
 int g_cliora_resident = [] { const char* e = getenv("CLIORA_RESIDENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
 int g_cliora_resident_max_pairs = [] { const char* e = getenv("CLIORA_RESIDENT_MAX_PAIRS"); return e ? atoi(e) : 1000; }();
 extern "C" int cliora_set_resident(int mode) {
@@ -406,72 +376,12 @@ extern "C" int cliora_set_resident(int mode) {
     g_cliora_resident = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
     return prev;
 }
-extern "C" int cliora_set_persistent(int mode) {
-    const int prev = g_cliora_persistent;
-    g_cliora_persistent = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
-    return prev;
-}
-// A persistent launch that gives up on a grid barrier (another process held CUs for seconds) returns early with its chart partly
-// written and counts that in a device word.  The word follows every such launch to pinned host memory; the next call into the
-// library on that device looks at it and fails loudly instead of training on garbage: cliora_chart_backward waits for the copy (wait =
-// true: the backward of the same step is enqueued before the copy lands), cliora_chart_forward only queries.
-// Both run under the device's lanes mutex (the callers hold it).
-int cliora_persist_note(cliora_plan* plan, hipStream_t st) {
-    PersistWatch* w = plan->watch;
-    if (!w || !w->host) return CLIORA_OK;
-    HIPOK(hipMemcpyAsync(w->host, plan->persist_status, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIPOK(hipEventRecord(w->ev, st));
-    w->pending = true;
-    return CLIORA_OK;
-}
-int cliora_persist_check(cliora_plan* plan, bool wait) {
-    PersistWatch* w = plan->watch;
-    if (!w || !w->host) return CLIORA_OK;
-    if (w->pending) {
-        if (wait) HIPOK(hipEventSynchronize(w->ev));
-        else {
-            const hipError_t q = hipEventQuery(w->ev);
-            if (q == hipErrorNotReady) return CLIORA_OK;      // still in flight: the next call looks again
-            if (q != hipSuccess) return fail(CLIORA_EHIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
-        }
-        w->pending = false;
-    }
-    const unsigned now = __atomic_load_n(w->host, __ATOMIC_RELAXED);
-    if (now != w->seen) {
-        const unsigned n = now - w->seen;
-        w->seen = now;
-        return fail(CLIORA_EHIP, "a persistent level-loop launch gave up on " + std::to_string(n) + " grid barrier wait(s) (the device was shared): "
-                                 "the charts of that forward are incomplete and no gradient was produced from them; rerun the step, or set CLIORA_PERSISTENT=0");
-    }
-    return CLIORA_OK;
-}
-
-extern "C" int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream) {
-    if (!plan || !timeouts) return fail(CLIORA_EINVAL, "NULL argument");
-    if (!plan->uploaded) { *timeouts = 0; return CLIORA_OK; }
-    HIPOK(hipMemcpyAsync(timeouts, plan->persist_status, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPOK(hipStreamSynchronize((hipStream_t)stream));
-    return CLIORA_OK;
-}
-
-// diagnostics / tests: count one more given-up barrier wait in the device word, as a persistent launch that timed out would -- the
-// next persistent launch carries the word to the host and the library call after it fails (cliora_persist_check)
-static __global__ void persist_bump_status(unsigned* status) { atomicAdd(status, 1u); }
-extern "C" int cliora_persistent_inject_timeout(cliora_plan* plan, void* stream) {
-    if (!plan) return fail(CLIORA_EINVAL, "NULL argument");
-    if (!plan->uploaded) return fail(CLIORA_EINVAL, "no forward has run on this plan");
-    hipLaunchKernelGGL(persist_bump_status, dim3(1), dim3(1), 0, (hipStream_t)stream, plan->persist_status);
-    LAUNCHOK("persist_bump_status");
-    return CLIORA_OK;
-}
-
-// diagnostics: wall-clock stamps (100 MHz) of the last persistent launch traced with CLIORA_PERSIST_TRACE=1:
-// out[workgroup][phase 4*k + sub][2] = {after the wait, after the work}, `count` 64-bit words
-extern "C" int cliora_persistent_trace(cliora_plan* plan, unsigned long long* out, size_t count, void* stream) {
+// diagnostics: wall-clock stamps (100 MHz) of the last resident launch traced with CLIORA_RES_TRACE=1 (tools/resident_trace.py), `count` 64-bit words
+extern "C" int cliora_resident_trace(cliora_plan* plan, unsigned long long* out, size_t count, void* stream) {
     if (!plan || !out) return fail(CLIORA_EINVAL, "NULL argument");
     if (!plan->uploaded) return fail(CLIORA_EINVAL, "no forward has run on this plan");
-    if (count * 8 > PERSIST_TRACE_BYTES) return fail(CLIORA_EINVAL, "trace buffer holds fewer words");
-    HIPOK(hipMemcpyAsync(out, plan->persist_status + 16, count * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (count * 8 > TRACE_BYTES) return fail(CLIORA_EINVAL, "trace buffer holds fewer words");
+    HIPOK(hipMemcpyAsync(out, plan->trace_words, count * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPOK(hipStreamSynchronize((hipStream_t)stream));
     return CLIORA_OK;
 }

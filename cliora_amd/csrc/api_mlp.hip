@@ -3,12 +3,6 @@
 #include "api_common.hpp"
 #include <hip/hip_ext.h>
 #include "level_kernels.hpp"
-#ifdef CLIORA_WITH_ROWS_STATIONARY      // the rows-stationary forward compose (measured: no level of any shape selects it) is an optional build
-#include "compose_rs_kernels.hpp"
-#endif
-#ifdef CLIORA_WITH_PERSISTENT          // the one-launch forward (measured: AUTO selects it for no BASELINE configuration) is an optional build
-#include "persist_kernels.hpp"
-#endif
 #include "resident_kernels.hpp"
 #include "vl_kernels.hpp"
 
@@ -20,45 +14,12 @@
     } while (0)
 
 // ------------------------------------------------------------------ fused level kernels (level_kernels.hpp)
-// Geometry of a level's compose launch: the plan's tasks (plan.cpp compose_geom, shared with the persistent kernel so that both
-// paths sum in the same order) on at most `cap` workgroups per column block.
-struct ComposeLaunch { int TG, SP, ntask, gx; bool rs; };
-unsigned long long* g_rs_trace_buf = nullptr;      // diagnostic builds (-DCLIORA_RS_STAMPS): the plan's trace words
-// Rows-stationary forward compose (compose_rs_kernels.hpp) for the levels whose operand gathers outweigh re-streaming the weights:
-// measured on MI355X at d 400 (tools/shapes.py, profiles/r03_rows_stationary.txt).  Only the Dp = 400 kernel is instantiated.
-static bool rows_stationary_level(const Plan& p, int ncell, int N, bool vl) {
-#ifndef CLIORA_WITH_ROWS_STATIONARY
-    (void)p; (void)ncell; (void)N; (void)vl;
-    return false;
-#endif
-    if (g_cliora_rows_stationary == 0 || p.arch != 0 || p.Dp != 400 || N < 1 || N > 8 * HP_PARTS) return false;
-    (void)vl;
-    if (g_cliora_rows_stationary > 0) return true;
-    return (long long)ncell * N >= g_cliora_rs_min_rows;
-}
-static bool plan_has_rows_stationary_levels(const Plan& p) {
-    for (int pass = 0; pass < 2; ++pass)
-        for (int level = pass ? 0 : 1; level < (pass ? p.L - 1 : p.L); ++level) {
-            const int32_t* e = p.persist_levels.data() + ((size_t)(pass ? p.L : 0) + level) * PLEVEL_INTS;
-            if (rows_stationary_level(p, p.B * e[0], e[1], false)) return true;
-        }
-    return false;
-}
-static ComposeLaunch compose_launch(const cliora_plan* plan, int level, bool outside_pass, bool vl) {
+// Geometry of a level's compose launch: the plan's tasks (plan.cpp compose_geom) on at most `cap` workgroups per column block.
+struct ComposeLaunch { int TG, SP, ntask, gx; };
+static ComposeLaunch compose_launch(const cliora_plan* plan, int level, bool outside_pass) {
     const Plan& p = plan->p;
-    const int32_t* e = p.persist_levels.data() + ((size_t)(outside_pass ? p.L : 0) + level) * PLEVEL_INTS;
-    if (rows_stationary_level(p, p.B * e[0], e[1], vl)) {
-        const ComposeGeom q = compose_geom_rs(p.B * e[0], e[1]);
-        if (q.TG > 0) {
-            if (g_cliora_rows_stationary == 2) {         // the same tasks on the weight-stationary kernel
-                ComposeLaunch w{q.TG, q.SP, q.ntask, std::min(q.ntask, p.compose_cap), false};
-                if (w.gx >= 8 && (w.gx + 7) / 8 * 8 <= p.compose_cap) w.gx = (w.gx + 7) / 8 * 8;
-                return w;
-            }
-            return ComposeLaunch{q.TG, q.SP, q.ntask, std::min(q.ntask, std::max(1, plan->ncu)), true};
-        }
-    }
-    ComposeLaunch q{e[5], e[6], e[7], std::min(e[7], p.compose_cap), false};
+    const int32_t* e = p.level_geom.data() + ((size_t)(outside_pass ? p.L : 0) + level) * PLEVEL_INTS;
+    ComposeLaunch q{e[5], e[6], e[7], std::min(e[7], p.compose_cap)};
     // workgroups are dealt round-robin over the 8 XCDs by linear id (x + y*gx): with gx a multiple of 8 the column blocks
     // that gather the same operand rows share one XCD's L2 (speed only, never correctness)
     if (q.gx >= 8 && (q.gx + 7) / 8 * 8 <= p.compose_cap) q.gx = (q.gx + 7) / 8 * 8;
@@ -89,26 +50,6 @@ static int launch_level_compose(hipStream_t st, const float* W, const float* Wim
     const bool f32 = !split_bf16();
     const uint32_t* I = reinterpret_cast<const uint32_t*>(f32 ? W : Wimg);
     const int S = f32 ? Dp : S3;
-#ifdef CLIORA_WITH_ROWS_STATIONARY
-    if (q.rs) {
-        unsigned long long* rs_trace = nullptr;
-#ifdef CLIORA_RS_STAMPS
-        { static const char* e = getenv("CLIORA_RS_TRACE_ROWS"); if (e && g_rs_trace_buf && lv.ncell * lv.N == atoi(e)) rs_trace = g_rs_trace_buf; }
-#endif
-        if (ct != 5 || Dp != 400 || (lv.N + q.SP - 1) / q.SP > 8 / q.TG) return fail(CLIORA_EINVAL, "rows-stationary compose: shape or geometry not covered");
-        if (f32) {
-            OKR(cliora_ensure_max_lds((const void*)level_compose_fwd_rs<5, 25, true>));
-            hipLaunchKernelGGL((level_compose_fwd_rs<5, 25, true>), dim3(q.gx), dim3(512), rs_lds_bytes<5>(), st, I, S, lv, PA, lda, PB, ldb, bias, Pp,
-                               q.TG, q.SP, q.ntask, ncb, HP, hp_stride, Dp, ymask, Y, rs_trace);
-        } else {
-            OKR(cliora_ensure_max_lds((const void*)level_compose_fwd_rs<5, 25, false>));
-            hipLaunchKernelGGL((level_compose_fwd_rs<5, 25, false>), dim3(q.gx), dim3(512), rs_lds_bytes<5>(), st, I, S, lv, PA, lda, PB, ldb, bias, Pp,
-                               q.TG, q.SP, q.ntask, ncb, HP, hp_stride, Dp, ymask, Y, rs_trace);
-        }
-        LAUNCHOK("level_compose_fwd_rs");
-        return CLIORA_OK;
-    }
-#endif
 #define LC_ARGS st, I, S, Dp, ncb, lv, PA, lda, PB, ldb, bias, Pp, HP, hp_stride, Dp, ymask, Y, q
 #define LC_CASE(c, k16) return f32 ? launch_level_compose_inst<c, k16, true>(LC_ARGS) : launch_level_compose_inst<c, k16, false>(LC_ARGS)
     if (ct == 5 && Dp == 400) LC_CASE(5, 25);
@@ -249,8 +190,13 @@ static int launch_level_compose2(hipStream_t st, const ComposeSeg& a, const Comp
 #undef LC2_CASE
 #undef LC2_ARGS
 }
-// diagnostics (timing experiments, WRONG results): CLIORA_P2_DIAG bit 0: no score blocks, bit 1: no projection blocks
+// diagnostics (timing experiments, WRONG results; only in a build with -DCLIORA_DIAG_P2, tools/ab/build_variant.sh -- the shipped library
+// ignores the variable): CLIORA_P2_DIAG bit 0: no score blocks, bit 1: no projection blocks
+#ifdef CLIORA_DIAG_P2
 static int p2_diag() { static const int d = [] { const char* e = getenv("CLIORA_P2_DIAG"); return e ? atoi(e) : 0; }(); return d; }
+#else
+static constexpr int p2_diag() { return 0; }
+#endif
 template <int SP0, int SP1>
 static int launch_level_project2_inst(hipStream_t st, const ProjSeg& a_, const ProjSeg& b_) {
     ProjSeg a = a_, b = b_;
@@ -299,42 +245,15 @@ static bool merged_pays(const Plan& p, bool vl) {
     if (p.arch != 0 || p.L <= 2) return false;
     if (g_cliora_wavefront != 2 && !(g_cliora_wavefront < 0 && wavefront_pays(p, -1))) return false;
     for (size_t e = 0; e < (size_t)2 * p.L; ++e) {
-        const int sp = p.persist_levels[e * PLEVEL_INTS + 6];
-        if (p.persist_levels[e * PLEVEL_INTS + 1] > 0 && !project2_parts_ok(sp)) return false;
+        const int sp = p.level_geom[e * PLEVEL_INTS + 6];
+        if (p.level_geom[e * PLEVEL_INTS + 1] > 0 && !project2_parts_ok(sp)) return false;
     }
     return true;
 }
 
-// The level loop as ONE persistent launch (persist_kernels.hpp) when the shape allows: text-only DioraMLP, every handed-over buffer
-// within the 32-bit offsets of a buffer descriptor, at least one CU per resident weight block.  Measured on MI355X
-// (tools/persist_ab.py, profiles/r03_persist_ab.txt): the one launch wins where the levels are launch-bound (D <= 64: forward
-// 0.240 -> 0.201 ms at B 8 / L 10, 0.384 -> 0.345 at B 16 / L 16) and loses at D = 400 (1.10 -> 1.22 ms at B 64 / L 20): a
-// persistent workgroup is 8 waves per CU, and the projection / score phases are latency chains that the launch-per-level
-// kernels hide with 32 waves per CU.  AUTO therefore takes it for Dp <= 64; cliora_set_persistent / CLIORA_PERSISTENT=0|1 force
-// it off / on (on is still refused for shapes the kernel does not cover).
-static bool persist_pays(const cliora_plan* plan, bool vl) {
-#ifndef CLIORA_WITH_PERSISTENT
-    (void)plan; (void)vl;
-    return false;
-#else
-    const Plan& p = plan->p;
-    if (g_cliora_persistent == 0 || vl || p.arch != 0 || p.L < 2) return false;
-    if (plan_has_rows_stationary_levels(p)) return false;       // their geometry is not the plan's (the kernel's level table)
-    if (g_cliora_persistent < 0 && p.Dp > 64) return false;
-    const size_t lim = 0xfff00000ull;
-    const size_t BC = (size_t)p.B * p.C;
-    if (BC * p.nblk * p.Dp * 4 > lim || (size_t)HP_PARTS * BC * p.Dp * 4 > lim || (size_t)(p.R_in + p.R_out) * 4 > lim) return false;
-    const int nslots = p.fwd.ncb3 * (p.share ? 1 : 2);
-    if (plan->ncu < nslots || plan->ncu < 8 || p.L > PK_MAX_L) return false;
-    const size_t image = (size_t)p.fwd.ct3 * 16 * (split_bf16() ? p.fwd.S3 : p.Dp) * sizeof(uint32_t);
-    if (image + PK_LDS_EXTRA > 160 * 1024) return false;
-    return true;
-#endif
-}
-
 // One workgroup per sentence for every level of both passes (resident_kernels.hpp) when a row fits a wavefront: text-only DioraMLP,
 // Dp <= 64, no per-pair hook states.  Measured on MI355X (tools/resident_ab.py, profiles/r03_resident_ab.txt), forward / forward +
-// backward ms, launches (persistent forward where AUTO takes it) -> resident:
+// backward ms, launches -> resident:
 //   D 50 / B 8 / L 10 (configs[0])   0.198 -> 0.196 / 0.80 -> 0.56        D 50 / B 256 / L 10   0.31 -> 0.23 / 1.59 -> 1.25
 //   D 32 / B 64 / L 12               0.246 -> 0.211 / 1.07 -> 0.86        D 16 / B 128 / L 8    0.159 -> 0.094 / 0.75 -> 0.51
 //   D 64 / B 64 / L 16               0.36 -> 0.46 / 1.40 -> 1.81          D 64 / B 8 / L 40     1.19 -> 3.84 / 3.0 -> 11.7
@@ -422,7 +341,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
-    OKR(cliora_persist_check(plan));
     ForkGuard fork_guard(st);                          // declared after the lock: runs (joins the side streams) before it is released
     float* ws = (float*)fwd_ws;
     const FwdLayout& f = p.fwd;
@@ -564,18 +482,16 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     // (which waits for the event of inside step k-1: its riding scores of level L-k-1 read inside level k-1).  The 2(L-1)
     // dependent levels of the reference become L steps of two concurrent, latency-bound launches (tools/ubench/wavefront_bench.hip:
     // two streams run such kernels side by side at the cost of one; an event dependency per step adds 3 us).
-    const bool persist = !resident && !compress && persist_pays(plan, vl);
     // round 5: the same wavefront on ONE queue -- the two passes' launches of a step as one grid each (level_compose_fwd2 /
     // level_project2): no side stream, no event per step (merged_pays)
-    const bool merged = run_outside && !persist && !compress && !resident && merged_pays(p, vl);
-    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !persist && !compress && !resident && !merged;
+    const bool merged = run_outside && !compress && !resident && merged_pays(p, vl);
+    const bool two_streams = wavefront_pays(p, g_cliora_wavefront) && run_outside && !compress && !resident && !merged;
     hipStream_t sa = st, sb = two_streams ? plan->side : st;
 
     auto inside_step = [&](int level, hipEvent_t project_stop) -> int {          // diora.py:295-331 for one level
         const LevelArgs g = level_args(p, level, false);
         const int ncell = B * g.Lc;
-        g_rs_trace_buf = reinterpret_cast<unsigned long long*>(plan->persist_status + 16);
-        const ComposeLaunch cq = compose_launch(plan, level, false, vl);
+        const ComposeLaunch cq = compose_launch(plan, level, false);
         const int SP = cq.SP;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sa);
@@ -607,7 +523,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
     auto outside_step = [&](int level) -> int {         // diora.py:358-398 for one level
         const LevelArgs g = level_args(p, level, true);
         const int ncell = B * g.Lc;
-        const ComposeLaunch cq = compose_launch(plan, level, true, vl);
+        const ComposeLaunch cq = compose_launch(plan, level, true);
         const int SP = cq.SP;
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, sb);
@@ -629,7 +545,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         // QR = M h of the leaves: the partner of a newest-level LEFT child is always a leaf (see level_project)
         OKR(launch_rows_direct(st, ws + f.matp, PROJ_IMG(f.matq3), Dp, Dp, B * L, LevelRowsA{IH, Dp, C, 0, L},
                                StoreRowsE{ws + f.qrleaf, Dp, nullptr, 0, Dp}));
-        if (!persist) OKR(launch_scores(st, score_args(1, false, -1, 0)));
+        OKR(launch_scores(st, score_args(1, false, -1, 0)));
     }
     if (two_streams) {
         HIPOK(hipEventRecord(plan->ev_fork[0], st));
@@ -649,7 +565,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             LAUNCHOK("unit_norm_rows(root)");
             if (L > 1) {
                 OKR(launch_rows_direct(sb, ws + f.w1ro, PROJ_IMG(f.w1ro3), Dp, Dp, B, LevelRowsA{OH, Dp, C, C - 1, 1}, StoreLevelE{ws + f.po, Dp, C, C - 1, 1, nullptr, 0}));
-                if (!persist) OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
+                OKR(launch_scores(sb, score_args(L - 2, true, -1, 0)));
             }
         } else {
             HIPOK(hipMemsetAsync(OH, 0, (size_t)B * C * Dp * sizeof(float), st));
@@ -658,40 +574,6 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         return CLIORA_OK;
     };
     if (!compress) OKR(init_root());
-#ifdef CLIORA_WITH_PERSISTENT
-    if (persist) {
-        // ---- every level of both passes in one launch (persist_kernels.hpp): the first scores of both chains included ----
-        PersistFwd a{};
-        a.tabs = p.d_tables; a.lev = reinterpret_cast<const PLevel*>(p.d_tables + p.dev.persist_levels);
-        a.pa_in = (uint32_t)p.dev.pair_a_in; a.pb_in = (uint32_t)p.dev.pair_b_in;
-        a.pa_out = (uint32_t)p.dev.pair_a_out; a.pb_out = (uint32_t)p.dev.pair_b_out;
-        a.PI = ws + f.pi; a.PO = ws + f.po; a.HPi = HPi; a.HPo = HPo; a.Pp = ws + f.pp; a.Sp = ws + f.sp;
-        a.IH = IH; a.OH = OH; a.IS = IS; a.OS = OS; a.nrmi = ws + f.nrmi; a.nrmo = ws + f.nrmo;
-        a.ymask = YM; a.Y = PH; a.QRleaf = ws + f.qrleaf;
-        const bool f32 = !split_bf16();
-        a.Wimg[0] = reinterpret_cast<const uint32_t*>(f32 ? ws + f.w2i : ws + f.w2i3);
-        a.Wimg[1] = reinterpret_cast<const uint32_t*>(f32 ? ws + f.w2o : ws + f.w2o3);
-        a.b2[0] = ws + f.b2i; a.b2[1] = ws + f.b2o;
-        a.wcat_frag = ws + f.wcat3; a.bcat = ws + f.bcat; a.w1ro_frag = ws + f.w1ro3;
-        a.sync = reinterpret_cast<unsigned*>(ws + f.sync); a.status = plan->persist_status;
-        static const bool trace_env = [] { const char* e = getenv("CLIORA_PERSIST_TRACE"); return e && atoi(e) != 0; }();
-        a.trace = (trace_env && plan->ncu <= 256) ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
-        a.B = B; a.L = L; a.C = C; a.Dp = Dp; a.ldpi = ldpi; a.blk_plo = p.blk_plo; a.blk_qlo = p.blk_qlo; a.normalize = p.normalize;
-        a.share = p.share; a.S = f.S3; a.K = Dp; a.ncb = f.ncb3; a.run_outside = run_outside;
-        const size_t BC = (size_t)B * C;
-        a.hp_stride_bytes = (uint32_t)(hp_stride * sizeof(float));
-        a.bytes_PI = (uint32_t)(BC * ldpi * 4); a.bytes_PO = (uint32_t)(BC * Dp * 4); a.bytes_HP = (uint32_t)((size_t)HP_PARTS * BC * Dp * 4);
-        a.bytes_R = (uint32_t)((size_t)(p.R_in + p.R_out) * 4); a.bytes_H = (uint32_t)(BC * Dp * 4); a.bytes_S = (uint32_t)(BC * 4);
-        HIPOK(hipMemsetAsync(a.sync, 0, PK_SYNC_WORDS * sizeof(unsigned), st));
-        HIPOK(hipStreamWaitEvent(st, plan->ev_persist, 0));           // never two spinning grids on one device
-        {
-            ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
-            OKR(cliora_launch_persist_fwd(st, a, f.ct3, plan->ncu));
-        }
-        HIPOK(hipEventRecord(plan->ev_persist, st));
-        OKR(cliora_persist_note(plan, st));
-    }
-#endif
     if (resident) {
         // ---- one workgroup per sentence, every level of both passes (resident_kernels.hpp) ----
         ResArgs a = resident_args(plan, ws, IH, OH, IS, OS, run_outside);
@@ -699,7 +581,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         if (padded) { a.outIH = inside_h; a.outOH = run_outside ? outside_h : nullptr; }     // the un-padded charts straight from the kernel
         if (!keep) a.ymask = nullptr;
         static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
-        a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
+        a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->trace_words) : nullptr;
         OKR(cliora_ensure_max_lds((const void*)resident_fwd));
         ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
         hipLaunchKernelGGL(resident_fwd, dim3(std::min(B, std::max(1, plan->ncu))), dim3(RES_THREADS), resident_lds_bytes(p), st, a);
@@ -709,7 +591,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
         const bool f32w = !split_bf16();
         auto compose_seg = [&](int level, bool outside_pass) {
             ComposeSeg sg{};
-            const int32_t* e = p.persist_levels.data() + ((size_t)(outside_pass ? L : 0) + level) * PLEVEL_INTS;
+            const int32_t* e = p.level_geom.data() + ((size_t)(outside_pass ? L : 0) + level) * PLEVEL_INTS;
             const float* w = outside_pass ? (f32w ? ws + f.w2o : ws + f.w2o3) : (f32w ? ws + f.w2i : ws + f.w2i3);
             sg.Wimg = reinterpret_cast<const uint32_t*>(w);
             sg.lv = pair_level(level, outside_pass);
@@ -766,7 +648,7 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
             OKR(launch_level_project2(st, (ca.gx && !vl) ? ca.SP : 1, cb.gx ? cb.SP : 1, qa, qb));
         }
     }
-    for (int k = 1; k <= L && !persist && !resident && !merged; ++k) {
+    for (int k = 1; k <= L && !resident && !merged; ++k) {
         if (k <= L - 1) {
             const bool by_kernel = two_streams && stop_events_on() && !vl && k < L - 1;      // the step ends with a level_project launch
             OKR(inside_step(k, by_kernel ? plan->ev_level[k] : nullptr));
@@ -817,10 +699,6 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     hipStream_t st = (hipStream_t)stream;
     OKR(cliora_plan_ready(plan, st));
     std::lock_guard<std::mutex> lanes_lock(*plan->lanes_mu);
-    // the forward of this step may have run as one persistent launch: its timeout word is WAITED for here (a host sync, on the persistent
-    // path only) -- an asynchronous step enqueues this backward before the word's copy has landed, and a chart left partly written must
-    // fail this call, not the next step's forward after clip + Adam have applied its gradients
-    OKR(cliora_persist_check(plan, true));
     ForkGuard fork_guard(st);
     fork_guard.arm(1, plan->side2, plan->ev_join[1]);     // the weight-gradient stream takes work at several points of the call
     const Dev dv = dev_views(p);
@@ -878,7 +756,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     // fp32-input MFMA (16 x 16 x 4 in 32 cycles) -- and each remedy alone lost (profiles/r05_notes.md section 14); split-bf16 products on
     // 32 x 48 tiles take both: c2 3.005 -> 2.905 ms, L 40 16.37 -> 16.19.  Shapes 22 / 32 / 24: 2.95-2.96; 42 / 33 / 25 / 13 / 15: 3.0-3.14.
     // CLIORA_BWD_GEMM3=0: the fp32 16 x 16 kernel (always in the exact-fp32 arithmetic mode).
-    static const int bwd_gemm3 = [] { const char* e = getenv("CLIORA_BWD_GEMM3"); return e ? atoi(e) : 23; }();
+    static const int bwd_gemm3 = gemm3_shape_env("CLIORA_BWD_GEMM3", true);
     static const int bwd_gemm3_min = [] { const char* e = getenv("CLIORA_BWD_GEMM3_MIN"); return e ? atoi(e) : 0; }();     // 0 / 128 / 256 / 512 / 768 cells: 2.905 / 2.91 / 2.92 / 2.92 / 2.94
     auto gemm3_pays = [&](int ncell) { return bwd_gemm3 > 0 && split_bf16() && ncell >= bwd_gemm3_min; };
     // X / DZ of the pair rows as tiled split-bf16 operands (wgrad_tiles.hpp) instead of fp32 rows.  CLIORA_PAIR_TILES=0: off.
@@ -1101,7 +979,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         a.dIH = d_inside_h; a.dIS = d_inside_s; a.dOH = d_outside_h; a.dOS = d_outside_s;
         a.VHo = VHo; a.dPI = dPI; a.dPO = dPO; a.DA = DA; a.DS = DS; a.DZ = DZ; a.Xrows = Xp; a.dU = dU; a.dX = d_x_span;
         static const bool res_trace = [] { const char* e = getenv("CLIORA_RES_TRACE"); return e && atoi(e) != 0; }();
-        a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->persist_status + 16) : nullptr;
+        a.trace = res_trace ? reinterpret_cast<unsigned long long*>(plan->trace_words) : nullptr;
         OKR(cliora_ensure_max_lds((const void*)resident_bwd));
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, st);

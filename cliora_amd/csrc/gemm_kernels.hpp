@@ -1275,7 +1275,7 @@ static __global__ __launch_bounds__(256) void tn_gemm_dma3(const float* __restri
 }
 
 // tn_gemm_dma3x: tn_gemm_dma3 with EIGHT waves (two per SIMD).  With one wave per SIMD everything a stage needs besides its 189 MFMAs
-// -- 17 LDS-DMA pieces (100-250 issue cycles each, the price measured in compose_rs_kernels.hpp), the operand reads and splits -- sits in
+// -- 17 LDS-DMA pieces (100-250 issue cycles each, the price measured with round 3's rows-stationary kernel, profiles/r03_rows_stationary.txt), the operand reads and splits -- sits in
 // that wave's own instruction stream: 8 500 cycles per 32-row stage for 3 024 cycles of MFMA (28 % MFMA-busy by PMC).  Here wave w takes
 // the i-tiles of wave w & 3 of the four-wave kernel and HALF of the block's j-tiles (NJW = ceil(NJT / 2); the second half has a spare
 // slot, which carries the ones-tile of the bias gradient in block 0), so that one wave's DMA issue and operand forming run under its

@@ -14,7 +14,6 @@
 //                        the newest level and its partner is then a leaf, so the scoring needs none of the new projections
 //   (level_scores: the scoring alone, for the first level of a pass; level_finish: norm + chart rows of a level without projections)
 //
-// The same device code runs as phases of ONE persistent launch in persist_kernels.hpp (cliora_set_persistent), bitwise equal.
 //
 // Tile order.  A 16-row MFMA tile is (16 consecutive target cells t = b*Lc + p of the level) x (ONE split n): the N tiles of
 // a "cell tile" differ only in n, so the weighted sum over the splits is an element-wise FMA into a register accumulator --

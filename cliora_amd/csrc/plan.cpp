@@ -33,20 +33,6 @@ ComposeGeom compose_geom(int ncell, int N, int cap) {
     return best;
 }
 
-ComposeGeom compose_geom_rs(int ncell, int N) {
-    const int G = (ncell + 15) / 16;
-    ComposeGeom best{0, 0, 0};
-    int best_slots = 1 << 30;
-    for (int SP = 1; SP <= HP_PARTS && SP <= std::max(1, N); ++SP)
-        for (int TG : {8, 4, 2, 1}) {                   // more cell tiles per task first: less idle at equal slot count
-            const int wpg = 8 / TG;
-            if ((N + SP - 1) / SP > wpg) continue;
-            const int slots = SP * wpg;
-            if (slots < best_slots) { best_slots = slots; best = ComposeGeom{TG, SP, (G + TG - 1) / TG * SP}; }
-        }
-    return best;
-}
-
 // Compose workgroups per column block that level `lv` of a pass (0 inside, 1 outside) may count on: step k of the forward composes
 // inside level k and outside level L-k side by side, so each gets its share of compose_cap -- by pair rows
 // (shared weights: any workgroup serves either pass), or the half that holds its weight image (unshared).
@@ -224,7 +210,6 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         f.att_u = take(R > 0 ? BC * Dp : 0);
         f.att_pk = take(R > 0 ? BC * 64 : 0);
         f.att_nrmu = take(R > 0 ? BC : 0);
-        f.sync = take(1280);
         f.rootw = take(arch == 0 ? Dp * Dp : 0); f.rootwT = take(arch == 0 ? Dp * Dp : 0);
         f.rootw3 = arch == 0 ? img(Dp, Dp) : o; f.rootwT3 = arch == 0 ? img(Dp, Dp) : o;
         f.rootpb = take(arch == 0 ? (size_t)B * Dp : 0);
@@ -285,17 +270,16 @@ std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, i
         v.slab = take(v.slab_floats);
         v.total = o;
     }
-    // ---- per-level shapes and compose geometry (the launch-per-level path and the persistent kernels use the same) ----
+    // ---- per-level shapes and compose geometry (one entry per pass and level) ----
     // sized for one workgroup per CU of a 256-CU part, the column blocks of a task on one XCD: ((256 / 8) / ncb) * 8 per block
     p.compose_cap = std::max(1, (32 / std::max(1, p.fwd.ncb3))) * 8;
     if (p.fwd.ncb3 > 32) p.compose_cap = std::max(1, 256 / p.fwd.ncb3);
-    p.persist_levels.assign((size_t)2 * L * PLEVEL_INTS, 0);
-    // Step k of the forward composes inside level k and outside level L-k side by side (in the persistent
-    // kernel as ONE task list): each level's geometry is sized for its share of the compose workgroups, by pair rows
+    p.level_geom.assign((size_t)2 * L * PLEVEL_INTS, 0);
+    // Step k of the forward composes inside level k and outside level L-k side by side: each level's geometry is sized for its share of the compose workgroups, by pair rows
     // (shared weights), or for the half that holds its weight image (unshared).
     for (int pass = 0; pass < 2; ++pass)
         for (int lv = 0; lv < L; ++lv) {
-            int32_t* e = p.persist_levels.data() + ((size_t)pass * L + lv) * PLEVEL_INTS;
+            int32_t* e = p.level_geom.data() + ((size_t)pass * L + lv) * PLEVEL_INTS;
             const int Lc = L - lv, N = pass ? L - lv - 1 : lv;
             e[0] = Lc; e[1] = N; e[2] = p.level_offset[lv];
             e[3] = (int32_t)(pass ? p.row_base_out(lv) : p.row_base_in(lv));
@@ -354,7 +338,7 @@ std::vector<int32_t> flatten_tables(Plan& p) {
     }
     p.dev.lvl_base_in = put(p.lvl_base_in);
     p.dev.lvl_base_out = put(p.lvl_base_out);
-    p.dev.persist_levels = put(p.persist_levels);
+    p.dev.level_geom = put(p.level_geom);
     if (p.arch == 1) build_row_maps(p);
     p.dev.arow = put(p.arow); p.dev.brow = put(p.brow); p.dev.trow = put(p.trow);
     if (flat.empty()) flat.push_back(0);
@@ -369,7 +353,7 @@ const std::vector<int32_t>* find_table(Plan& p, const std::string& name) {
     if (name == "pair_b_out") return &p.pair_b_out;
     if (name == "pair_lvl_base_in") return &p.lvl_base_in;
     if (name == "pair_lvl_base_out") return &p.lvl_base_out;
-    if (name == "persist_levels") return &p.persist_levels;
+    if (name == "level_geom") return &p.level_geom;
     if (name == "tile_base_in") return &p.tile_base_in_;          // 16-row tiles of the pair rows (wgrad_tiles.hpp): first tile of a level, per pass
     if (name == "tile_base_out") return &p.tile_base_out_;
     if (name == "arow" || name == "brow" || name == "trow") build_row_maps(p);

@@ -21,7 +21,7 @@ constexpr int ROLE_OUTB = 3;  // outside cell used as PARENT in the outside pass
 constexpr int N_ROLES = 4;
 constexpr int HP_PARTS = 4;        // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
 constexpr int CLIORA_MAX_L = 64;   // sentence length bound: one split per lane in the score kernels
-constexpr int PLEVEL_INTS = 8;     // ints per entry of Plan::persist_levels (struct PLevel of persist_kernels.hpp)
+constexpr int PLEVEL_INTS = 8;     // ints per entry of Plan::level_geom {Lc, N, level offset, pair-row base, pair-table base, TG, SP, ntask}
 
 struct UseList {
     std::vector<int32_t> off;      // C+1, CSR offsets per cell
@@ -59,7 +59,6 @@ struct FwdLayout {
     size_t nrmi, nrmo;                  // per-cell pre-normalisation norm (B*C)
     size_t icp, ocp, nrmic, nrmoc, rootc;   // TreeLSTM: cell-state charts (B*C x Dp), their norms, padded root c
     size_t att_u, att_pk, att_nrmu;     // CLIORA per inside cell: u = unit(aggregate) (B*C x Dp), region probabilities (B*C x 64), |aggregate| (B*C)
-    size_t sync;                        // 1280 words (PK_SYNC_WORDS): the barrier words of the persistent level-loop kernels (zeroed by every call)
     size_t total;
 };
 
@@ -102,7 +101,7 @@ struct Plan {
     std::vector<int32_t> arow, brow, trow;
     // per (pass, level): {Lc, N, chart offset, first pair row, offset into the pass's pair tables, TG, SP, ntask} -- the level's
     // shape and the task geometry of its compose kernel (compose_geom), inside levels first; 2 * L entries of PLEVEL_INTS ints
-    std::vector<int32_t> persist_levels;
+    std::vector<int32_t> level_geom;
     int compose_cap;          // compose workgroups per column block that geometry is sized for
     FwdLayout fwd;
     BwdLayout bwd;
@@ -112,7 +111,7 @@ struct Plan {
     // device copies (filled lazily by the HIP side)
     int32_t* d_tables = nullptr;
     size_t d_tables_count = 0;
-    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out, persist_levels; } dev;
+    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out, level_geom; } dev;
 
     int Lc(int level) const { return L - level; }
     int Nin(int level) const { return level; }
@@ -133,9 +132,6 @@ struct Plan {
 struct ComposeGeom { int TG, SP, ntask; };
 ComposeGeom compose_geom(int ncell, int N, int cap);
 int compose_cap_share(const Plan& p, int pass, int lv);   // the cap a level's geometry is sized for: its share of Plan::compose_cap in its wavefront step
-// Geometry of the rows-stationary compose kernel (compose_rs_kernels.hpp): every wave takes ONE split, so a task covers
-// SP x (8 / TG) split slots >= N; the fullest slot table wins, fewer parts on a tie.  TG = 0: no such geometry (N > 32).
-ComposeGeom compose_geom_rs(int ncell, int N);
 
 // Builds every host table and the workspace layouts.  Returns "" or an error message.
 std::string build_plan(Plan& p, int B, int L, int D, int share, int normalize, int R, int arch = 0);

@@ -1,8 +1,8 @@
 // Sentence-resident chart kernels for small hidden sizes (Dp <= 64; BASELINE configs[0]: d 50, batch 8, length 10) (gfx950).
 //
-// At these sizes a chart level is a few hundred pair rows for the whole batch: the launch-per-level path (level_kernels.hpp) and
-// the persistent level loop (persist_kernels.hpp) are both bound by what separates two levels -- a launch boundary or a grid-wide
-// barrier -- not by the work.  The sentences of a batch never exchange anything inside the recursion (diora.py:295-331, 358-398
+// At these sizes a chart level is a few hundred pair rows for the whole batch: the launch-per-level path (level_kernels.hpp) is
+// bound by what separates two levels -- a launch boundary (or, in round 3's one-launch level loop, a grid-wide barrier:
+// profiles/r03_persist_ab.txt) -- not by the work.  The sentences of a batch never exchange anything inside the recursion (diora.py:295-331, 358-398
 // index one sentence's chart only), so here ONE WORKGROUP owns ONE SENTENCE and walks every level of both passes by itself:
 // the only thing between two levels is a workgroup barrier.  Sixteen waves; a wave owns a chart cell of the level:
 //

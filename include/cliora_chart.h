@@ -315,38 +315,14 @@ int cliora_set_mfma_mode(int mode);
 #define CLIORA_WAVEFRONT_AUTO (-1)
 #define CLIORA_WAVEFRONT_OFF 0
 #define CLIORA_WAVEFRONT_ON 1
-/* MERGED (round 5; text-only DioraMLP plans): the same wavefront on ONE queue -- step k runs ONE compose grid over inside level k and
- * outside level L-k and ONE projection / score grid for both, on the caller's stream: no side stream and no cross-stream event per
- * step.  AUTO takes it wherever the two-stream form would pay; ON keeps the two streams; other plans treat MERGED as ON.  Bitwise the
- * same results again (CLIORA_WAVEFRONT=2). */
+/* MERGED (DioraMLP and CLIORA plans, R >= 0): the same wavefront on ONE queue -- step k of the FORWARD runs ONE compose grid over
+ * inside level k and outside level L-k and ONE projection / score grid for both, on the caller's stream (CLIORA plans: the region
+ * attention of the new inside cells, cliora.py:140-157, between the two grids): no side stream and no cross-stream event per step.
+ * AUTO takes it wherever the two-stream form would pay; ON keeps the two streams.  TreeLSTM plans and compress = True treat MERGED
+ * as ON (two streams); the backward always runs its two chains on two streams.  Bitwise the same results again
+ * (CLIORA_WAVEFRONT=2). */
 #define CLIORA_WAVEFRONT_MERGED 2
 int cliora_set_wavefront(int mode);
-
-/* The level loop as one launch.  By default (CLIORA_PERSISTENT_AUTO; the environment variable CLIORA_PERSISTENT=0|1 sets the
- * initial value) the forward of a text-only DioraMLP plan runs every level of both passes (cliora/net/diora.py:312-331, 378-398)
- * inside ONE persistent kernel -- one workgroup per CU that keeps its block of the compose weight in LDS across all levels,
- * with the level boundaries as grid-wide counter barriers (csrc/persist_kernels.hpp) -- instead of two launches per level.
- * OFF runs the launch-per-level path.  Results are bitwise identical either way.  Such a kernel owns the device while it
- * runs: the library chains these launches device-wide; cliora_persistent_status reports (after synchronising `stream`) how
- * many barrier waits ever gave up (another process held CUs for seconds), 0 in normal operation.  Process-wide; returns the
- * previous mode. */
-#define CLIORA_PERSISTENT_AUTO (-1)
-#define CLIORA_PERSISTENT_OFF 0
-#define CLIORA_PERSISTENT_ON 1
-int cliora_set_persistent(int mode);
-int cliora_persistent_status(cliora_plan* plan, unsigned* timeouts, void* stream);
-/* Round 5: AUTO selects this kernel for no BASELINE configuration (d = 400: the launches win, profiles/r03_persist_ab.txt; configs[0]:
- * the sentence-resident kernels come first), so it is an OPTIONAL part of the build: csrc compiled with -DCLIORA_WITH_PERSISTENT
- * (`CLIORA_BUILD_EXTRA=-DCLIORA_WITH_PERSISTENT python -m cliora_amd.build --force`).  Without it cliora_set_persistent still records
- * the mode but every forward runs the launch-per-level (or sentence-resident) path.  1 if built in. */
-int cliora_built_with_persistent(void);
-/* A persistent launch that gives up on a barrier leaves its charts partly written.  The library does not let that pass silently:
- * the timeout word follows every persistent launch to pinned host memory.  cliora_chart_backward WAITS for the word of the last
- * persistent launch on the device (a host synchronisation, on the persistent path only) and returns CLIORA_EHIP if it has moved --
- * so the backward of the same step fails before any gradient is produced; cliora_chart_forward looks at it without waiting
- * (an inference loop sees the failure at its next call).
- * cliora_persistent_inject_timeout (diagnostics, tests) counts one such give-up in the device word without any launch failing. */
-int cliora_persistent_inject_timeout(cliora_plan* plan, void* stream);
 
 /* One workgroup per sentence.  For a text-only DioraMLP plan whose rows fit a wavefront (D <= 64; BASELINE configs[0]) the level
  * loops of the forward (cliora/net/diora.py:312-331, 378-398) and of the backward run inside ONE launch each, a workgroup walking
@@ -361,31 +337,16 @@ int cliora_persistent_inject_timeout(cliora_plan* plan, void* stream);
 #define CLIORA_RESIDENT_ON 1
 int cliora_set_resident(int mode);
 
-/* Rows-stationary forward compose (csrc/compose_rs_kernels.hpp) for the big levels of a d = 400 DioraMLP / CLIORA plan: the two
- * operand rows of a span pair (cliora/net/diora.py:112-118, get_inside_states) are gathered ONCE and kept in registers while the
- * second compose layer's weight (diora.py:65-72) streams through LDS, instead of once per block of 80 output columns.  AUTO
- * (default; CLIORA_ROWS_STATIONARY=0|1 sets the initial value) takes it for the levels with at least CLIORA_RS_MIN_ROWS pair rows
- * and at most 32 splits -- no level by default: on MI355X the kernel ties with the weight-stationary one at L = 40 and loses
- * below (DESIGN.md section 4c has the in-kernel trace); ON for every level with at most 32 splits; OFF never.  GEOMETRY_ONLY (2, tests) deals the tasks
- * the rows-stationary way but runs them on the weight-stationary kernel: with the same tasks the two kernels agree to the bit.
- * The split range of a cell is cut into parts differently in the two geometries, so AUTO / ON and OFF agree to fp32 rounding of
- * the aggregate (sum over the splits), not to the bit.  Process-wide; returns the previous mode. */
-#define CLIORA_ROWS_STATIONARY_AUTO (-1)
-#define CLIORA_ROWS_STATIONARY_OFF 0
-#define CLIORA_ROWS_STATIONARY_ON 1
-#define CLIORA_ROWS_STATIONARY_GEOMETRY_ONLY 2
-int cliora_set_rows_stationary(int mode);
-/* Round 4: AUTO selects the kernel for no level of any shape, so it is an OPTIONAL part of the build (csrc compiled with
- * -DCLIORA_WITH_ROWS_STATIONARY: `CLIORA_BUILD_EXTRA=-DCLIORA_WITH_ROWS_STATIONARY python -m cliora_amd.build --force`).  Without
- * it cliora_set_rows_stationary still records the mode but every level runs the weight-stationary kernel.  1 if built in. */
-int cliora_built_with_rows_stationary(void);
-
 /* Float offset of a named region of the forward workspace ("pi", "po", "hp", "hp_o", "sp", "pp", "ymask", "nrmi", "nrmo", "t",
- * "qrleaf", "sync", "total"), for tests and tooling that compare two runs region by region; (size_t)-1 for an unknown name. */
+ * "qrleaf", "total"), for tests and tooling that compare two runs region by region; (size_t)-1 for an unknown name. */
 size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* name);
 
 /* Bytes of device index tables the plan uploads at its first use. */
 size_t cliora_plan_device_bytes(const cliora_plan* plan);
+
+/* Diagnostics: the wall-clock stamps (100 MHz) the sentence-resident kernels leave when CLIORA_RES_TRACE=1 (tools/resident_trace.py):
+ * copies `count` 64-bit words of the device's stamp buffer to `out` (host) after synchronising `stream`. */
+int cliora_resident_trace(cliora_plan* plan, unsigned long long* out, size_t count, void* stream);
 
 const char* cliora_version(void);
 

@@ -13,10 +13,10 @@ static int check(const Plan& p) {
     if ((int)p.pair_a_in.size() != p.P_in || (int)p.pair_a_out.size() != p.P_out) return 2;
     for (int v : p.pair_a_in) if (v < 0 || v >= C) return 3;
     for (int v : p.pair_b_out) if (v < 0 || v >= C) return 4;
-    if ((int)p.persist_levels.size() != 2 * L * PLEVEL_INTS) return 5;
+    if ((int)p.level_geom.size() != 2 * L * PLEVEL_INTS) return 5;
     for (int pass = 0; pass < 2; ++pass)
         for (int lv = 0; lv < L; ++lv) {
-            const int32_t* e = p.persist_levels.data() + ((size_t)pass * L + lv) * PLEVEL_INTS;
+            const int32_t* e = p.level_geom.data() + ((size_t)pass * L + lv) * PLEVEL_INTS;
             const int N = pass ? L - lv - 1 : lv;
             if (e[0] != L - lv || e[1] != N) return 6;
             if (e[5] < 1 || e[5] > 8 || e[6] < 1 || e[6] > HP_PARTS || e[7] < 1) return 7;
@@ -45,7 +45,7 @@ int main() {
                         if (rc) { printf("check %d failed for B %d L %d D %d share %d arch %d\n", rc, B, L, D, share, arch); return rc; }
                         std::vector<int32_t> flat = flatten_tables(p);
                         if (flat.empty()) return 11;
-                        if (p.dev.persist_levels + p.persist_levels.size() > flat.size()) return 12;
+                        if (p.dev.level_geom + p.level_geom.size() > flat.size()) return 12;
                         build_row_maps(p);
                         if (p.arow.size() != (size_t)(p.R_in + p.R_out)) return 13;
                         if (!find_table(p, "use_row_outb") || find_table(p, "nope")) return 14;
@@ -54,13 +54,6 @@ int main() {
     Plan bad;
     if (build_plan(bad, 1, 65, 16, 1, 1, 0, 0).empty()) return 20;      // L > 64 is refused
     if (build_plan(bad, 1, 4, 16, 1, 1, 3, 1).empty()) return 21;       // TreeLSTM with image regions is refused
-    {   // geometry of the rows-stationary compose kernel: one split per wave, fullest slot table
-        for (int N = 1; N <= 40; ++N) {
-            const ComposeGeom q = compose_geom_rs(64 * 7, N);
-            if (N > 8 * HP_PARTS) { if (q.TG != 0) return 22; continue; }
-            if (q.TG < 1 || q.SP < 1 || q.SP > HP_PARTS || (N + q.SP - 1) / q.SP > 8 / q.TG) return 23;
-        }
-    }
     printf("plans ok: %d\n", n);
     return 0;
 }

@@ -63,7 +63,6 @@ def test_resident_and_launch_paths_agree_in_every_combination(B, L, D, share, no
     P, x, cot = synth.diora_case(D, B, L, 3 if B == 300 else 77 + L, share=share)
     m = _module_from_params(P, D, share, normalize)
     prev_mode = _lib.set_mfma_mode('f32')
-    prev_p = _lib.set_persistent('off')
     try:
         base_o, base_g = _run(m, x, cot, 'off', 'off')
         # without unit normalisation the vectors (and every rounding error) grow with the level
@@ -84,7 +83,6 @@ def test_resident_and_launch_paths_agree_in_every_combination(B, L, D, share, no
         for n in g1:
             assert torch.equal(g1[n], g2[n]), n
     finally:
-        _lib.set_persistent(prev_p)
         _lib.set_mfma_mode(prev_mode)
 
 
@@ -130,7 +128,6 @@ def test_resident_no_grad_and_inside_only():
     D, B, L = 50, 6, 9
     P, x, _ = synth.diora_case(D, B, L, 5)
     res = {}
-    prev_p = _lib.set_persistent('off')
     prev_m = _lib.set_mfma_mode('f32')
     try:
         for outside in (True, False):
@@ -150,4 +147,3 @@ def test_resident_no_grad_and_inside_only():
         assert float(res[(False, 'on')]['outside_h'].abs().max()) == 0.0
     finally:
         _lib.set_mfma_mode(prev_m)
-        _lib.set_persistent(prev_p)

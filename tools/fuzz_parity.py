@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Random-shape parity sweep of the HIP path against the CPU oracle (outputs and gradients), over the module variants and the schedule
-switches: DioraMLP / CLIORA / DioraTreeLSTM, share, normalize, compress, arithmetic mode, wavefront, persistent, rows-stationary, sentence-resident.
+switches: DioraMLP / CLIORA / DioraTreeLSTM, share, normalize, compress, arithmetic mode, wavefront, sentence-resident.
 Not a test (the committed tests pin chosen cases): a tool for hunting shape-dependent bugs.   python tools/fuzz_parity.py [n] [seed] [small]
 ('small': text-only DioraMLP at D <= 64 only -- the shapes of the sentence-resident kernels)"""
 import os
@@ -54,13 +54,12 @@ for case in range(n_cases):
     compress = arch != 'treelstm' and rnd.random() < 0.25
     Rr = rnd.randint(1, 40)
     mode = rnd.choice(['f32', 'bf16x3'])
-    wf, ps = rnd.choice(['auto', 'off', 'on', 'merged']), rnd.choice(['auto', 'off', 'on'])
-    rs = rnd.choice(['auto', 'on', 'geometry']) if D == 400 else 'auto'
+    wf = rnd.choice(['auto', 'off', 'on', 'merged'])
     rd = rnd.choice(['auto', 'off', 'on']) if D <= 64 else 'auto'
     seed = rnd.randint(0, 10 ** 6)
     desc = dict(arch=arch, D=D, L=L, B=B, share=share, normalize=normalize, compress=compress, R=Rr if arch == 'cliora' else 0, mode=mode,
-                wavefront=wf, persistent=ps, rows_stationary=rs, resident=rd, seed=seed)
-    _lib.set_mfma_mode(mode); _lib.set_wavefront(wf); _lib.set_persistent(ps); _lib.set_rows_stationary(rs); _lib.set_resident(rd)
+                wavefront=wf, resident=rd, seed=seed)
+    _lib.set_mfma_mode(mode); _lib.set_wavefront(wf); _lib.set_resident(rd)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, L, D, generator=g)
     C = L * (L + 1) // 2

@@ -1,4 +1,4 @@
-"""A/B of the level-loop schedules for small hidden sizes: launches per level (+ the persistent forward where AUTO takes it) vs the
+"""A/B of the level-loop schedules for small hidden sizes: launches per level vs the
 sentence-resident kernels (csrc/resident_kernels.hpp), forward-only and forward + backward ms over a few chart shapes.
 python tools/resident_ab.py"""
 import os

@@ -15,7 +15,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 plan=_lib.get_plan(B,L,D,True,'unit',0,torch.cuda.current_device())
 buf=np.zeros(256+8*L,dtype=np.uint64)
-_lib.check(_lib.lib().cliora_persistent_trace(plan.handle, buf.ctypes.data_as(C.c_void_p), buf.size, None),'trace')
+_lib.check(_lib.lib().cliora_resident_trace(plan.handle, buf.ctypes.data_as(C.c_void_p), buf.size, None),'trace')
 f=buf[256:].reshape(L,8).astype(np.float64)/100.0
 t=buf[:4*L].reshape(L,4).astype(np.float64)/100.0
 for lv in range(2,L):
@@ -32,7 +32,7 @@ for _ in range(3):
     m(x,x); torch.autograd.backward([getattr(m,k) for k in keys], cots)
 torch.cuda.synchronize()
 buf=np.zeros(512+16*L,dtype=np.uint64)
-_lib.check(_lib.lib().cliora_persistent_trace(plan.handle, buf.ctypes.data_as(C.c_void_p), buf.size, None),'trace')
+_lib.check(_lib.lib().cliora_resident_trace(plan.handle, buf.ctypes.data_as(C.c_void_p), buf.size, None),'trace')
 g=buf[512:].reshape(L,16).astype(np.float64)/100.0
 print('backward, per step j: outside cell (level j) | inside cell (level L-1-j): gather, project, dnorm, pairs [us]; step span')
 for j in range(L):
