@@ -67,7 +67,7 @@ def host_cpu():
 def port_vs_reference():
     """Measured wall-time ratio of the oracle to the imported reference (tools/cpu_port_check.py, build container: the reference cannot
     travel to the GPU box) -- SURVEY 8(d) wants the port within +-10 %; the committed measurement is printed beside the baseline."""
-    for cand in ('r05_cpu_port_check.json',):
+    for cand in ('r06_cpu_port_check.json', 'r05_cpu_port_check.json'):
         fp = os.path.join(ROOT, 'profiles', cand)
         if os.path.exists(fp):
             try:
@@ -120,10 +120,50 @@ def cpu_baseline(L, D, B, budget_s=25.0):
         one = dict(value=round(8 / t1, 3), unit='sentences/s', sample='1 step of 8 sentences, 1 thread, %.2f s' % t1)
     finally:
         torch.set_num_threads(threads)
+    pvr = port_vs_reference()
+    ratio = (pvr or {}).get('d400_ratio')
     return dict(value=b / med, unit='sentences/s', cores=threads, kind='port',
+                # the oracle port runs `ratio` x the imported reference's wall time on the same inputs (measured in the build container, where the
+                # reference exists): what the reference itself would do on THIS host's cores, as an estimate, beside the raw port figure
+                reference_estimate=(round(b / med * ratio, 3) if ratio else None), port_over_reference_time=ratio,
                 sample='%d steps of %d sentences (L=%d, d=%d), chart fwd+bwd, torch %s CPU oracle, %d threads, median %.2f s/step, %.1f s total'
                        % (len(times), b, L, D, torch.__version__, threads, med, t_all),
-                host=host_cpu(), one_thread=one, port_vs_reference=port_vs_reference())
+                host=host_cpu(), one_thread=one, port_vs_reference=pvr)
+
+
+CPU_CACHE = os.path.join(ROOT, 'gpurun_out', 'cpu_baseline_cache.json')
+
+
+def remember_cpu_baseline(key, rec):
+    """The N = 1 run leaves its CPU figure where the N > 1 runs of the same box find it (SCALE runs N = 1, 2, 4, 8 back to back)."""
+    try:
+        os.makedirs(os.path.dirname(CPU_CACHE), exist_ok=True)
+        j = json.load(open(CPU_CACHE)) if os.path.exists(CPU_CACHE) else {}
+        j[key] = dict(rec, measured_at=time.strftime('%Y-%m-%dT%H:%M:%S'), hostname=os.uname().nodename)
+        json.dump(j, open(CPU_CACHE, 'w'))
+    except (OSError, ValueError):
+        pass
+
+
+def carried_cpu_baseline(key, committed):
+    """N > 1 lines: the CPU baseline is timed at N = 1 only (rank 0); this carries that figure beside the N-GPU value -- from the N = 1 run of
+    this box if it left one (same hostname), else the figure committed under profiles/ -- labelled as carried, never re-timed here."""
+    try:
+        if os.path.exists(CPU_CACHE):
+            rec = json.load(open(CPU_CACHE)).get(key)
+            if rec and rec.get('hostname') == os.uname().nodename:
+                return dict(rec, carried_from='the N = 1 run of this box (%s)' % rec.get('measured_at'))
+    except (OSError, ValueError):
+        pass
+    fp = os.path.join(ROOT, 'profiles', committed)
+    try:
+        line = [ln for ln in open(fp).read().splitlines() if ln.strip().startswith('{')][-1]
+        rec = json.loads(line).get('cpu_baseline')
+        if rec:
+            return dict(rec, carried_from='profiles/%s (committed N = 1 line, another box of the same pool)' % committed)
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
 
 
 def cpu_baseline_c3(L, D, B, budget_s=20.0):
@@ -171,7 +211,9 @@ def cpu_baseline_c3(L, D, B, budget_s=20.0):
 def shape_traffic(label):
     """Committed PMC traffic per step of one of the other workloads (tools/pmc_shape.sh: 2 x FETCH_SIZE + WRITE_SIZE over every kernel of a
     3-step run, own --pmc passes), or None."""
-    fp = os.path.join(ROOT, 'profiles', 'r05_traffic_shapes.json')
+    fp = os.path.join(ROOT, 'profiles', 'r06_traffic_shapes.json')
+    if not os.path.exists(fp):
+        fp = os.path.join(ROOT, 'profiles', 'r05_traffic_shapes.json')
     if not os.path.exists(fp):
         return None
     try:
@@ -180,7 +222,7 @@ def shape_traffic(label):
         return None
     if not j:
         return None
-    return dict(bytes_per_step=j['total_bytes_per_step'], file='profiles/r05_traffic_shapes.json', commit=j.get('commit', 'not recorded'),
+    return dict(bytes_per_step=j['total_bytes_per_step'], file='profiles/' + os.path.basename(fp), commit=j.get('commit', 'not recorded'),
                 kind='committed rocprofv3 PMC figure (2 x FETCH_SIZE + WRITE_SIZE over every kernel of the step), not collected in this run',
                 top_kernels=dict(list(j.get('by_kernel', {}).items())[:5]))
 
@@ -211,14 +253,30 @@ def algorithmic_bytes(plan, B, D, cell_floats=None):
 
 
 def launch_ranks(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher around it: start torch.distributed.run as a CHILD process (this
-    process has not touched the GPU and never does) and pass its exit code on."""
+    """`python bench.py --gpus N` with N > 1 (or `--via-launcher` at N = 1) and no launcher around it: start torch.distributed.run as a
+    CHILD process (this process has not touched the GPU and never does) and pass its exit code on."""
     port = os.environ.get('MASTER_PORT', '29533')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-port', port, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--via-launcher'] + ['--launched']
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     return subprocess.call(cmd, env=env)
+
+
+def rank_view(torch, dist, dev, dt, steps, use_dist, world):
+    """What proves the N-rank launch: ranks_seen = an all-reduce of ones over the process group (RCCL saw that many ranks), and every
+    rank's own ms per step (min / max over ranks: stragglers).  Returns (max-over-ranks seconds, dict)."""
+    if not use_dist:
+        ms = dt / steps * 1e3
+        return dt, dict(ranks_seen=1, per_rank_ms_per_step=dict(min=round(ms, 4), max=round(ms, 4)), process_group=None)
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per = [float(t.item()) / steps * 1e3 for t in every]
+    return max(float(t.item()) for t in every), dict(ranks_seen=int(round(float(ones.item()))), process_group=dist.get_backend(),
+                                                      per_rank_ms_per_step=dict(min=round(min(per), 4), max=round(max(per), 4), all=[round(v, 4) for v in per]))
 
 
 def timed_steps(torch, step, fence, n):
@@ -392,10 +450,7 @@ def cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, u
     for _ in range(args.warmup):
         step()
     dt, step_ms = timed_steps(torch, step, fence, args.steps)
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, ranks = rank_view(torch, dist, dev, dt, args.steps, use_dist, world)
     if rank == 0:
         plan = _lib.get_plan(B, L, D, True, 'unit', Rg, local)
         step_bytes, _ = algorithmic_bytes(plan, B, D)
@@ -412,6 +467,8 @@ def cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, u
                                    % (D, B, L, 3 if world > 1 else 2),
                        'global_batch': world * B, 'length': L, 'dim': D, 'mfma': mfma_mode,
                        'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU',
+                       'ranks_seen': ranks['ranks_seen'], 'world_size': world, 'via_launcher': bool(args.launched),
+                       'per_rank_ms_per_step': ranks['per_rank_ms_per_step'],
                        **({'gradient_exchange': 'RCCL all-reduce (backend %s) of one flat fp32 buffer of %d floats per step (chart + heads + ImageEncoder); '
                                                 '%d of %d gradients copied in (the chart backward writes the rest in place)'
                                                 % (args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
@@ -421,8 +478,14 @@ def cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, u
                              achieved=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                              frac=round((step_bytes + scorer_bytes) / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4), traffic=shape_traffic('c3_step'),
                              model='SURVEY.md section 8(d) chart bytes (%d per step) + the (B, B, C, 36) scorer tensor three times (%d)' % (step_bytes, scorer_bytes)),
-            'cpu_baseline': cpu_baseline_c3(L, D, B) if (world == 1 and not args.no_cpu_baseline) else None,
         }
+        if args.no_cpu_baseline:
+            out['cpu_baseline'] = None
+        elif world == 1:
+            out['cpu_baseline'] = cpu_baseline_c3(L, D, B)
+            remember_cpu_baseline('c3', out['cpu_baseline'])
+        else:
+            out['cpu_baseline'] = carried_cpu_baseline('c3', 'r06_bench_c3.json')
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -449,9 +512,13 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the f32-mode / other-shape / whole-step side figures')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the gradient all-reduce even at world size 1 (self-test of the N>1 path)')
     ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL on ROCm)')
+    ap.add_argument('--via-launcher', action='store_true',
+                    help='take the N > 1 launch route at any N (also --gpus 1): this process starts torch.distributed.run as a child, the rank '
+                         'initialises the process group and runs the gradient all-reduce -- the exact path `--gpus 8` takes, testable on one GPU')
+    ap.add_argument('--launched', action='store_true', help=argparse.SUPPRESS)      # set by launch_ranks() on the ranks it starts
     args = ap.parse_args()
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or args.via_launcher) and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args))
 
     import torch
@@ -467,7 +534,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    use_dist = world > 1 or args.force_dist
+    use_dist = world > 1 or args.force_dist or args.launched
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
@@ -511,10 +578,7 @@ def main():
     kclasses = ('compose_fwd', 'compose_bwd', 'wgrad')
     events = (rank == 0) and not args.no_kernel_events
     dt, step_ms = timed_steps(torch, step, fence, args.steps)
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, ranks = rank_view(torch, dist, dev, dt, args.steps, use_dist, world)
     # Second pass of the same K steps with a HIP event pair around every launch of the three GEMM classes (on the
     # launch stream), for the roofline object.  It is separate from the timed region above because the event records
     # serialise neighbouring launches; every rank runs the steps so the all-reduces stay matched, only rank 0 records events.
@@ -598,7 +662,7 @@ def main():
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command, so that
             # frac can be reproduced from profiles/ alone (the two clocks agree within a few per cent)
             rocprof = None
-            for cand in ('r05_kernel_stats.csv', 'r04_kernel_stats.csv', 'r03_kernel_stats.csv', 'r02_kernel_stats.csv'):
+            for cand in ('r06_kernel_stats.csv', 'r05_kernel_stats.csv', 'r04_kernel_stats.csv'):
                 kp = os.path.join(ROOT, 'profiles', cand)
                 if os.path.exists(kp):
                     import csv
@@ -610,28 +674,61 @@ def main():
                             break
                     break
             hbm_bound = t_hbm >= t_mfma
+            t_roof = max(t_hbm, t_mfma)
+            # The kernel's duration with the chip to itself (third pass, wavefront off) is the one that agrees with the committed
+            # rocprofv3 --kernel-trace --stats average (the profiler runs the two chains' kernels one after the other): `frac`, `achieved`
+            # and `avg_launch_ms` are quoted on it.  The second pass's figure -- HIP events around every launch while the other chain
+            # shares the chip, the records themselves barrier packets -- is reported beside it as `frac_as_run` / `avg_launch_ms_as_run`.
+            alone = kern_seq.get(dom) if kern_seq.get(dom) and kern_seq[dom]['launches'] else None
+            t_alone = (alone['total_ms'] / n_seq * 1e-3) if alone else t_meas
+            avg_alone_ms = (alone['total_ms'] / alone['launches']) if alone else avg_ms
+            # Whole step against SURVEY 8(d): t_roof = max(bytes / HBM peak, executed FLOPs / MFMA peak of the arithmetic each part uses).
+            # FLOPs of the factored formulation per step: pair layers 2 D^2 per pair (forward) + twice that (backward: u = W2^T dz, dW2);
+            # per-cell projections 10 D^2 per cell and chart (forward, exact fp32 MFMA in both modes) + twice that (backward: split-bf16 in the
+            # default mode).  Split-bf16 parts issue 3 bf16 MFMAs per product: priced at the bf16 peak / 3.
+            C_cells = L * (L + 1) // 2
+            cell_fwd = 10.0 * Dp * Dp * C_cells * B
+            if mfma_mode == 'bf16x3':
+                t_step_mfma = (3.0 * flops_class + 2.0 * cell_fwd) / (PEAK_BF16_MFMA_TFLOPS / 3.0 * 1e12) + cell_fwd / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            else:
+                t_step_mfma = (3.0 * flops_class + 3.0 * cell_fwd) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            t_step_hbm = step_bytes / (PEAK_HBM_GBS * 1e9)
+            t_step = dt / args.steps
+            ws_bound = 'hbm' if t_step_hbm >= t_step_mfma else 'mfma'
+            ws_frac = max(t_step_hbm, t_step_mfma) / t_step
             roof = dict(bound='hbm' if hbm_bound else 'mfma', kernel='level_' + dom,
-                        achieved=round(ach_gb if hbm_bound else ach_tf, 2), peak=PEAK_HBM_GBS if hbm_bound else round(peak_mfma, 1),
-                        unit='GB/s' if hbm_bound else 'TFLOP/s', frac=round(max(t_hbm, t_mfma) / t_meas, 4), traffic=traffic,
+                        achieved=round((alg_bytes[dom] / t_alone / 1e9) if hbm_bound else (flops_class / t_alone / 1e12), 2),
+                        peak=PEAK_HBM_GBS if hbm_bound else round(peak_mfma, 1),
+                        unit='GB/s' if hbm_bound else 'TFLOP/s', frac=round(t_roof / t_alone, 4), traffic=traffic,
+                        frac_as_run=round(t_roof / t_meas, 4),
+                        avg_launch_ms=round(avg_alone_ms, 5), avg_launch_ms_as_run=round(avg_ms, 5),
+                        rocprof_avg_launch_ms=(rocprof or {}).get('avg_launch_ms'), rocprof_file=(rocprof or {}).get('file'),
+                        launches_per_step=nlaunch,
+                        # the whole step, both terms of SURVEY 8(d) (flat keys: the driver keeps scalars)
+                        whole_step_t_roof_hbm_ms=round(t_step_hbm * 1e3, 4), whole_step_t_roof_mfma_ms=round(t_step_mfma * 1e3, 4),
+                        whole_step_bound=ws_bound, whole_step_frac=round(ws_frac, 4), whole_step_ms=round(t_step * 1e3, 4),
+                        whole_step=dict(t_roof_hbm_ms=round(t_step_hbm * 1e3, 4), t_roof_mfma_ms=round(t_step_mfma * 1e3, 4), bound=ws_bound,
+                                        frac=round(ws_frac, 4), ms_per_step=round(t_step * 1e3, 4), algorithmic_bytes=round(step_bytes),
+                                        executed_flop=dict(pair_layers_fwd_bwd=round(3.0 * flops_class), cell_projections_fwd=round(cell_fwd),
+                                                           cell_projections_bwd=round(2.0 * cell_fwd)),
+                                        achieved_GBs=round(step_bytes / t_step / 1e9, 1), frac_of_hbm=round(t_step_hbm / t_step, 4),
+                                        frac_of_mfma=round(t_step_mfma / t_step, 4),
+                                        model='SURVEY.md 8(d): max(algorithmic bytes / 8 TB/s, executed FLOPs / MFMA peak of the arithmetic used); split-bf16 '
+                                              'products = 3 bf16 MFMAs at 2.5 PFLOP/s dense, fp32 products at 157.3 TFLOP/s'),
                         traffic_source=traffic_src, rocprof=rocprof,
                         model='SURVEY.md section 8(d): t_roof = max(algorithmic bytes / 8 TB/s, executed FLOPs / MFMA peak of the arithmetic used)',
-                        hbm_term=dict(algorithmic_bytes_per_launch=round(alg_bytes[dom] / nlaunch), achieved_GBs=round(ach_gb, 1),
-                                      peak_GBs=PEAK_HBM_GBS, frac=round(t_hbm / t_meas, 4)),
-                        mfma_term=dict(algorithmic_flop_per_launch=round(flops_class / nlaunch), achieved_TFLOPs=round(ach_tf, 2),
-                                       peak_TFLOPs=round(peak_mfma, 1), frac=round(t_mfma / t_meas, 4),
-                                       frac_of_f32_mfma_peak=round(ach_tf / PEAK_FP32_MFMA_TFLOPS, 4)),
-                        avg_launch_ms=round(avg_ms, 5), launches_per_step=nlaunch,
-                        measured='second pass of the same %d steps with per-launch HIP events on the stream each launch goes to; in the default '
-                                 'schedule the two chains\' compose kernels share the chip, so a launch\'s duration includes its neighbour\'s share' % args.steps,
+                        hbm_term=dict(algorithmic_bytes_per_launch=round(alg_bytes[dom] / nlaunch), achieved_GBs=round(alg_bytes[dom] / t_alone / 1e9, 1),
+                                      peak_GBs=PEAK_HBM_GBS, frac=round(t_hbm / t_alone, 4), frac_as_run=round(t_hbm / t_meas, 4)),
+                        mfma_term=dict(algorithmic_flop_per_launch=round(flops_class / nlaunch), achieved_TFLOPs=round(flops_class / t_alone / 1e12, 2),
+                                       peak_TFLOPs=round(peak_mfma, 1), frac=round(t_mfma / t_alone, 4), frac_as_run=round(t_mfma / t_meas, 4),
+                                       frac_of_f32_mfma_peak=round(flops_class / t_alone / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)),
+                        measured='frac / achieved / avg_launch_ms: third pass, %d steps with cliora_set_wavefront(OFF) -- the kernel with the chip to itself, HIP '
+                                 'events on the launch stream (agrees with the rocprofv3 --stats average, rocprof_avg_launch_ms); *_as_run: second pass of the '
+                                 'same %d steps in the default schedule, where the other chain\'s kernels share the chip and the event records add barrier '
+                                 'packets' % (n_seq, args.steps),
                         ms_per_step_with_events=round(dt_ev / args.steps * 1e3, 4),
-                        sequential=(dict(note='same kernel with the chip to itself: %d steps with cliora_set_wavefront(OFF), one stream' % n_seq,
-                                         avg_launch_ms=round(kern_seq[dom]['total_ms'] / kern_seq[dom]['launches'], 5),
-                                         frac=round(max(t_hbm, t_mfma) / (kern_seq[dom]['total_ms'] / n_seq * 1e-3), 4),
-                                         ms_per_step_with_events=round(dt_seq / n_seq * 1e3, 4))
-                                    if kern_seq.get(dom) and kern_seq[dom]['launches'] else None),
+                        ms_per_step_sequential_with_events=(round(dt_seq / n_seq * 1e3, 4) if dt_seq else None),
                         implementation_bytes=impl_bytes,
-                        whole_step=dict(algorithmic_bytes=round(step_bytes), achieved_GBs=round(step_bytes / (dt / args.steps) / 1e9, 1),
-                                        frac_of_hbm=round(step_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 4)),
                         classes={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 4), launches_per_step=v['launches'] / args.steps,
                                          tflops=round(flops_class * args.steps / (v['total_ms'] * 1e-3) / 1e12, 2),
                                          algorithmic_GBs=(round(alg_bytes[k] * args.steps / (v['total_ms'] * 1e-3) / 1e9, 1) if alg_bytes[k] else None))
@@ -648,6 +745,8 @@ def main():
                                    % (D, B, L),
                        'global_batch': world * B, 'length': L, 'dim': D, 'mfma': mfma_mode,
                        'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU',
+                       'ranks_seen': ranks['ranks_seen'], 'world_size': world, 'via_launcher': bool(args.launched),
+                       'per_rank_ms_per_step': ranks['per_rank_ms_per_step'],
                        **({'gradient_exchange': 'RCCL all-reduce (backend %s) of one flat fp32 buffer of %d floats per step; %d of %d gradients copied in '
                                                 '(the chart backward writes the rest in place)'
                                                 % (args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
@@ -668,10 +767,13 @@ def main():
             del model
             torch.cuda.empty_cache()
             out['other_shapes'] = other_measurements(torch, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(L, D, B)
-        else:
+        if args.no_cpu_baseline:
             out['cpu_baseline'] = None
+        elif world == 1:
+            out['cpu_baseline'] = cpu_baseline(L, D, B)
+            remember_cpu_baseline('c2', out['cpu_baseline'])
+        else:
+            out['cpu_baseline'] = carried_cpu_baseline('c2', 'r06_bench.json')
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

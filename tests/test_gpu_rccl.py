@@ -46,3 +46,24 @@ def test_bench_c3_force_dist_runs_the_cliora_step_through_rccl():
     assert 'configs[2]' in d['config']['workload'] and d['config']['global_batch'] == 64
     ge = d['config'].get('gradient_exchange', '')
     assert ge.startswith('RCCL') and '; 0 of ' in ge, d['config']        # chart, head and ImageEncoder gradients all written in place
+
+
+def test_bench_via_launcher_takes_the_n_gpu_route_on_one_gpu():
+    """`bench.py --gpus N` (N > 1) starts torch.distributed.run as a child process before anything touches the GPU (bench.py: launch_ranks);
+    no 8-GPU node runs in a round, so the SAME route is taken here with one rank: --via-launcher sends --gpus 1 through launch_ranks(), the
+    rank initialises RCCL from the launcher's environment, and the line must show that the process group saw WORLD_SIZE ranks
+    (config.ranks_seen = an all-reduce of ones) and every rank's own ms per step (batch_iterator.py:134-136, trainer.py:572-574)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}      # no launcher around this one
+    env.update(MASTER_PORT='29537', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--via-launcher', '--steps', '3', '--warmup', '1', '--no-extras',
+           '--no-cpu-baseline', '--no-kernel-events']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert lines, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[-1])
+    c = d['config']
+    assert d['n_gpus'] == 1 and d['value'] > 0
+    assert c['via_launcher'] is True and c['ranks_seen'] == c['world_size'] == 1, c
+    assert c['per_rank_ms_per_step']['min'] > 0 and c['per_rank_ms_per_step']['max'] >= c['per_rank_ms_per_step']['min']
+    assert c.get('gradient_exchange', '').startswith('RCCL'), c

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Timeline of ONE step from a rocprofv3 kernel-trace CSV: every launch with its queue, start (us since the step's first
 kernel), duration and the gap to the previous launch on the same queue.  The last step of the trace is taken (between two
-copy2d_multi pack launches).   python tools/timeline.py <kernel_trace.csv> [max rows]"""
+copy2d_multi pack launches that open a forward).   python tools/timeline.py <kernel_trace.csv> [max rows]
+Exits non-zero (with a message, no traceback) when the trace holds no complete step."""
 import csv
 import re
 import sys
@@ -9,8 +10,13 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-# a step starts with the forward's parameter pack (copy2d_multi followed by split_weight_image)
-starts = [i for i in range(len(rows) - 1) if 'copy2d_multi' in names[i] and 'split_weight_image' in names[i + 1]]
+# a step starts with the forward's parameter pack: copy2d_multi followed by the launch that builds the weight images
+# (weight_images_all since round 5's ffae15a; split_weight_image / frag_weight_image before)
+IMAGE_KERNELS = ('weight_images_all', 'split_weight_image', 'frag_weight_image')
+starts = [i for i in range(len(rows) - 1) if 'copy2d_multi' in names[i] and any(k in names[i + 1] for k in IMAGE_KERNELS)]
+if len(starts) < 2:
+    sys.exit('timeline.py: %d step starts (copy2d_multi + %s) in %s: need at least 2 for one complete step; kernels seen: %s'
+             % (len(starts), ' / '.join(IMAGE_KERNELS), sys.argv[1], sorted({re.sub(r'[<(].*', '', n) for n in names})[:12]))
 a, b = starts[-2], starts[-1]
 step = rows[a:b]
 t0 = int(step[0]['Start_Timestamp'])
