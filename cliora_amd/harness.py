@@ -193,12 +193,27 @@ class Net(nn.Module):
         return ret
 
 
+def select_diora(arch, obj_feats):
+    """The module class `build_net` takes for --arch / --obj_feats (trainer.py:518-526).  The reference knows 'mlp' (cliora.DioraMLP with
+    obj_feats, diora.DioraMLP without) and raises NotImplementedError for everything else; BASELINE config 5 names the TreeLSTM, which the
+    reference ships only as commented text (vg.py:28-76): 'treelstm' selects this library's reconstruction of it (text-only; parity
+    unpinned, cliora_amd/treelstm.py), any other name raises like the reference."""
+    if arch == 'mlp':
+        return VLDiora if obj_feats else TextDiora
+    if arch == 'treelstm':
+        if obj_feats:
+            raise NotImplementedError('arch=treelstm is text-only (the reference has no vision-language TreeLSTM)')
+        from .treelstm import DioraTreeLSTM
+        return DioraTreeLSTM
+    raise NotImplementedError('arch=%r (trainer.py:518-526 knows mlp; this library adds treelstm)' % (arch,))
+
+
 def build_net(size, embeddings, obj_feats=False, img_dim=2048, k_neg=100, share=True, normalize='unit',
-              vg_loss=False, use_contr=False, vl_margin=0.2, alpha_contr=1.0, alpha_vg=1.0):
+              vg_loss=False, use_contr=False, vl_margin=0.2, alpha_contr=1.0, alpha_vg=1.0, arch='mlp'):
     """What trainer.py:504-582 assembles, on the native chart modules."""
     embed = Embed(embeddings, embeddings.weight.shape[1], size)
     enc = ImageEncoder(img_dim, size)
-    diora = (VLDiora if obj_feats else TextDiora)(size, outside=True, normalize=normalize, compress=False, share=share)
+    diora = select_diora(arch, obj_feats)(size, outside=True, normalize=normalize, compress=False, share=share)
     losses = [ReconstructionSoftmaxLoss(embeddings, embeddings.weight.shape[1], size, k_neg=k_neg)]
     if vg_loss:
         losses.append(VGLoss(alpha_vg))

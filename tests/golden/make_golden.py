@@ -13,6 +13,8 @@ What is captured (inputs + expected outputs only -- no reference source):
   sampler_batches.npz   FixedLengthBatchSampler batches, BatchIterator.partition  [data/dataloader.py, batch_iterator.py]
   interchange.npz + ref_model_*.pt   checkpoints written/loaded by Trainer.save_model/load_model, span lists, F1,
                         parse.jsonl trees  [net/trainer.py, analysis/utils.py, scripts/parse.py helpers]
+  interchange_run.npz   the reference Net AFTER Trainer.load_model of ref_model_{noemb,ddp}.pt, run on a fixture batch:
+                        charts, loss, trees (what a native module that loaded the same file must reproduce)
 """
 import os
 import sys
@@ -459,7 +461,49 @@ def interchange_case(name):
     save(name, **arrs)
 
 
+def interchange_run_case(name):
+    """The reference's own Net after Trainer.load_model (trainer.py:399-435) of the checkpoints interchange_case wrote, run forward on a
+    fixture batch (trainer.py:243-304): the charts, the loss and the trees a native module that loaded the same file must reproduce."""
+    D, V, K, B, L = 24, 41, 6, 3, 7
+
+    def make_net(seed):
+        emb = torch.nn.Embedding(V, 16)
+        embed = ref_trainer.Embed(emb, input_size=16, size=D)
+        enc = ImageEncoder(input_size=20, size=D)
+        d = ref_diora.DioraMLP(D, outside=True, normalize='unit', compress=False, share=True)
+        losses = [ref_trainer.ReconstructionSoftmaxLoss(emb, margin=1, k_neg=K, input_size=16, size=D)]
+        net = ref_trainer.Net(embed, enc, d, obj_feats=False, visualize=False, loss_funcs=losses)
+        seeded_params(net, seed)
+        return net
+
+    g = torch.Generator().manual_seed(71)
+    sent = torch.randint(0, V, (B, L), generator=g)
+    neg = torch.randperm(V, generator=g)[:K]
+    bm = dict(example_ids=list(range(B)), sentences=sent, image_feats=torch.zeros(B, 1), neg_samples=neg, obj_feats=None,
+              boxes=torch.zeros(B, 36, 4), obj_cates=torch.zeros(B, 36), GT=None, batch_size=B, length=L)
+    arrs = dict(sentences=sent.numpy(), neg_samples=neg.numpy())
+    arrs.update(state_np(make_net(67), 'dst0__'))          # the receiving net's own initialisation (the embedding table survives a noemb load)
+    for tag, fname, origin_emb in (('noemb', 'ref_model_noemb.pt', False), ('ddp', 'ref_model_ddp.pt', True)):
+        net = make_net(67)
+        ref_trainer.Trainer.load_model(origin_emb, net, os.path.join(HERE, fname))
+        net.eval()
+        tr = ref_trainer.Trainer(net, k_neg=K, ngpus=1, cuda=False)
+        attach_hooks(net.diora)
+        with torch.no_grad():
+            out = tr.run_net(bm)
+        d = net.diora
+        for k in ('inside_h', 'inside_s', 'outside_h', 'outside_s'):
+            arrs['%s__%s' % (tag, k)] = getattr(d, k).detach().numpy().copy()
+        arrs['%s__total_loss' % tag] = out['total_loss'].detach().numpy().copy()
+        arrs['%s__trees' % tag] = np.array(json.dumps([tree_to_str(t) for t in run_cky(net.diora, B, L)[0]]))
+    arrs['meta'] = np.array(json.dumps(dict(META, D=D, V=V, K=K, B=B, L=L)))
+    save(name, **arrs)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['interchange_run']:          # one new fixture without rewriting the others
+        interchange_run_case('interchange_run.npz')
+        sys.exit(0)
     index_tables()
     diora_case('diora_c1.npz', D=50, B=8, L=10, seed=1234)                       # BASELINE config 1
     diora_case('diora_noshare.npz', D=24, B=3, L=7, seed=7, share=False)
@@ -477,3 +521,4 @@ if __name__ == '__main__':
     treelstm_case('treelstm_recon_noshare.npz', D=24, B=3, L=7, seed=43, share=False)
     sampler_case('sampler_batches.npz')
     interchange_case('interchange.npz')
+    interchange_run_case('interchange_run.npz')

@@ -82,3 +82,41 @@ def test_spans_f1_and_parse_records_match_the_reference():
         assert rec['tree_index_conll'] == c['tree']
     assert abs(f1.corpus_f1 - m['corpus_f1']) < 1e-12
     assert abs(f1.sentence_f1 - m['sent_f1']) < 1e-12
+
+
+def test_loaded_checkpoint_reproduces_the_reference_run_on_the_oracle():
+    """tests/golden/interchange_run.npz (the reference Net after ITS load_model, run on a fixture batch): the native loader's parameters
+    fed to the CPU oracle give the reference's charts and loss -- the CPU half of row f4 (the GPU half: tests/test_gpu_interchange.py)."""
+    from oracle import diora_ref as R
+    g = load_golden('interchange_run.npz')
+    m = g['meta']
+    sent, neg = torch.from_numpy(g['sentences']), torch.from_numpy(g['neg_samples'])
+    for tag, fname, origin_emb in (('noemb', 'ref_model_noemb.pt', False), ('ddp', 'ref_model_ddp.pt', True)):
+        torch.manual_seed(3)
+        net = H.build_net(m['D'], torch.nn.Embedding(m['V'], 16), obj_feats=False, img_dim=20, k_neg=m['K'])
+        net.load_state_dict({k[len('dst0__'):].replace('__', '.'): torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith('dst0__')})
+        X.load_model(origin_emb, net, os.path.join(GOLDEN_DIR, fname))
+        sd = net.state_dict()
+        P = {k[len('diora.'):]: v for k, v in sd.items() if k.startswith('diora.')}
+        xs, xw = R.embed_forward(sd['embed.embeddings.weight'], sd['embed.mat'], sd['embed.mat1'], sent)
+        ref = R.diora_forward(P, xs, xw)
+        for k in ('inside_h', 'inside_s', 'outside_h', 'outside_s'):
+            assert np.abs(ref[k].numpy() - g['%s__%s' % (tag, k)]).max() <= 2e-6 * max(1.0, np.abs(g['%s__%s' % (tag, k)]).max()), (tag, k)
+        loss = R.reconstruction_loss(sd['embed.embeddings.weight'], sd['reconstruct_softmax_loss.mat'], sent, neg, ref['outside_h'])
+        assert abs(float(loss) - float(g['%s__total_loss' % tag].reshape(-1)[0])) <= 2e-6 * max(1.0, abs(float(loss)))
+
+
+def test_build_net_arch_switch():
+    """trainer.py:518-526: 'mlp' picks the text / vision-language DioraMLP, anything else raises; this library adds 'treelstm' (config 5)."""
+    import pytest
+    emb = torch.nn.Embedding(11, 16)
+    assert type(H.build_net(16, emb, arch='mlp').diora).__module__.endswith('.diora')
+    assert type(H.build_net(16, torch.nn.Embedding(11, 16), obj_feats=True, img_dim=16, arch='mlp').diora).__module__.endswith('.cliora')
+    net = H.build_net(16, emb, arch='treelstm')
+    assert type(net.diora).__name__ == 'DioraTreeLSTM'
+    assert {'diora.inside_compose_func.W', 'diora.inside_compose_func.U', 'diora.inside_compose_func.B', 'diora.inside_score_func.mat',
+            'diora.root_vector_out_h', 'diora.root_vector_out_c'} <= set(net.state_dict())
+    with pytest.raises(NotImplementedError):
+        H.build_net(16, emb, arch='hard')
+    with pytest.raises(NotImplementedError):
+        H.build_net(16, emb, obj_feats=True, arch='treelstm')
