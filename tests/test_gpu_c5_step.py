@@ -44,7 +44,7 @@ def test_c5_whole_step_embed_treelstm_reconstruction():
     net = net.cuda().train()
     out = net(sent.cuda(), None, neg.cuda())
     loss = out['total_loss'].mean(0).sum()
-    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * max(1.0, abs(float(ref_loss.detach())))
     for k in ('inside_h', 'inside_c', 'inside_s', 'outside_h', 'outside_c', 'outside_s'):
         err = float((getattr(net.diora, k).detach().cpu() - ref[k].detach()).abs().max())
         assert err <= 1e-4 * _scale(ref[k].detach()), (k, err)
@@ -58,12 +58,15 @@ def test_c5_whole_step_embed_treelstm_reconstruction():
         else:
             # the table is ONE parameter reached through Embed and through the loss (trainer.py:541 keeps it trainable when emb = none)
             want = ref_p[k if k in ref_p else 'embed.embeddings.weight'].grad
+        if want is None:                          # embed.mat1: the word projection feeds only the vision-language scorers (cliora.py:453-468)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
         d = (p.grad.detach().cpu().double() - want.double()).abs().flatten()
         sc = _scale(want)
         assert float(torch.quantile(d[:: max(1, d.numel() // 200000)], 0.99)) <= 2e-4 * sc, k
         assert float(d.max()) <= 2e-2 * sc, (k, float(d.max()), sc)
         checked += 1
-    assert checked == len(named) and checked >= 9
+    assert checked == len(named) - 1 and checked >= 9, (checked, sorted(named))
     # ---- and the update rule on top: Trainer.step (clip 5.0 + Adam over the flat buffer) moves every parameter and lowers the loss ----
     tr = H.Trainer(net, lr=2e-3)
     bm = dict(sentences=sent.cuda(), neg_samples=neg.cuda())
@@ -73,7 +76,7 @@ def test_c5_whole_step_embed_treelstm_reconstruction():
         l1 = tr.step(bm, train=True)['total_loss']
     assert l1 < l0, (l0, l1)
     for k, p in named.items():
-        if k == 'embed.embeddings.weight':        # only the looked-up rows move
+        if k in ('embed.embeddings.weight', 'embed.mat1'):        # only the looked-up rows move; mat1 has no gradient in a text-only net
             continue
         assert not torch.equal(p.detach(), before[k]), k
 
