@@ -103,6 +103,8 @@ def lib():
     L.cliora_recon_backward.restype = i32
     L.cliora_rows_scatter_add.argtypes = [vp, vp, i32, i32, vp, C.c_int64, vp]     # mandatory: heads.scatter_rows has no other path
     L.cliora_rows_scatter_add.restype = i32
+    L.cliora_rows_scatter_add_segments.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, i32, vp, C.c_int64, vp]
+    L.cliora_rows_scatter_add_segments.restype = i32
     L.cliora_vg_workspace_bytes.argtypes = [i32, i32]
     L.cliora_vg_workspace_bytes.restype = sz
     L.cliora_vg_loss.argtypes = [i32, i32, i32, vp, C.c_float, vp, vp, vp, sz, vp]

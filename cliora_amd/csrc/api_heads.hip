@@ -244,15 +244,32 @@ extern "C" int cliora_recon_backward(const int64_t* tokens, const int64_t* neg, 
 // ------------------------------------------------------------------ clip_grad_norm_ + Adam on one flat buffer
 // table_grad (V, K) = zeros, then table_grad[index[i]] += rows[i]: the scatter F.embedding's backward does (the last ATen op of the
 // training step in round 3: zeros_like + index_add_), deterministic
-extern "C" int cliora_rows_scatter_add(const float* rows, const int64_t* index, int n, int K, float* table_grad, int64_t V, void* stream) {
-    if (!rows || !index || !table_grad) return fail(CLIORA_EINVAL, "NULL argument");
-    if (n < 0 || K <= 0 || K % 4 != 0 || V <= 0) return fail(CLIORA_EINVAL, "rows_scatter_add: n >= 0, K a positive multiple of 4, V > 0");
+extern "C" int cliora_rows_scatter_add_segments(const float* const* rows, const int64_t* const* index, const int* n, int nseg, int K, float* table_grad,
+                                               int64_t V, void* stream) {
+    if (!rows || !index || !n || !table_grad) return fail(CLIORA_EINVAL, "NULL argument");
+    if (nseg < 0 || nseg > SCATTER_MAX_SEGS) return fail(CLIORA_EINVAL, "rows_scatter_add: at most " + std::to_string(SCATTER_MAX_SEGS) + " segments");
+    if (K <= 0 || K % 4 != 0 || V <= 0) return fail(CLIORA_EINVAL, "rows_scatter_add: K a positive multiple of 4, V > 0");
     hipStream_t st = (hipStream_t)stream;
+    ScatterSegs g{};
+    long long total = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (n[s] < 0 || (n[s] > 0 && (!rows[s] || !index[s]))) return fail(CLIORA_EINVAL, "rows_scatter_add: bad segment");
+        if (n[s] == 0) continue;                       // empty segments are dropped
+        g.rows[g.nseg] = rows[s]; g.index[g.nseg] = reinterpret_cast<const long long*>(index[s]); g.first[g.nseg] = (int)total;
+        total += n[s]; ++g.nseg;
+    }
+    if (total > 0x7fffffffLL) return fail(CLIORA_EINVAL, "rows_scatter_add: too many rows");
+    g.first[g.nseg] = (int)total;
     HIPOK(hipMemsetAsync(table_grad, 0, (size_t)V * K * sizeof(float), st));
-    if (n == 0) return CLIORA_OK;
-    hipLaunchKernelGGL(rows_scatter_add, dim3(n), dim3(256), 0, st, rows, reinterpret_cast<const long long*>(index), n, K, table_grad, (long long)V);
+    if (total == 0) return CLIORA_OK;
+    hipLaunchKernelGGL(rows_scatter_add, dim3((unsigned)total), dim3(256), 0, st, g, K, table_grad, (long long)V);
     LAUNCHOK("rows_scatter_add");
     return CLIORA_OK;
+}
+extern "C" int cliora_rows_scatter_add(const float* rows, const int64_t* index, int n, int K, float* table_grad, int64_t V, void* stream) {
+    if (!rows || !index || !table_grad) return fail(CLIORA_EINVAL, "NULL argument");
+    if (n < 0) return fail(CLIORA_EINVAL, "rows_scatter_add: n >= 0");
+    return cliora_rows_scatter_add_segments(&rows, &index, &n, 1, K, table_grad, V, stream);
 }
 
 extern "C" size_t cliora_clip_adam_workspace_bytes(void) { return (1024 + 64) * sizeof(float); }

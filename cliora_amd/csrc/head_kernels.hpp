@@ -196,25 +196,73 @@ static __global__ void concat_index(int n0, const int64_t* __restrict__ a, int n
 // ---------------------------------------------------------------------------------------------------------------------------
 // Gradient of an embedding table from the gradients of its looked-up rows (the backward of F.embedding, trainer.py:219 / :54-58):
 //   table_grad[index[i]] += rows[i]   for i < n,  every other row of table_grad zero (the caller clears it first).
-// One workgroup per looked-up row; the FIRST occurrence of a token owns its table row and adds the later occurrences in ascending i
-// (each workgroup scans the whole index list, n <= a few thousand): no atomics, the same bits every run -- torch's index_add_ adds
-// with float atomics in arrival order.  K a multiple of 4.
-static __global__ __launch_bounds__(256) void rows_scatter_add(const float* __restrict__ rows, const long long* __restrict__ index, int n, int K,
-                                                        float* __restrict__ table_grad, long long V) {
-    __shared__ int owner;
-    const int i = blockIdx.x;
-    const long long tok = index[i];
+// The looked-up rows come in up to SCATTER_MAX_SEGS segments (round 6: every producer of a step -- the reconstruction loss's positives
+// and negatives, Embed's span and word projections -- in ONE launch instead of a scatter + a dense add each); row v of the launch is
+// row v - first[s] of segment s.  One workgroup per row; the FIRST occurrence of a token owns its table row and adds the later
+// occurrences in ascending v: no atomics on floats, the same bits every run -- torch's index_add_ adds with float atomics in arrival
+// order.  All 256 threads scan the index list (a few thousand entries, L2-resident) once: ownership from the entries before v, the list
+// of later occurrences (collected with an LDS counter, then sorted: a handful at most) from those behind it.  K a multiple of 4.
+constexpr int SCATTER_MAX_SEGS = 4;
+constexpr int SCATTER_LIST = 128;
+struct ScatterSegs {
+    const float* rows[SCATTER_MAX_SEGS];
+    const long long* index[SCATTER_MAX_SEGS];
+    int first[SCATTER_MAX_SEGS + 1];       // first[s] = rows before segment s; first[nseg] = n
+    int nseg;
+};
+__device__ __forceinline__ int scatter_seg_of(const ScatterSegs& g, int v) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < SCATTER_MAX_SEGS; ++k) s += (k < g.nseg && v >= g.first[k]) ? 1 : 0;
+    return s;
+}
+__device__ __forceinline__ long long scatter_tok(const ScatterSegs& g, int v) {
+    const int s = scatter_seg_of(g, v);
+    return g.index[s][v - g.first[s]];
+}
+__device__ __forceinline__ const float* scatter_row(const ScatterSegs& g, int v, int K) {
+    const int s = scatter_seg_of(g, v);
+    return g.rows[s] + (size_t)(v - g.first[s]) * K;
+}
+static __global__ __launch_bounds__(256) void rows_scatter_add(ScatterSegs g, int K, float* __restrict__ table_grad, long long V) {
+    __shared__ int owner, cnt;
+    __shared__ int later[SCATTER_LIST];
+    const int v = blockIdx.x, n = g.first[g.nseg];
+    const long long tok = scatter_tok(g, v);
     if (tok < 0 || tok >= V) return;
-    if (threadIdx.x == 0) owner = 1;
+    if (threadIdx.x == 0) { owner = 1; cnt = 0; }
     __syncthreads();
-    for (int j = threadIdx.x; j < i; j += 256)
-        if (index[j] == tok) owner = 0;            // an earlier occurrence owns the row (benign race: every writer stores 0)
+    for (int j = threadIdx.x; j < n; j += 256) {
+        if (j == v || scatter_tok(g, j) != tok) continue;
+        if (j < v) owner = 0;                      // an earlier occurrence owns the row (benign race: every writer stores 0)
+        else {
+            const int k = atomicAdd(&cnt, 1);      // integer counter in LDS: the ORDER of the list is fixed by the sort below
+            if (k < SCATTER_LIST) later[k] = j;
+        }
+    }
     __syncthreads();
     if (!owner) return;
+    const int m = cnt;
+    if (m > SCATTER_LIST) {                        // a token repeated more than SCATTER_LIST times: the plain ordered scan
+        for (int c = 4 * threadIdx.x; c < K; c += 1024) {
+            float4 acc = ld4(scatter_row(g, v, K) + c);
+            for (int j = v + 1; j < n; ++j)
+                if (scatter_tok(g, j) == tok) acc = f4add(acc, ld4(scatter_row(g, j, K) + c));
+            st4(table_grad + (size_t)tok * K + c, acc);
+        }
+        return;
+    }
+    if (threadIdx.x == 0)                          // ascending v: insertion sort of a handful of entries
+        for (int a = 1; a < m; ++a) {
+            const int x = later[a];
+            int b = a - 1;
+            for (; b >= 0 && later[b] > x; --b) later[b + 1] = later[b];
+            later[b + 1] = x;
+        }
+    __syncthreads();
     for (int c = 4 * threadIdx.x; c < K; c += 1024) {
-        float4 acc = ld4(rows + (size_t)i * K + c);
-        for (int j = i + 1; j < n; ++j)
-            if (index[j] == tok) acc = f4add(acc, ld4(rows + (size_t)j * K + c));
+        float4 acc = ld4(scatter_row(g, v, K) + c);
+        for (int q = 0; q < m; ++q) acc = f4add(acc, ld4(scatter_row(g, later[q], K) + c));
         st4(table_grad + (size_t)tok * K + c, acc);
     }
 }

@@ -159,6 +159,27 @@ class VGLoss(nn.Module):
         return self.alpha * F.cross_entropy(logits, torch.arange(B, device=logits.device))
 
 
+class LossDict(dict):
+    """What Net.forward returns: the named losses, plus -- built only when somebody asks for it -- the reference's `total_loss`, the (1, n)
+    row of the losses (trainer.py:300-303).  `total()` is the scalar the reference roots its backward at,
+    `total_loss.mean(dim=0).sum()` (trainer.py:487), as the plain sum of the parts: the same value and the same gradients without the
+    cat / mean / sum launches and their four backward launches per step."""
+    parts = ()
+
+    def __missing__(self, key):
+        if key != 'total_loss':
+            raise KeyError(key)
+        v = torch.cat([p.view(1, 1) for p in self.parts], 1)
+        self[key] = v
+        return v
+
+    def total(self):
+        t = self.parts[0]
+        for p in self.parts[1:]:
+            t = t + p
+        return t
+
+
 class Net(nn.Module):
     def __init__(self, embed, image_encoder, diora, obj_feats, loss_funcs=()):
         super().__init__()
@@ -178,7 +199,7 @@ class Net(nn.Module):
         self.diora(x_span, x_word, o_span, o_word)
         if not compute_loss:
             return {'total_loss': torch.ones(1, 1, device=x_span.device)}
-        ret, parts = {}, []
+        ret, parts = LossDict(), []
         for name in self.loss_func_names:
             fn = getattr(self, name)
             if 'reconstruct' in name:
@@ -188,8 +209,8 @@ class Net(nn.Module):
             else:
                 v = fn(self.diora.vg_atten_score)
             ret[name] = v
-            parts.append(v.view(1, 1))
-        ret['total_loss'] = torch.cat(parts, 1)
+            parts.append(v)
+        ret.parts = parts
         return ret
 
 
@@ -229,6 +250,7 @@ class Trainer(object):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.reducer = reducer                               # cliora_amd.parallel.FlatGradAllReduce or None
+        self.defer_table_grads = True
         self.fused = _native(*self.params)                   # clip + Adam as three launches over one flat buffer (heads.FusedClipAdam)
         if self.fused:
             self.optimizer = heads.FusedClipAdam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0, reducer=reducer)
@@ -242,10 +264,19 @@ class Trainer(object):
         self.net.train(train)
         with torch.set_grad_enabled(train):
             out = self.net(batch_map['sentences'], batch_map.get('obj_feats'), batch_map.get('neg_samples'), compute_loss)
-        total = out['total_loss'].mean(dim=0).sum()
+        total = out.total() if isinstance(out, LossDict) else out['total_loss'].mean(dim=0).sum()
         if train:
             self.optimizer.zero_grad()
-            total.backward()
+            # this step owns its gradients from backward to the update, so the embedding table's gradient is assembled once, in the flat
+            # buffer, from every lookup's rows (heads.DeferredTableGrads) instead of one dense scatter per lookup + dense adds
+            defer = heads.DeferredTableGrads(self.optimizer.grads) if (self.fused and self.defer_table_grads) else None
+            heads._deferred = defer
+            try:
+                total.backward()
+            finally:
+                heads._deferred = None
+            if defer is not None:
+                defer.flush()
             if self.reducer is not None:
                 self.reducer.all_reduce_mean()
             if self.fused:

@@ -32,10 +32,52 @@ def supported(*tensors):
     return all(t is None or (t.is_cuda and t.dtype in (torch.float32, torch.int64)) for t in tensors)
 
 
+class DeferredTableGrads(object):
+    """The embedding table's gradient of ONE training step, collected instead of scattered (harness.Trainer owns the step, so it may):
+    every producer of a backward pass -- the reconstruction loss's positives and negatives (trainer.py:54-58), Embed's lookups (:219) --
+    leaves its (rows, index) here and returns no gradient; flush() then writes the table's slice of the flat gradient buffer with ONE
+    zero-fill + ONE cliora_rows_scatter_add_segments launch.  Autograd alone scatters each producer into its own dense (V, K) tensor and
+    adds them (two 41 MB fills, two scatters and a 41 MB add per step at V 10 000 x 1024).  Producers arrive in autograd's (fixed)
+    order, so the sum order -- and every bit of the result -- is the same run after run."""
+
+    def __init__(self, arena):
+        self.arena = arena                  # cliora_amd.parallel.FlatGradAllReduce: who owns which parameter's gradient slice
+        self.pending = {}                   # id(param) -> (param, view, [(rows, index), ...])
+
+    def offer(self, d_rows, index, table):
+        """True when the contribution was taken (the caller then returns None as the table's gradient)."""
+        pv = self.arena.lookup(table)
+        if pv is None or pv[0].grad is not None or pv[1].shape != table.shape:
+            return False
+        ent = self.pending.setdefault(id(pv[0]), (pv[0], pv[1], []))
+        if len(ent[2]) >= 4:                # cliora_rows_scatter_add_segments takes four segments
+            return False
+        ent[2].append((d_rows.contiguous(), index.contiguous().reshape(-1)))
+        return True
+
+    def flush(self):
+        for param, view, segs in self.pending.values():
+            n = len(segs)
+            rows = (C.c_void_p * n)(*[t.data_ptr() for t, _ in segs])
+            idx = (C.c_void_p * n)(*[i.data_ptr() for _, i in segs])
+            cnt = (C.c_int32 * n)(*[int(i.numel()) for _, i in segs])
+            with torch.cuda.device(view.device):
+                _lib.check(_lib.lib().cliora_rows_scatter_add_segments(rows, idx, cnt, n, int(view.shape[1]), _p(view), int(view.shape[0]), _st()),
+                           'cliora_rows_scatter_add_segments')
+            param.grad = view.detach()      # an alias of the arena slice: the reducer / FusedClipAdam see a gradient already in place
+        self.pending = {}
+
+
+_deferred = None        # a DeferredTableGrads while harness.Trainer.step runs a backward pass, else None
+
+
 def scatter_rows(d_rows, index, table):
     """Gradient of the embedding `table` (V, K) from the gradients d_rows (n, K) of its looked-up rows index (n,): cliora_rows_scatter_add,
     written into the table's slice of a live flat gradient buffer when this is the first producer of the pass (else a fresh tensor that
-    autograd adds).  Replaces zeros_like + index_add_ (round 3's last ATen op on the step), deterministic for repeated ids."""
+    autograd adds).  Replaces zeros_like + index_add_ (round 3's last ATen op on the step), deterministic for repeated ids.
+    Inside harness.Trainer.step the contribution is deferred instead (DeferredTableGrads) and None is returned."""
+    if _deferred is not None and _deferred.offer(d_rows, index, table):
+        return None
     out = _grad_out(table)
     with torch.cuda.device(table.device):
         _lib.check(_lib.lib().cliora_rows_scatter_add(_p(d_rows.contiguous()), _p(index.contiguous()), int(index.numel()), int(table.shape[1]), _p(out),
@@ -86,7 +128,8 @@ class Proj(torch.autograd.Function):
                 if index is None:
                     d_x = d_rows.view(ctx.x_shape)
                 else:       # the embedding table's gradient: rows of repeated tokens add up (in place in the flat gradient buffer when there is one)
-                    d_x = scatter_rows(d_rows, index.reshape(-1), x2).view(ctx.x_shape)
+                    d_x = scatter_rows(d_rows, index.reshape(-1), x2)
+                    d_x = d_x.view(ctx.x_shape) if d_x is not None else None
         return d_x, None, d_w, d_b
 
 
@@ -201,6 +244,11 @@ class FusedClipAdam(object):
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.t = 0
+        # parameters that have never received a gradient (embed.mat1 of a text-only net: the word projection feeds only the vision-language
+        # scorers) have zero moments and a zero arena slice: the dense launch leaves them exactly where they are (0 / (0 + eps)), so they
+        # need neither the save / restore of the skipped segments nor a fill per step
+        self.ever = [False] * len(self.params)
+        self.grads.flat.zero_()
         self.ws = torch.empty(_lib.lib().cliora_clip_adam_workspace_bytes(), device=dev, dtype=torch.uint8)
 
     def zero_grad(self):
@@ -213,13 +261,18 @@ class FusedClipAdam(object):
         skipped = []              # parameters without a gradient this step: torch.optim.Adam leaves them (and their moments) untouched
         if not gathered:
             o = 0
-            for p, v in zip(ar.params, ar.views):
+            for k, (p, v) in enumerate(zip(ar.params, ar.views)):
                 if p.grad is None:
-                    v.zero_()
-                    skipped.append((o, p.numel()))
-                elif p.grad.data_ptr() != v.data_ptr():
-                    v.copy_(p.grad)
+                    if self.ever[k]:
+                        v.zero_()
+                        skipped.append((o, p.numel()))
+                else:
+                    self.ever[k] = True
+                    if p.grad.data_ptr() != v.data_ptr():
+                        v.copy_(p.grad)
                 o += p.numel()
+        else:
+            self.ever = [True] * len(self.params)          # the reducer zero-filled and averaged every slice: plain dense update
         # a zero gradient is not "no gradient" to Adam (the moments decay and the parameter keeps moving on its momentum): the
         # skipped segments are put back after the launch.  (Their bias-correction step count still advances with the rest: a
         # parameter that receives gradients only on SOME steps is corrected with the global count here, with its own in torch.)

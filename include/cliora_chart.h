@@ -223,6 +223,12 @@ int cliora_proj_backward(const float* x, const int64_t* index, int nrows, int K,
  *   table_grad (V, K) = 0;  table_grad[index[i]] += rows[i], i < n      (index int64, K a multiple of 4; ids outside [0, V) are skipped)
  * Repeated ids add up in ascending i, without atomics: bitwise reproducible. */
 int cliora_rows_scatter_add(const float* rows, const int64_t* index, int n, int K, float* table_grad, int64_t V, void* stream);
+/* The same with the looked-up rows in up to 4 segments (rows[s] (n[s], K), index[s] (n[s])), as ONE zero-fill + ONE launch: a training
+ * step reaches the table through several lookups (trainer.py:54-58 positives and negatives of the reconstruction loss, :219 Embed), and
+ * autograd would scatter each into its own dense (V, K) tensor and add them.  Row order = segment order, then row order inside a
+ * segment; repeated ids add up in that order, bitwise reproducible.  (Host arrays of device pointers.) */
+int cliora_rows_scatter_add_segments(const float* const* rows, const int64_t* const* index, const int* n, int nseg, int K, float* table_grad,
+                                     int64_t V, void* stream);
 
 /* ReconstructionSoftmaxLoss.forward (cliora/net/trainer.py:46-78): tokens (B*L) and neg (Kn) int64 ids into emb (V, E), mat (D, E),
  * outside_h (B, C, D) of which the leaf cells [:, :L] are read:

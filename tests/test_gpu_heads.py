@@ -139,3 +139,79 @@ def test_rows_scatter_add_matches_index_add_and_is_deterministic():
             outs.append(out.cpu())
         assert torch.equal(outs[0], outs[1])
         assert float((outs[0] - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), (n, K, V)
+
+
+def test_rows_scatter_add_segments_is_the_sum_of_the_lookups():
+    """cliora_rows_scatter_add_segments: the table gradient of a whole step -- the reconstruction loss's positives + negatives and Embed's
+    lookups (trainer.py:54-58, :219) -- from ONE launch, against torch's zeros + index_add_ per lookup; tokens shared between the
+    lookups, a token repeated more often than the kernel's in-LDS list holds (its ordered fallback), empty segments; same bits every run;
+    a segment order that matters only to rounding is the given one (bitwise equal to the one-segment call on the concatenation)."""
+    import ctypes as C
+    from cliora_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for sizes, K, V in (((1380, 1280), 1024, 10000), ((9, 0, 300, 4), 48, 7), ((3,), 16, 5), ((0, 0), 16, 5)):
+        idx = [torch.randint(0, V, (n,), generator=g) for n in sizes]
+        rows = [torch.randn(n, K, generator=g) for n in sizes]
+        if sizes[0] > 8:
+            idx[1][:6] = idx[0][:6]                                # tokens that both lookups hit
+        want = torch.zeros(V, K)
+        for i, r in zip(idx, rows):
+            want.index_add_(0, i, r)
+        rows_d, idx_d = [r.cuda() for r in rows], [i.cuda() for i in idx]
+        n = len(sizes)
+        outs = []
+        for rep in range(2):
+            out = torch.full((V, K), float('nan'), device='cuda')
+            rc = _lib.lib().cliora_rows_scatter_add_segments((C.c_void_p * n)(*[r.data_ptr() for r in rows_d]), (C.c_void_p * n)(*[i.data_ptr() for i in idx_d]),
+                                                             (C.c_int32 * n)(*sizes), n, K, C.c_void_p(out.data_ptr()), V, st())
+            _lib.check(rc, 'cliora_rows_scatter_add_segments')
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1])
+        assert float((outs[0] - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), (sizes, K, V)
+        if sum(sizes):
+            cat_r, cat_i = torch.cat(rows_d), torch.cat(idx_d)
+            one = torch.empty((V, K), device='cuda')
+            _lib.check(_lib.lib().cliora_rows_scatter_add(C.c_void_p(cat_r.data_ptr()), C.c_void_p(cat_i.data_ptr()), int(cat_i.numel()), K,
+                                                          C.c_void_p(one.data_ptr()), V, st()), 'cliora_rows_scatter_add')
+            assert torch.equal(one.cpu(), outs[0])
+    rc = _lib.lib().cliora_rows_scatter_add_segments((C.c_void_p * 5)(), (C.c_void_p * 5)(), (C.c_int32 * 5)(), 5, 16, C.c_void_p(1), 5, st())
+    assert rc != 0 and b'segments' in _lib.lib().cliora_last_error()
+
+
+@pytest.mark.parametrize('vl', [False, True])
+def test_deferred_table_gradient_is_the_autograd_one(vl):
+    """harness.Trainer.step assembles the embedding table's gradient once per step from every lookup's rows (heads.DeferredTableGrads);
+    with the switch off autograd scatters per lookup and adds.  Same losses, same parameters after three steps (to the rounding of the
+    one sum whose order differs: a token that two lookups share), and a parameter that never receives a gradient (embed.mat1 in a
+    text-only net) stays exactly where it was."""
+    from cliora_amd import harness as H
+    res = {}
+    for defer in (True, False):
+        torch.manual_seed(11)
+        V, E, D, B, L, K = 300, 64, 48, 6, 7, 20
+        emb = torch.nn.Embedding(V, E)
+        net = H.build_net(D, emb, obj_feats=vl, img_dim=32, k_neg=K, vg_loss=vl, use_contr=vl).cuda()
+        if vl:
+            emb.weight.requires_grad = True                    # exercise the deferred path in the vision-language net too
+            for p in net.img_encoder.parameters():
+                torch.nn.init.normal_(p, std=0.05)
+        tr = H.Trainer(net, lr=2e-3)
+        tr.defer_table_grads = defer
+        g = torch.Generator().manual_seed(12)
+        bm = dict(sentences=torch.randint(0, 40, (B, L), generator=g).cuda(), neg_samples=torch.randperm(V, generator=g)[:K].cuda())
+        bm['neg_samples'][:3] = bm['sentences'][0, :3]         # negatives that are also words of the batch
+        if vl:
+            bm['obj_feats'] = torch.randn(B, 36, 32, generator=g).cuda()
+        net.train = lambda mode=True, net=net: torch.nn.Module.train(net, False)      # dropout off: the two runs must see the same step
+        mat1_0 = net.embed.mat1.detach().clone()
+        losses = [tr.step(bm, train=True)['total_loss'] for _ in range(3)]
+        res[defer] = (losses, {k: p.detach().clone() for k, p in net.named_parameters()})
+        if not vl:
+            assert torch.equal(net.embed.mat1.detach(), mat1_0)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+    for k in res[False][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), k
