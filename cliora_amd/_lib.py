@@ -129,10 +129,30 @@ def lib():
     L.cliora_set_wavefront.restype = i32
     L.cliora_set_resident.argtypes = [i32]
     L.cliora_set_resident.restype = i32
+    L.cliora_device_side_stream.argtypes = [vp, C.POINTER(vp)]
+    L.cliora_device_side_stream.restype = i32
     L.cliora_resident_trace.argtypes = [vp, vp, sz, vp]
     L.cliora_resident_trace.restype = i32
     _lib = L
     return L
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """torch handle of the library's caller lane on `device` (include/cliora_chart.h: cliora_device_side_stream): a stream that runs beside
+    the current stream and the chart's own side streams.  One per device, created at the first request."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(idx)
+    if s is None:
+        out = C.c_void_p()
+        with torch.cuda.device(idx):
+            check(lib().cliora_device_side_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(out)), 'cliora_device_side_stream')
+        s = torch.cuda.ExternalStream(out.value, device=torch.device('cuda', idx))
+        _side_streams[idx] = s
+    return s
 
 
 def check(rc, what):

@@ -111,10 +111,11 @@ class VLScoreFunction(torch.autograd.Function):
         dev = inside_h.device
         cont = lambda g: g.contiguous().float() if g is not None else None
         d_all, d_vg = cont(d_all), cont(d_vg)
-        d_sum = torch.empty_like(inside_h)
-        d_obj_span = torch.empty_like(obj_span)
-        d_x_word = torch.empty_like(x_word) if x_word is not None else None
-        d_obj_word = torch.empty_like(obj_word) if obj_word is not None else None
+        need = ctx.needs_input_grad          # (plan, training, inside_h, outside_h, obj_span, x_word, obj_word, want_all)
+        d_sum = torch.empty_like(inside_h) if (need[2] or need[3]) else None
+        d_obj_span = torch.empty_like(obj_span) if need[4] else None
+        d_x_word = torch.empty_like(x_word) if (x_word is not None and need[5]) else None
+        d_obj_word = torch.empty_like(obj_word) if (obj_word is not None and need[6]) else None
         ws = torch.empty(ctx.nbytes, device=dev, dtype=torch.uint8)
         rc = _lib.lib().cliora_vl_scores_backward(plan.handle, _ptr(inside_h), _ptr(outside_h), _ptr(obj_span), _ptr(x_word),
                                                  _ptr(obj_word), ctx.training, _ptr(d_all), _ptr(d_vg), _ptr(d_sum),
@@ -161,6 +162,94 @@ class VLMaxFunction(torch.autograd.Function):
         return None, d_sum, d_sum, d_obj
 
 
+class VLMaxRows(torch.autograd.Function):
+    """The region-max scorer as the node that owns the gradient of the CHART rows only (d inside_h = d outside_h = d_sum_h): the region
+    matrix comes in detached.  Its twin VLMaxObj owns the region matrix's gradient and runs on the library's caller lane, so that the
+    chart backward -- which needs d_sum_h -- does not wait for the 0.1-0.2 ms of the region-matrix half (cliora_vl_scores_max_backward
+    takes either output as NULL).  JoinGrad hands the one cotangent to both."""
+
+    @staticmethod
+    @_lib.on_device(lambda ctx, plan, inside_h, *a: inside_h)
+    def forward(ctx, plan, inside_h, outside_h, obj_span):
+        B, Cc = plan.B, plan.C
+        tens = [t.contiguous().float() for t in (inside_h, outside_h, obj_span)]
+        dev = tens[0].device
+        vmax = torch.empty((B, B, Cc), device=dev, dtype=torch.float32)
+        arg = torch.empty((B, B, Cc), device=dev, dtype=torch.int32)
+        nbytes = _lib.lib().cliora_plan_vl_workspace_bytes(plan.handle)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_max_forward(plan.handle, *[_ptr(t) for t in tens], _ptr(vmax), _ptr(arg), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_max_forward')
+        ctx.plan, ctx.nbytes = plan, nbytes
+        ctx.save_for_backward(*tens, arg)
+        ctx.mark_non_differentiable(arg)
+        return vmax, arg
+
+    @staticmethod
+    @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
+    def backward(ctx, d_max, _d_arg):
+        plan = ctx.plan
+        inside_h, outside_h, obj_span, arg = ctx.saved_tensors
+        if d_max is None:
+            return None, None, None, None
+        d_max = d_max.contiguous().float()
+        d_sum = torch.empty_like(inside_h)
+        ws = torch.empty(ctx.nbytes, device=inside_h.device, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_max_backward(plan.handle, _ptr(inside_h), _ptr(outside_h), _ptr(obj_span), _ptr(d_max), _ptr(arg),
+                                                     _ptr(d_sum), None, _ptr(ws), ctx.nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_max_backward')
+        return None, d_sum, d_sum, None
+
+
+class VLMaxObj(torch.autograd.Function):
+    """The region matrix's half of the region-max scorer's backward.  forward: no work (hands `vmax` through); it is called under the
+    caller lane's stream so that autograd runs the backward there (a node's backward runs on its forward's stream)."""
+
+    @staticmethod
+    def forward(ctx, plan, obj_span, inside_h, outside_h, vmax, arg):
+        ctx.plan = plan
+        ctx.nbytes = _lib.lib().cliora_plan_vl_workspace_bytes(plan.handle)
+        ctx.save_for_backward(inside_h, outside_h, obj_span, arg)
+        return vmax.view_as(vmax)
+
+    @staticmethod
+    @_lib.on_device(lambda ctx, *a: ctx.saved_tensors[0])
+    def backward(ctx, d_max):
+        plan = ctx.plan
+        inside_h, outside_h, obj_span, arg = ctx.saved_tensors
+        if d_max is None:
+            return None, None, None, None, None, None
+        d_max = d_max.contiguous().float()
+        d_obj = torch.empty_like(obj_span)
+        ws = torch.empty(ctx.nbytes, device=inside_h.device, dtype=torch.uint8)
+        rc = _lib.lib().cliora_vl_scores_max_backward(plan.handle, _ptr(inside_h), _ptr(outside_h), _ptr(obj_span), _ptr(d_max), _ptr(arg),
+                                                     None, _ptr(d_obj), _ptr(ws), ctx.nbytes, _stream())
+        _lib.check(rc, 'cliora_vl_scores_max_backward')
+        return None, d_obj, None, None, None, None
+
+
+class JoinGrad(torch.autograd.Function):
+    """a (values) with b as a second path for the cotangent: forward returns a, backward hands the same cotangent to a's and b's producers."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def region_max(plan, inside_h, outside_h, obj_span, lane):
+    """(max over regions, its region) of the span-region scores; with a lane: the region matrix's gradient as a node of its own there."""
+    if lane is None or not obj_span.requires_grad or not torch.is_grad_enabled():
+        return VLMaxFunction.apply(plan, inside_h, outside_h, obj_span)
+    vmax_a, arg = VLMaxRows.apply(plan, inside_h, outside_h, obj_span.detach())
+    with torch.cuda.stream(lane):
+        vmax_b = VLMaxObj.apply(plan, obj_span, inside_h.detach(), outside_h.detach(), vmax_a.detach(), arg)
+    return JoinGrad.apply(vmax_a, vmax_b), arg
+
+
 class RegionMax(tuple):
     """What `all_atten_score.max(-1)` returns: (values, indices) with the field names of torch.return_types.max."""
     values = property(lambda self: self[0])
@@ -174,8 +263,8 @@ class LazyRegionScores:
     tensor at B 64 / L 20 / R 36 is never written or differentiated through).  Anything else -- indexing, torch functions,
     tensor attributes -- materialises the dense tensor once through the ordinary scorer and behaves like it."""
 
-    def __init__(self, plan, inside_h, outside_h, obj_span):
-        self._plan, self._args = plan, (inside_h, outside_h, obj_span)
+    def __init__(self, plan, inside_h, outside_h, obj_span, lane=None):
+        self._plan, self._args, self._lane = plan, (inside_h, outside_h, obj_span), lane
         self._dense, self._max = None, None
         self.shape = torch.Size((plan.B, plan.B, plan.C, plan.R))
         self.device, self.dtype = inside_h.device, torch.float32
@@ -189,7 +278,7 @@ class LazyRegionScores:
     def max(self, dim=None, keepdim=False):
         if dim in (-1, 3) and not keepdim and self._dense is None:
             if self._max is None:
-                vmax, arg = VLMaxFunction.apply(self._plan, *self._args)
+                vmax, arg = region_max(self._plan, *self._args, self._lane)
                 self._max = RegionMax((vmax, arg.long()))
             return self._max
         return self.materialize().max() if dim is None else self.materialize().max(dim, keepdim)
@@ -263,6 +352,10 @@ class DioraMLP(DioraBase):
         self.root_vector_out_c = None
         self.dropout_mask = None      # tests inject a (B, C, R) pre-scaled mask here; None = draw one per forward
         self.lazy_region_scores = True   # training mode: all_atten_score is a LazyRegionScores (False: always the dense tensor)
+        # The library's caller lane (include/cliora_chart.h: cliora_device_side_stream) for the work of a training step that the chart does not
+        # wait for: the word-region scorer (its inputs may already live there: harness.Net puts the word projections on it) and the region
+        # matrix's half of the region-max backward.  None (default) = everything on the current stream; harness.Net sets it per forward.
+        self.word_lane = None
 
     def get_chart_wrapper(self):
         return self
@@ -299,8 +392,19 @@ class DioraMLP(DioraBase):
         # cliora.py:453-468
         if self.training and self.lazy_region_scores:
             # training: vg_atten does not read all_atten (cliora.py:459-461) and the contrastive loss only wants its region max
-            _, vg = VLScoreFunction.apply(plan, True, ih, oh, obj_embed_span, x_word, obj_embed_word, False)
-            all_att = LazyRegionScores(plan, ih, oh, obj_embed_span)
+            lane = self.word_lane if x_span.is_cuda else None
+            if lane is not None:
+                # the word-region scorer on the caller lane: neither its forward nor its backward (0.2 ms at c3) is on the chart's path; the
+                # chart rows and the span region matrix are not read by it (detached: no gradient edge into the chart either)
+                cur = torch.cuda.current_stream(x_span.device)
+                lane.wait_stream(cur)
+                with torch.cuda.stream(lane):
+                    _, vg = VLScoreFunction.apply(plan, True, ih.detach(), oh.detach(), obj_embed_span.detach(), x_word, obj_embed_word, False)
+                cur.wait_stream(lane)                 # whoever reads vg next on this stream (the VG loss) finds it complete
+                vg.record_stream(cur)
+            else:
+                _, vg = VLScoreFunction.apply(plan, True, ih, oh, obj_embed_span, x_word, obj_embed_word, False)
+            all_att = LazyRegionScores(plan, ih, oh, obj_embed_span, lane)
         else:
             all_att, vg = VLScoreFunction.apply(plan, self.training, ih, oh, obj_embed_span, x_word, obj_embed_word, True)
         self.all_atten_score = all_att

@@ -121,6 +121,7 @@ extern "C" size_t cliora_plan_device_bytes(const cliora_plan* plan) {
 // Side streams and fork / join / level events of one device, created at the first call there and kept for the life of the process.
 struct DeviceLanes {
     hipStream_t side = nullptr, side2 = nullptr;
+    hipStream_t side3 = nullptr;            // the callers' lane (cliora_device_side_stream), created at its first request
     hipEvent_t fork[3], join[3], level[CLIORA_MAX_L + 1];
     unsigned long long* trace = nullptr;    // TRACE_BYTES of device words for the diagnostic stamps of the resident kernels (CLIORA_RES_TRACE)
     int ncu = 0;
@@ -212,6 +213,27 @@ static int device_lanes(int dev, hipStream_t st, DeviceLanes** out) {
         g_lanes[dev] = ln;
     }
     *out = g_lanes[dev];
+    return CLIORA_OK;
+}
+
+// A fourth lane for the CALLERS of the chart path: work that is independent of the chart -- the word branch of a CLIORA step (word
+// projections, word-region scorer, their backward; cliora.py:459-461) and the region-matrix half of the span-region scorer's backward --
+// runs there beside the chart's two chains and its weight-gradient stream.  Picked like the library's own lanes (a stream that runs a
+// probe kernel concurrently with the caller's stream and the two lanes), once per device, so that it does not land on one of their
+// hardware queues.  The stream belongs to the library; callers only enqueue on it and order it against their own streams by events.
+extern "C" int cliora_device_side_stream(void* caller_stream, void** out) {
+    if (!out) return fail(CLIORA_EINVAL, "out is NULL");
+    int dev = 0;
+    HIPOK(hipGetDevice(&dev));
+    hipStream_t st = (hipStream_t)caller_stream;
+    DeviceLanes* ln = nullptr;
+    OKR(device_lanes(dev, st, &ln));
+    std::lock_guard<std::mutex> lk(ln->mu);
+    if (!ln->side3) {
+        hipStream_t busy[3] = {st, ln->side, ln->side2};
+        OKR(pick_concurrent_stream(busy, 3, &ln->side3));
+    }
+    *out = (void*)ln->side3;
     return CLIORA_OK;
 }
 

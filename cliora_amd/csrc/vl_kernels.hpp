@@ -352,7 +352,10 @@ static __global__ __launch_bounds__(256) void region_max_bwd_rows(int B, int Cq,
         }
         float4 v0[4], v1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v0[j] = act0 ? ld4(row[j] + col0) : f4zero(); v1[j] = act1 ? ld4(row[j] + col1) : f4zero(); }
+        for (int j = 0; j < 4; ++j) {       // a zero cotangent (every span beyond the first C / 2 under the contrastive loss, trainer.py:126) adds nothing: no row fetch
+            const bool live = gv[j] != 0.f;
+            v0[j] = (act0 && live) ? ld4(row[j] + col0) : f4zero(); v1[j] = (act1 && live) ? ld4(row[j] + col1) : f4zero();
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc0 = f4fma(gv[j], v0[j], acc0); acc1 = f4fma(gv[j], v1[j], acc1); }
     }
@@ -393,8 +396,9 @@ static __global__ __launch_bounds__(256) void region_max_bwd_obj(int B, int Cq, 
         const size_t base = ((size_t)a * B + c) * Cq;
         for (int b0 = 0; b0 < Cq; b0 += 64) {
             const int b = b0 + lane;
-            const bool hit = b < Cq && arg[base + b] == d;
-            const float gl = hit ? G[base + b] : 0.f;
+            const float gq = b < Cq ? G[base + b] : 0.f;
+            const bool hit = gq != 0.f && arg[base + b] == d;      // a zero cotangent adds nothing (trainer.py:126: only the first C / 2 spans carry one)
+            const float gl = hit ? gq : 0.f;
             unsigned long long m = __ballot(hit);
             while (m) {                              // up to four matches in flight, in span order
                 int bb[4]; float gv[4];

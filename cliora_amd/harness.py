@@ -42,12 +42,18 @@ class Embed(nn.Module):
         self.mat1 = nn.Parameter(torch.empty(size, input_size))
         _normal_(self)
 
-    def forward(self, tokens):
+    def forward(self, tokens, word_lane=None):
+        """word_lane: a stream for the WORD projection (the second output), whose only reader is then the word-region scorer on the same
+        stream (cliora_amd.cliora.DioraMLP.word_lane); None: both on the current stream."""
         B, L = tokens.shape
         w = self.embeddings.weight
         if _native(w, tokens) and w.shape[1] % 16 == 0:
             idx = tokens.reshape(-1)
-            return heads.proj(w, idx, self.mat).view(B, L, -1), heads.proj(w, idx, self.mat1).view(B, L, -1)
+            span = heads.proj(w, idx, self.mat).view(B, L, -1)
+            if word_lane is None:
+                return span, heads.proj(w, idx, self.mat1).view(B, L, -1)
+            with torch.cuda.stream(word_lane):
+                return span, heads.proj(w, idx, self.mat1).view(B, L, -1)
         e = self.embeddings(tokens.reshape(-1))
         return (e @ self.mat.t()).view(B, L, -1), (e @ self.mat1.t()).view(B, L, -1)
 
@@ -61,12 +67,15 @@ class ImageEncoder(nn.Module):
         for p in self.parameters():
             p.data.zero_()
 
-    def forward(self, obj_feats):
+    def forward(self, obj_feats, word_lane=None):
         x = obj_feats.float()
         if _native(x) and x.shape[-1] % 16 == 0:
             lead = x.shape[:-1]
-            return (heads.proj(x, None, self.fc.weight, self.fc.bias).view(*lead, -1),
-                    heads.proj(x, None, self.fc_vis.weight, self.fc_vis.bias).view(*lead, -1))
+            span = heads.proj(x, None, self.fc.weight, self.fc.bias).view(*lead, -1)
+            if word_lane is None:
+                return span, heads.proj(x, None, self.fc_vis.weight, self.fc_vis.bias).view(*lead, -1)
+            with torch.cuda.stream(word_lane):          # see Embed.forward
+                return span, heads.proj(x, None, self.fc_vis.weight, self.fc_vis.bias).view(*lead, -1)
         return self.fc(x), self.fc_vis(x)
 
 
@@ -184,6 +193,7 @@ class Net(nn.Module):
     def __init__(self, embed, image_encoder, diora, obj_feats, loss_funcs=()):
         super().__init__()
         self.obj_feats = obj_feats
+        self.overlap_word_branch = True      # vision-language training steps: the word branch on the library's caller lane (forward())
         if obj_feats:
             self.img_encoder = image_encoder
         self.embed, self.diora = embed, diora
@@ -192,10 +202,26 @@ class Net(nn.Module):
             setattr(self, m.name, m)
 
     def forward(self, tokens, obj_feats=None, neg_samples=None, compute_loss=True):
-        x_span, x_word = self.embed(tokens)
+        # The word branch of a vision-language training step -- Embed's word projection, ImageEncoder's fc_vis, the word-region scorer and,
+        # in the backward, their gradients and the region matrix's half of the region-max backward -- shares nothing with the chart
+        # (cliora.py:459-461, trainer.py:139-171): it runs on the library's caller lane beside the chart's forward and backward
+        # (autograd runs a node's backward on its forward's stream and orders the streams itself; the lane joins the current stream
+        # before the VG loss reads the scores, and again when backward() returns).
+        lane = None
+        if (self.overlap_word_branch and self.obj_feats and self.training and torch.is_grad_enabled() and tokens.is_cuda and heads.NATIVE_LANES
+                and getattr(self.diora, 'lazy_region_scores', False)):
+            from . import _lib
+            lane = _lib.side_stream(tokens.device)
+            lane.wait_stream(torch.cuda.current_stream(tokens.device))     # the step's inputs and the parameters of the last update
+        if hasattr(self.diora, 'word_lane'):
+            self.diora.word_lane = lane
+        if lane is not None:
+            x_span, x_word = self.embed(tokens, word_lane=lane)
+        else:
+            x_span, x_word = self.embed(tokens)
         o_span = o_word = None
         if self.obj_feats:
-            o_span, o_word = self.img_encoder(obj_feats)
+            o_span, o_word = self.img_encoder(obj_feats, word_lane=lane) if lane is not None else self.img_encoder(obj_feats)
         self.diora(x_span, x_word, o_span, o_word)
         if not compute_loss:
             return {'total_loss': torch.ones(1, 1, device=x_span.device)}

@@ -68,6 +68,7 @@ class DeferredTableGrads(object):
         self.pending = {}
 
 
+NATIVE_LANES = True     # False: never use the library's caller lane (harness.Net.forward), everything on the current stream (A/B, tests)
 _deferred = None        # a DeferredTableGrads while harness.Trainer.step runs a backward pass, else None
 
 

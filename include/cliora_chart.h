@@ -350,6 +350,13 @@ size_t cliora_plan_fwd_offset(const cliora_plan* plan, const char* name);
 /* Bytes of device index tables the plan uploads at its first use. */
 size_t cliora_plan_device_bytes(const cliora_plan* plan);
 
+/* A stream of the library's, on the current device, for work of the CALLER that is independent of the chart call it surrounds (the
+ * word branch of cliora/net/cliora.py:459-461 and trainer.py:139-171: word projections, word-region scorer, VG loss gradient; the
+ * region-matrix half of the span-region scorer's backward): chosen once per device so that it runs concurrently with `caller_stream`
+ * and with the two streams the chart calls fork onto.  The caller orders it against its own streams with events (torch:
+ * torch.cuda.ExternalStream(handle), wait_stream); the library never waits on it.  The handle stays valid for the life of the process. */
+int cliora_device_side_stream(void* caller_stream, void** out);
+
 /* Diagnostics: the wall-clock stamps (100 MHz) the sentence-resident kernels leave when CLIORA_RES_TRACE=1 (tools/resident_trace.py):
  * copies `count` 64-bit words of the device's stamp buffer to `out` (host) after synchronising `stream`. */
 int cliora_resident_trace(cliora_plan* plan, unsigned long long* out, size_t count, void* stream);

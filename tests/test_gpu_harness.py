@@ -151,3 +151,41 @@ def test_trainer_with_a_reducer_writes_chart_gradients_in_place_and_double_forwa
             sc = max(1.0, float(single[n].abs().max()))
             assert float((p.grad - 2.0 * single[n]).abs().max()) <= 1e-5 * sc, n
     red.close()
+
+
+def test_word_branch_on_the_caller_lane_is_the_single_stream_step():
+    """A vision-language training step with the word branch (Embed's word projection, ImageEncoder.fc_vis, the word-region scorer, their
+    backward, the region matrix's half of the region-max backward) on the library's caller lane (harness.Net.overlap_word_branch,
+    cliora_device_side_stream) against the same step on one stream: the same kernels on the same data, only the streams differ -- losses,
+    every gradient of the first step and the parameters after three steps agree to the bit (sums of two terms commute)."""
+    from cliora_amd import harness as H
+    res = {}
+    for overlap in (True, False):
+        torch.manual_seed(21)
+        V, E, D, B, L, K, R = 200, 64, 48, 5, 6, 12, 36
+        net = H.build_net(D, torch.nn.Embedding(V, E), obj_feats=True, img_dim=32, k_neg=K, vg_loss=True, use_contr=True).cuda()
+        for p in net.img_encoder.parameters():
+            torch.nn.init.normal_(p, std=0.05)
+        net.overlap_word_branch = overlap
+        g = torch.Generator().manual_seed(22)
+        bm = dict(sentences=torch.randint(0, V, (B, L), generator=g).cuda(), neg_samples=torch.randperm(V, generator=g)[:K].cuda(),
+                  obj_feats=torch.randn(B, R, 32, generator=g).cuda())
+        C = L * (L + 1) // 2
+        net.diora.dropout_mask = (torch.rand(B, C, R, generator=g) > 0.1).float().cuda() / 0.9        # the same recorded mask in both runs
+        net.train()
+        out = net(bm['sentences'], bm['obj_feats'], bm['neg_samples'])
+        assert (net.diora.word_lane is not None) == overlap
+        out.total().backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        net.zero_grad()
+        tr = H.Trainer(net, lr=2e-3)
+        losses = [tr.step(bm, train=True)['total_loss'] for _ in range(3)]
+        res[overlap] = (float(out.total().detach()), grads, losses, {k: p.detach().clone() for k, p in net.named_parameters()})
+    assert res[True][0] == res[False][0]
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) >= 10
+    for k in res[False][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+    assert res[True][2] == res[False][2]
+    for k in res[False][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k

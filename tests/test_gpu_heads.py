@@ -153,8 +153,9 @@ def test_rows_scatter_add_segments_is_the_sum_of_the_lookups():
     for sizes, K, V in (((1380, 1280), 1024, 10000), ((9, 0, 300, 4), 48, 7), ((3,), 16, 5), ((0, 0), 16, 5)):
         idx = [torch.randint(0, V, (n,), generator=g) for n in sizes]
         rows = [torch.randn(n, K, generator=g) for n in sizes]
-        if sizes[0] > 8:
-            idx[1][:6] = idx[0][:6]                                # tokens that both lookups hit
+        big = max(range(len(sizes)), key=lambda k: (k > 0, sizes[k])) if len(sizes) > 1 else 0
+        if big and sizes[0] > 8 and sizes[big] >= 6:
+            idx[big][:6] = idx[0][:6]                              # tokens that both lookups hit
         want = torch.zeros(V, K)
         for i, r in zip(idx, rows):
             want.index_add_(0, i, r)
