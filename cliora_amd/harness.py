@@ -297,10 +297,14 @@ class Trainer(object):
             # buffer, from every lookup's rows (heads.DeferredTableGrads) instead of one dense scatter per lookup + dense adds
             defer = heads.DeferredTableGrads(self.optimizer.grads) if (self.fused and self.defer_table_grads) else None
             heads._deferred = defer
+            heads._step_lanes = lanes = set() if self.fused else None
             try:
                 total.backward()
             finally:
                 heads._deferred = None
+                heads._step_lanes = None
+            for lane in (lanes or ()):               # leaf gradients that backward nodes left to the caller lane (heads._step_lane)
+                torch.cuda.current_stream(lane.device).wait_stream(lane)
             if defer is not None:
                 defer.flush()
             if self.reducer is not None:

@@ -68,17 +68,33 @@ class DeferredTableGrads(object):
         self.pending = {}
 
 
+_step_lanes = None      # inside harness.Trainer.step: the set of caller lanes that backward nodes put work on (joined before the update)
+
+
+def _step_lane(device):
+    """The library's caller lane for work that only the parameter update waits for -- available while harness.Trainer.step runs the
+    backward pass (it joins the lane before the all-reduce / clip + Adam), else None."""
+    if _step_lanes is None or not NATIVE_LANES:
+        return None
+    lane = _lib.side_stream(device)
+    _step_lanes.add(lane)
+    return lane
+
+
 NATIVE_LANES = True     # False: never use the library's caller lane (harness.Net.forward), everything on the current stream (A/B, tests)
 _deferred = None        # a DeferredTableGrads while harness.Trainer.step runs a backward pass, else None
 
 
-def scatter_rows(d_rows, index, table):
+def scatter_rows(d_rows, index, table, producer_lane=None):
     """Gradient of the embedding `table` (V, K) from the gradients d_rows (n, K) of its looked-up rows index (n,): cliora_rows_scatter_add,
     written into the table's slice of a live flat gradient buffer when this is the first producer of the pass (else a fresh tensor that
     autograd adds).  Replaces zeros_like + index_add_ (round 3's last ATen op on the step), deterministic for repeated ids.
-    Inside harness.Trainer.step the contribution is deferred instead (DeferredTableGrads) and None is returned."""
+    Inside harness.Trainer.step the contribution is deferred instead (DeferredTableGrads) and None is returned.
+    producer_lane: the stream d_rows is produced on when that is not the current one."""
     if _deferred is not None and _deferred.offer(d_rows, index, table):
         return None
+    if producer_lane is not None:           # d_rows is still being written on another stream and the scatter runs here, now
+        torch.cuda.current_stream(table.device).wait_stream(producer_lane)
     out = _grad_out(table)
     with torch.cuda.device(table.device):
         _lib.check(_lib.lib().cliora_rows_scatter_add(_p(d_rows.contiguous()), _p(index.contiguous()), int(index.numel()), int(table.shape[1]), _p(out),
@@ -177,15 +193,25 @@ class ReconLoss(torch.autograd.Function):
             d_mat = _grad_out(mat) if ctx.needs_input_grad[1] else None
             d_rows = torch.empty((B * L + Kn, E), device=emb.device) if ctx.needs_input_grad[0] else None
             nb = ctx.ws.numel()
-            _lib.check(lib.cliora_recon_backward(_p(tokens), _p(neg), B, L, Cc, Kn, _p(emb), E, _p(mat), D, _p(outside_h), _p(g), _p(d_cell), _p(d_mat),
-                                                 _p(d_rows), _p(ctx.ws), nb, _st()), 'cliora_recon_backward')
+            args = lambda dc, dm, dr: (_p(tokens), _p(neg), B, L, Cc, Kn, _p(emb), E, _p(mat), D, _p(outside_h), _p(g), _p(dc), _p(dm), _p(dr), _p(ctx.ws), nb, _st())
+            lane = _step_lane(emb.device) if (d_cell is not None and (d_mat is not None or d_rows is not None)) else None
+            if lane is None:
+                _lib.check(lib.cliora_recon_backward(*args(d_cell, d_mat, d_rows)), 'cliora_recon_backward')
+            else:
+                # inside harness.Trainer.step: the chart backward waits for d cell only; the projection's and the looked-up rows' gradients
+                # (two GEMMs, 0.07 ms at c2) follow on the caller lane, behind the first call (they share its workspace), beside the chart
+                _lib.check(lib.cliora_recon_backward(*args(d_cell, None, None)), 'cliora_recon_backward')
+                cur = torch.cuda.current_stream(emb.device)
+                lane.wait_stream(cur)
+                with torch.cuda.stream(lane):
+                    _lib.check(lib.cliora_recon_backward(*args(None, d_mat, d_rows)), 'cliora_recon_backward')
             d_oh = None
             if d_cell is not None:
                 d_oh = torch.zeros_like(outside_h)
                 d_oh[:, :L] = d_cell.view(B, L, D)
             d_emb = None
             if d_rows is not None:
-                d_emb = scatter_rows(d_rows, torch.cat([tokens.reshape(-1), neg]), emb)
+                d_emb = scatter_rows(d_rows, torch.cat([tokens.reshape(-1), neg]), emb, producer_lane=lane)
         return d_emb, d_mat, d_oh, None, None
 
 
