@@ -103,8 +103,9 @@ def lib():
     L.cliora_recon_backward.restype = i32
     L.cliora_rows_scatter_add.argtypes = [vp, vp, i32, i32, vp, C.c_int64, vp]     # mandatory: heads.scatter_rows has no other path
     L.cliora_rows_scatter_add.restype = i32
-    L.cliora_rows_scatter_add_segments.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, i32, vp, C.c_int64, vp]
-    L.cliora_rows_scatter_add_segments.restype = i32
+    if hasattr(L, 'cliora_rows_scatter_add_segments'):          # (absent from older builds loaded through CLIORA_CHART_LIB for A/B runs)
+        L.cliora_rows_scatter_add_segments.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, i32, vp, C.c_int64, vp]
+        L.cliora_rows_scatter_add_segments.restype = i32
     L.cliora_vg_workspace_bytes.argtypes = [i32, i32]
     L.cliora_vg_workspace_bytes.restype = sz
     L.cliora_vg_loss.argtypes = [i32, i32, i32, vp, C.c_float, vp, vp, vp, sz, vp]
@@ -129,10 +130,12 @@ def lib():
     L.cliora_set_wavefront.restype = i32
     L.cliora_set_resident.argtypes = [i32]
     L.cliora_set_resident.restype = i32
-    L.cliora_device_side_stream.argtypes = [vp, C.POINTER(vp)]
-    L.cliora_device_side_stream.restype = i32
-    L.cliora_resident_trace.argtypes = [vp, vp, sz, vp]
-    L.cliora_resident_trace.restype = i32
+    if hasattr(L, 'cliora_device_side_stream'):
+        L.cliora_device_side_stream.argtypes = [vp, C.POINTER(vp)]
+        L.cliora_device_side_stream.restype = i32
+    if hasattr(L, 'cliora_resident_trace'):
+        L.cliora_resident_trace.argtypes = [vp, vp, sz, vp]
+        L.cliora_resident_trace.restype = i32
     _lib = L
     return L
 
