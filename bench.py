@@ -407,7 +407,7 @@ def other_measurements(torch, dev, budget_steps=12):
              ('whole step DIORA c2 (Embed, chart, reconstruction loss, clip, Adam)', lambda: whole(False)),
              ('whole step CLIORA c3 (+ ImageEncoder, VG and contrastive losses)', lambda: whole(True)))
     impl_note = {'c5 DioraTreeLSTM d400 B64 L40 (parity unpinned)':
-                 'implementation traffic ~118 GB per step (DESIGN.md section 7a: twelve rows per pair in the forward, nine rows per use and four uses per pair in the backward)'}
+                 'implementation traffic 136.6 GB per step by counters (profiles/r06_traffic_shapes.json; DESIGN.md section 4 / profiles/r06_notes.md section 6: five gate rows per operand -- 12 + 2 rows per pair in the forward, 2 x 9 in the backward)'}
     for name, fn in cases:
         try:
             out[name] = fn()
