@@ -356,6 +356,9 @@ class DioraMLP(DioraBase):
         # wait for: the word-region scorer (its inputs may already live there: harness.Net puts the word projections on it) and the region
         # matrix's half of the region-max backward.  None (default) = everything on the current stream; harness.Net sets it per forward.
         self.word_lane = None
+        # True: x_word / obj_embed_word were produced ON the lane (harness.Net.forward), so the scorer needs no wait for the current stream --
+        # it then runs beside the chart's forward instead of behind it
+        self.word_inputs_on_lane = False
 
     def get_chart_wrapper(self):
         return self
@@ -397,7 +400,8 @@ class DioraMLP(DioraBase):
                 # the word-region scorer on the caller lane: neither its forward nor its backward (0.2 ms at c3) is on the chart's path; the
                 # chart rows and the span region matrix are not read by it (detached: no gradient edge into the chart either)
                 cur = torch.cuda.current_stream(x_span.device)
-                lane.wait_stream(cur)
+                if not self.word_inputs_on_lane:      # inputs produced on this stream: the lane waits for them (and for the whole chart before them)
+                    lane.wait_stream(cur)
                 with torch.cuda.stream(lane):
                     _, vg = VLScoreFunction.apply(plan, True, ih.detach(), oh.detach(), obj_embed_span.detach(), x_word, obj_embed_word, False)
                 cur.wait_stream(lane)                 # whoever reads vg next on this stream (the VG loss) finds it complete

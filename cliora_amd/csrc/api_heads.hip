@@ -61,7 +61,7 @@ extern "C" int cliora_vg_loss(int B, int L, int R, const float* vg_atten, float 
     int32_t* arg = reinterpret_cast<int32_t*>(row_loss + al64((size_t)B));
     hipLaunchKernelGGL(vg_logits_fwd, dim3((B * B + 3) / 4), dim3(256), 0, st, B, L, R, vg_atten, logits, arg);
     LAUNCHOK("vg_logits_fwd");
-    hipLaunchKernelGGL(vg_ce, dim3(1), dim3(256), 0, st, B, alpha, logits, row_loss, dlog, loss);
+    hipLaunchKernelGGL(vg_ce, dim3(1), dim3(1024), 0, st, B, alpha, logits, row_loss, dlog, loss);
     LAUNCHOK("vg_ce");
     if (d_vg_atten) {
         const size_t n = (size_t)B * B * L * R;

@@ -263,7 +263,7 @@ extern "C" int cliora_contrastive_loss(int B, int C, const float* all_max, const
                            d_all_max, d_inside_s, d_outside_s);
         LAUNCHOK("contrastive_spans");
     }
-    hipLaunchKernelGGL(contrastive_finish, dim3(1), dim3(128), 0, st, B, C, nb, part, last, k, loss, d_inside_s);
+    hipLaunchKernelGGL(contrastive_finish, dim3(1), dim3(256), 0, st, B, C, nb, part, last, k, loss, d_inside_s);
     LAUNCHOK("contrastive_finish");
     return CLIORA_OK;
 }

@@ -96,12 +96,13 @@ static __global__ __launch_bounds__(256) void vg_logits_fwd(int B, int L, int R,
     }
     if (lane == 0) logits[pair] = sum / (float)L;
 }
-// One workgroup: cross entropy of the (B, B) logits against the diagonal; row a on wave a % 4.  d_logits for an upstream
-// cotangent of 1; the per-row losses are added in row order by one lane.
-static __global__ __launch_bounds__(256) void vg_ce(int B, float alpha, const float* __restrict__ logits, float* __restrict__ row_loss,
-                                                    float* __restrict__ d_logits, float* __restrict__ loss) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int a = wave; a < B; a += 4) {
+// One workgroup: cross entropy of the (B, B) logits against the diagonal; row a on wave a % 16 (sixteen waves: a row is three dependent
+// passes with a wave reduction each, 20 us on four waves at B 64).  d_logits for an upstream cotangent of 1; the per-row losses are
+// added in row order by one lane.
+static __global__ __launch_bounds__(1024) void vg_ce(int B, float alpha, const float* __restrict__ logits, float* __restrict__ row_loss,
+                                                     float* __restrict__ d_logits, float* __restrict__ loss) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int a = wave; a < B; a += nwave) {
         float m = -INFINITY;
         for (int c = lane; c < B; c += 64) m = fmaxf(m, logits[a * B + c]);
         m = wave_max(m);

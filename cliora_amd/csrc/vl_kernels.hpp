@@ -506,18 +506,35 @@ static __global__ __launch_bounds__(256) void contrastive_spans(int B, int Cq, c
     }
     if (tid == 0) part[b] = red[0];
 }
-// loss = k sum_b part[b];  d in_s[x][C-1] = -k sum_b last[b][x]   (fixed order)
-static __global__ void contrastive_finish(int B, int Cq, int nb, const float* __restrict__ part, const float* __restrict__ last, float k,
-                                          float* __restrict__ loss, float* __restrict__ dIS) {
-    const int x = threadIdx.x;
-    if (x == 0) {
-        float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += part[b];
-        loss[0] = k * s;
+// loss = k sum_b part[b];  d in_s[x][C-1] = -k sum_b last[b][x]   (fixed order: the same bits as one lane adding b = 0, 1, ...)
+// 256 threads: wave 0 prefetches the partial losses (lane l holds part[l], part[l + 64], ...) and lane 0 adds them in b order out of LDS;
+// waves 1..3 take the columns x < B, four loads in flight (the round-5 form was one dependent global load per addend on a single lane: 29 us
+// at C = 210).
+static __global__ __launch_bounds__(256) void contrastive_finish(int B, int Cq, int nb, const float* __restrict__ part, const float* __restrict__ last, float k,
+                                                                 float* __restrict__ loss, float* __restrict__ dIS) {
+    __shared__ float sp[1024];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int nbc = min(nb, 1024);
+        for (int b = tid; b < nbc; b += 64) sp[b] = part[b];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);
+        if (tid == 0) {
+            float s = 0.f;
+            for (int b = 0; b < nbc; ++b) s += sp[b];
+            for (int b = nbc; b < nb; ++b) s += part[b];
+            loss[0] = k * s;
+        }
+        return;
     }
-    if (x < B) {
+    for (int x = tid - 64; x < B; x += 192) {
         float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += last[(size_t)b * B + x];
+        int b = 0;
+        for (; b + 4 <= nb; b += 4) {
+            const float v0 = last[(size_t)b * B + x], v1 = last[(size_t)(b + 1) * B + x], v2 = last[(size_t)(b + 2) * B + x], v3 = last[(size_t)(b + 3) * B + x];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nb; ++b) s += last[(size_t)b * B + x];
         dIS[(size_t)x * Cq + Cq - 1] -= k * s;
     }
 }

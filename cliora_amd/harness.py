@@ -215,6 +215,7 @@ class Net(nn.Module):
             lane.wait_stream(torch.cuda.current_stream(tokens.device))     # the step's inputs and the parameters of the last update
         if hasattr(self.diora, 'word_lane'):
             self.diora.word_lane = lane
+            self.diora.word_inputs_on_lane = lane is not None
         if lane is not None:
             x_span, x_word = self.embed(tokens, word_lane=lane)
         else:
