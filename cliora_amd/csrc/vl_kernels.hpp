@@ -214,41 +214,54 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
 }
 
 // d obj[b][k][:] = sum over the inside cells of sentence b of  pm[cell][k] * dctx[cell][:] + dsc[cell][k] * u[cell][:]
-// One workgroup per (sentence, 4 regions): wave w owns region 4*blockIdx.y + w; cells in chart order.
-static __global__ __launch_bounds__(256) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
+// One workgroup (2 waves) per (sentence, region group y of 4): it owns the regions y + 4 m, m < NRW; wave w the float4 columns lane + 64 w.
+// A wave keeps NRW accumulators -- a cell's two rows are fetched ONCE for all of its regions (round 6; one wave per region re-read both rows
+// of every cell 36 times: 1.5 GB through L2 per launch at c3, 159 us on the stream that ends the CLIORA backward; now 4 reads per row).  The region weights of a cell
+// come as one lane-indexed load (lane k holds region k) and are broadcast by readlane.  Cells in chart order, the same two FMAs per cell and
+// element as before: the same bits.
+template <int NRW>
+static __global__ __launch_bounds__(128) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
                                                        const float* __restrict__ PMo, const float* __restrict__ DSC,
                                                        float* __restrict__ dOBJ) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x, k = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (k >= R) return;
+    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+    const int b = blockIdx.x, k0 = blockIdx.y;
     const int nv = Dp >> 2;
-    const bool a0 = lane < nv, a1 = lane + 64 < nv;
-    const int c0 = 4 * lane, c1 = 4 * (lane + 64);
-    float4 s0 = f4zero(), s1 = f4zero();
-    constexpr int NB = 8;                 // cells in flight: the loop is a latency chain (C / NB round trips), not bandwidth
+    const int v = lane + 64 * half;
+    const bool act = v < nv;
+    const int c0 = 4 * (act ? v : 0);
+    float4 acc[NRW];
+#pragma unroll
+    for (int m = 0; m < NRW; ++m) acc[m] = f4zero();
+    constexpr int NB = 8;                 // cells in flight: the loop is a latency chain (C / NB round trips)
     for (int cc = 0; cc < C; cc += NB) {
-        float pm[NB], ds[NB];
-        float4 d0[NB], d1[NB], u0[NB], u1[NB];
+        float pmv[NB], dsv[NB];
+        float4 d[NB], u[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const size_t crow = (size_t)b * C + min(cc + j, C - 1);
             const bool ok = cc + j < C;
-            pm[j] = ok ? PMo[crow * VL_MAXR + k] : 0.f;
-            ds[j] = ok ? DSC[crow * VL_MAXR + k] : 0.f;
-            d0[j] = a0 ? ld4(DCTX + crow * Dp + c0) : f4zero();
-            d1[j] = a1 ? ld4(DCTX + crow * Dp + c1) : f4zero();
-            u0[j] = a0 ? ld4(U + crow * Dp + c0) : f4zero();
-            u1[j] = a1 ? ld4(U + crow * Dp + c1) : f4zero();
+            pmv[j] = ok ? PMo[crow * VL_MAXR + lane] : 0.f;        // lane k: region k (VL_MAXR = 64 = the wave)
+            dsv[j] = ok ? DSC[crow * VL_MAXR + lane] : 0.f;
+            d[j] = act ? ld4(DCTX + crow * Dp + c0) : f4zero();
+            u[j] = act ? ld4(U + crow * Dp + c0) : f4zero();
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            s0 = f4fma(pm[j], d0[j], s0); s1 = f4fma(pm[j], d1[j], s1);
-            s0 = f4fma(ds[j], u0[j], s0); s1 = f4fma(ds[j], u1[j], s1);
+#pragma unroll
+            for (int m = 0; m < NRW; ++m) {
+                const int k = min(k0 + 4 * m, VL_MAXR - 1);
+                const float pm = __shfl(pmv[j], k), ds = __shfl(dsv[j], k);
+                acc[m] = f4fma(pm, d[j], acc[m]);
+                acc[m] = f4fma(ds, u[j], acc[m]);
+            }
         }
     }
-    float* o = dOBJ + ((size_t)b * R + k) * Dp;
-    if (a0) st4(o + c0, s0);
-    if (a1) st4(o + c1, s1);
+    if (!act) return;
+#pragma unroll
+    for (int m = 0; m < NRW; ++m) {
+        const int k = k0 + 4 * m;
+        if (k < R) st4(dOBJ + ((size_t)b * R + k) * Dp + c0, acc[m]);
+    }
 }
 
 // ---------------------------------------------------------------------------------
