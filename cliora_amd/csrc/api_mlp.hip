@@ -1110,8 +1110,15 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     if (vl && d_obj_span) {      // d obj: independent of the weight gradients, so beside the pair rows' tail on the GEMM stream
         float* dO = padded ? wb + bw.dobjp : d_obj_span;
         if (Dp > 512) return fail(CLIORA_EINVAL, "obj_grad_reduce: D > 512 is not supported");
-        if (p.R <= 36) hipLaunchKernelGGL(obj_grad_reduce<9>, dim3(B, 4), dim3(128), 0, sw, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo, wb + bw.dsc, dO);
-        else hipLaunchKernelGGL(obj_grad_reduce<16>, dim3(B, 4), dim3(128), 0, sw, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo, wb + bw.dsc, dO);
+        if (p.R <= 36) {
+            const size_t lds = (size_t)3 * 2 * 9 * 64 * sizeof(float4);
+            OKR(cliora_ensure_max_lds((const void*)obj_grad_reduce<9>));
+            hipLaunchKernelGGL(obj_grad_reduce<9>, dim3(B, 4), dim3(512), lds, sw, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo, wb + bw.dsc, dO);
+        } else {
+            const size_t lds = (size_t)3 * 2 * 16 * 64 * sizeof(float4);
+            OKR(cliora_ensure_max_lds((const void*)obj_grad_reduce<16>));
+            hipLaunchKernelGGL(obj_grad_reduce<16>, dim3(B, 4), dim3(512), lds, sw, B, C, Dp, p.R, wb + bw.dctx, ws + f.att_u, wb + bw.pmo, wb + bw.dsc, dO);
+        }
         LAUNCHOK("obj_grad_reduce");
     }
     if (!dpi_done_recorded) OKR(wcat_grad(sw, 0, tail_cells, tail_cells < C));

@@ -214,32 +214,37 @@ static __global__ __launch_bounds__(256) void cell_attend_bwd(LevelArgs g, float
 }
 
 // d obj[b][k][:] = sum over the inside cells of sentence b of  pm[cell][k] * dctx[cell][:] + dsc[cell][k] * u[cell][:]
-// One workgroup (2 waves) per (sentence, region group y of 4): it owns the regions y + 4 m, m < NRW; wave w the float4 columns lane + 64 w.
-// A wave keeps NRW accumulators -- a cell's two rows are fetched ONCE for all of its regions (round 6; one wave per region re-read both rows
-// of every cell 36 times: 1.5 GB through L2 per launch at c3, 159 us on the stream that ends the CLIORA backward; now 4 reads per row).  The region weights of a cell
-// come as one lane-indexed load (lane k holds region k) and are broadcast by readlane.  Cells in chart order, the same two FMAs per cell and
-// element as before: the same bits.
+// One workgroup (8 waves) per (sentence, region group y of 4): it owns the regions y + 4 m, m < NRW.  Wave w takes the float4 columns
+// lane + 64 (w & 1) and the quarter w >> 1 of the sentence's cells, with NRW accumulators: a cell's two rows are fetched ONCE for all of the
+// wave's regions (round 6; one wave per region re-read both rows of every cell 36 times -- 1.5 GB through L2 per launch at c3 -- and walked
+// all 210 cells in one dependent chain: 159 us on the stream that ends the CLIORA backward).  The region weights of a cell come as one
+// lane-indexed load (lane k holds region k) and are broadcast by readlane.  The four quarters meet in LDS and are added in quarter order:
+// a fixed order, the same bits every run (not the bits of the one-chain sum it replaces).
+constexpr int OGR_WAVES = 8;
 template <int NRW>
-static __global__ __launch_bounds__(128) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
+static __global__ __launch_bounds__(512) void obj_grad_reduce(int B, int C, int Dp, int R, const float* __restrict__ DCTX, const float* __restrict__ U,
                                                        const float* __restrict__ PMo, const float* __restrict__ DSC,
                                                        float* __restrict__ dOBJ) {
-    const int lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float4 ogr_part[];      // [3 quarters][2 halves][NRW][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = wave & 1, q = wave >> 1;
     const int b = blockIdx.x, k0 = blockIdx.y;
     const int nv = Dp >> 2;
     const int v = lane + 64 * half;
     const bool act = v < nv;
     const int c0 = 4 * (act ? v : 0);
+    const int per = (C + 3) / 4, cbeg = q * per, cend = min(C, cbeg + per);
     float4 acc[NRW];
 #pragma unroll
     for (int m = 0; m < NRW; ++m) acc[m] = f4zero();
-    constexpr int NB = 8;                 // cells in flight: the loop is a latency chain (C / NB round trips)
-    for (int cc = 0; cc < C; cc += NB) {
+    constexpr int NB = 8;                 // cells in flight
+    for (int cc = cbeg; cc < cend; cc += NB) {
         float pmv[NB], dsv[NB];
         float4 d[NB], u[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const size_t crow = (size_t)b * C + min(cc + j, C - 1);
-            const bool ok = cc + j < C;
+            const bool ok = cc + j < cend;
             pmv[j] = ok ? PMo[crow * VL_MAXR + lane] : 0.f;        // lane k: region k (VL_MAXR = 64 = the wave)
             dsv[j] = ok ? DSC[crow * VL_MAXR + lane] : 0.f;
             d[j] = act ? ld4(DCTX + crow * Dp + c0) : f4zero();
@@ -256,11 +261,19 @@ static __global__ __launch_bounds__(128) void obj_grad_reduce(int B, int C, int 
             }
         }
     }
-    if (!act) return;
+    if (q > 0) {
+#pragma unroll
+        for (int m = 0; m < NRW; ++m) ogr_part[(((q - 1) * 2 + half) * NRW + m) * 64 + lane] = acc[m];
+    }
+    __syncthreads();
+    if (q != 0 || !act) return;
 #pragma unroll
     for (int m = 0; m < NRW; ++m) {
+        float4 s = acc[m];
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) s = f4add(s, ogr_part[((qq * 2 + half) * NRW + m) * 64 + lane]);
         const int k = k0 + 4 * m;
-        if (k < R) st4(dOBJ + ((size_t)b * R + k) * Dp + c0, acc[m]);
+        if (k < R) st4(dOBJ + ((size_t)b * R + k) * Dp + c0, s);
     }
 }
 
