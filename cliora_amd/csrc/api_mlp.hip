@@ -639,6 +639,24 @@ extern "C" int cliora_chart_forward(cliora_plan* plan, const cliora_params* P, c
                 ProfScope ps(CLIORA_KCLASS_COMPOSE_FWD, st);
                 OKR(launch_level_compose2(st, ca, cb, f.S3, Dp, f.ct3, f.ncb3, ws + f.pp, hp_stride, YM, PH));
             }
+#ifdef CLIORA_DIAG_BG
+            // Timing proxy for the "old / new pairs" pipeline (profiles/r06_notes.md section 5): what does a BACKGROUND compose grid cost the
+            // critical chain?  Step k's compose is launched a second time on the side stream, behind the first (same inputs, the same values
+            // written again: results unchanged), so that it runs beside this step's projection / score grid and the next step's compose --
+            // where the background composition of the next level's old splits would run.  CLIORA_BG=1: every step; 2: the share (k-1)/(k+1)
+            // of its tasks, which is what the old splits are.
+            {
+                static const int bg = [] { const char* e = getenv("CLIORA_BG"); return e ? atoi(e) : 0; }();
+                if (bg && k >= 2 && k <= L - 1) {
+                    HIPOK(hipEventRecord(plan->ev_level[k], st));
+                    HIPOK(hipStreamWaitEvent(plan->side, plan->ev_level[k], 0));
+                    ComposeSeg ba = ca, bb = cb;
+                    if (bg == 2) { ba.ntask = std::max(1, ba.ntask * (k - 1) / (k + 1)); ba.gx = std::min(ba.gx, ba.ntask); if (bb.gx) { bb.ntask = std::max(1, bb.ntask * (k - 1) / (k + 1)); bb.gx = std::min(bb.gx, bb.ntask); } }
+                    OKR(launch_level_compose2(plan->side, ba, bb, f.S3, Dp, f.ct3, f.ncb3, ws + f.pp, hp_stride, YM, PH));
+                    fork_guard.arm(0, plan->side, plan->ev_join[0]);
+                }
+            }
+#endif
             if (vl && k <= L - 1) {   // cliora.py:140-157: the attention residual between the aggregate and the second unit norm (inside cells only)
                 const LevelArgs g = level_args(p, k, false);
                 ATTEND_LAUNCH(cell_attend_fwd, p.R, dim3(B * g.Lc), st, g, L, HPi, hp_stride, ca.SP, (const float*)nullptr, OBJ, p.R, drop_mask, p.normalize, IH,
