@@ -464,43 +464,6 @@ static int launch_tn_tiles(hipStream_t st, const float* DZt, const float* Xt, lo
     return CLIORA_OK;
 }
 
-// CLIORA_WGRAD_FORM=0 | 1: the pair rows' weight gradient from materialised X / DZ tiles (0) or from tiles formed inside the GEMM (1)
-static bool wgrad_form_on() {
-    static const int v = [] { const char* e = getenv("CLIORA_WGRAD_FORM"); return e ? atoi(e) : 0; }();
-    return v != 0;
-}
-// The same product with the operand tiles formed inside the GEMM from the cell rows (wgrad_tiles.hpp: tn_gemm_form): no X / DZ buffers.
-static int launch_tn_form(hipStream_t st, const FormSrc& fs, long long tile0, long long ntiles, long long tile0b, long long ntilesb,
-                          int Dp, float* slab, size_t slab_floats, float* out, float* colsum_out, int accumulate, int slices_cap) {
-    const int NT = Dp / 16;
-    const long long nt = ntiles + ntilesb;
-    if (nt <= 0) {
-        if (accumulate) return CLIORA_OK;
-        HIPOK(hipMemsetAsync(out, 0, (size_t)Dp * Dp * sizeof(float), st));
-        if (colsum_out) HIPOK(hipMemsetAsync(colsum_out, 0, (size_t)Dp * sizeof(float), st));
-        return CLIORA_OK;
-    }
-    constexpr int NTc = 25, NIT = 7, NJT = 9, NJW = 5, nkb = 3;      // d = 400 (pair_tiles_ok)
-    if (NT != NTc) return fail(CLIORA_EINVAL, "tiled pair-row operands: d = 400 only");
-    const size_t per_slice = (size_t)Dp * Dp + Dp;
-    long long cap = std::min<long long>((long long)(slab_floats / per_slice), slices_cap > 0 ? slices_cap : std::max(1, 230 / (8 * nkb)) * 8);
-    cap = std::max<long long>(2, std::min(cap, (nt + 3) / 4));
-    long long tps = (nt + cap - 1) / cap;
-    tps = (tps + 1) / 2 * 2;                                   // whole stages (two tiles)
-    long long s1 = (ntiles + tps - 1) / tps, s2 = (ntilesb + tps - 1) / tps;
-    while (s1 + s2 > cap) { tps += 2; s1 = (ntiles + tps - 1) / tps; s2 = (ntilesb + tps - 1) / tps; }
-    const int nsl = (int)(s1 + s2);
-    float* csl = slab + (size_t)nsl * Dp * Dp;
-    const size_t lds = (size_t)2 * 2048 * (NT + NJT) + 1024 + 3 * 32 * sizeof(FormRow) + (size_t)(fs.nlev + 1) * 8 * sizeof(int32_t);  // two stage buffers, the spare KiB, three stages of row contexts, the level table
-    OKR(cliora_ensure_max_lds((const void*)tn_gemm_form<NTc, NIT, NJT, NJW, true>));
-    hipLaunchKernelGGL((tn_gemm_form<NTc, NIT, NJT, NJW, true>), dim3(8 * nkb * ((nsl + 7) / 8)), dim3(512), lds, st, fs, tile0, (int)ntiles, (int)tps, nsl, nkb,
-                       slab, csl, (int)s1, tile0b, (int)ntilesb);
-    LAUNCHOK("tn_gemm_form");
-    launch_slab_reduce(st, slab, nsl, (size_t)Dp * Dp, out, accumulate, csl, (size_t)Dp, colsum_out);
-    LAUNCHOK("slab_reduce");
-    return CLIORA_OK;
-}
-
 // accumulate: add to out / colsum_out instead of overwriting; slices_cap > 0: at most that many row slices (= workgroups / nkb)
 // ldz / ldx: row strides of DZ / X when they are Dp-wide column blocks of wider matrices (0: Dp); only where tn_pairs_strided_ok()
 static bool tn_pairs_strided_ok(int Dp) {

@@ -779,21 +779,6 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
     auto gemm3_pays = [&](int ncell) { return bwd_gemm3 > 0 && split_bf16() && ncell >= bwd_gemm3_min; };
     // X / DZ of the pair rows as tiled split-bf16 operands (wgrad_tiles.hpp) instead of fp32 rows.  CLIORA_PAIR_TILES=0: off.
     const bool tiled = pair_tiles_ok(Dp) && !resident;
-    // Round 6: the weight-gradient GEMM forms its operand tiles itself from the cell rows (wgrad_tiles.hpp: tn_gemm_form); level_compose_bwd then
-    // stores neither X nor DZ.  Bitwise the materialised path's gradients.  CLIORA_WGRAD_FORM=0 | 1 (default: see wgrad_form_on).
-    const bool form = tiled && wgrad_form_on();
-    FormSrc fsrc{};
-    if (form) {
-        fsrc.tabs = p.d_tables; fsrc.lev_off = (int)p.dev.tile_levels; fsrc.nlev = p.n_tile_levels;
-        fsrc.PI = PI; fsrc.ldpi = ldpi; fsrc.blk_plo = p.blk_plo; fsrc.PO = ws + f.po;
-        fsrc.dGi = dG; fsrc.dGo = dGo; fsrc.ymask = YM; fsrc.Pp = Pp; fsrc.B = B; fsrc.C = C; fsrc.Dp = Dp;
-    }
-    float* const DZs = form ? nullptr : DZ;      // what level_compose_bwd is handed for its tile stores
-    float* const Xs = form ? nullptr : Xp;
-    auto tn_tiles = [&](hipStream_t s_, long long t0, long long n0, long long t0b, long long n0b, float* slab_, float* out_, float* cs_, int acc_, int cap_) -> int {
-        if (form) return launch_tn_form(s_, fsrc, t0, n0, t0b, n0b, Dp, slab_, bw.slab_floats, out_, cs_, acc_, cap_);
-        return launch_tn_tiles(s_, DZ, Xp, t0, n0, t0b, n0b, Dp, slab_, bw.slab_floats, out_, cs_, acc_, cap_);
-    };
 
     // Sibling uses of inside level s in the outside pass (cell_gather_bwd_sib), on the OUTSIDE chain's stream: they are complete once
     // the outside backward has done level L-2-s, one step before the inside chain reaches level s (which already waits for that
@@ -857,7 +842,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sb);
             OKR(launch_level_compose_bwd(sb, ws + f.w2oT, ws + f.w2oT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, true), dGo, YM, Pp,
-                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZs, Xs, DPP, DPB, tiled));
+                                         PI + (size_t)p.blk_plo * Dp, ldpi, ws + f.po, Dp, ws + f.b2o, DA, DZ, Xp, DPP, DPB, tiled));
         }
         const bool sib_last = sibling_runs(L - 2 - level);
         LAUNCH_SIGNALLING(sib_last ? nullptr : done, cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sb, g, f.ncb3, DPP, DPB, Sp, Pp, OS, dStoto, DS);
@@ -957,7 +942,7 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         {
             ProfScope ps(CLIORA_KCLASS_COMPOSE_BWD, sa);
             OKR(launch_level_compose_bwd(sa, ws + f.w2iT, ws + f.w2iT3, f.S3, Dp, f.ct3, f.ncb3, pair_level(level, false), dG, YM, Pp, PI, ldpi,
-                                         PI + Dp, ldpi, ws + f.b2i, DA, DZs, Xs, DPP, DPB, tiled));
+                                         PI + Dp, ldpi, ws + f.b2i, DA, DZ, Xp, DPP, DPB, tiled));
         }
         hipLaunchKernelGGL(cell_dsoftmax, dim3(cells_grid(ncell)), dim3(256), 0, sa, g, f.ncb3, DPP, DPB, Sp, Pp, IS, dStot, DS);
         LAUNCHOK("cell_dsoftmax(in)");
@@ -1043,7 +1028,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             early_t0 = p.tile_base_in(L - 1 - j);
             early_t1 = p.tile_base_out(j + 1);
             if (tiled)
-                OKR(tn_tiles(sw, early_t0, early_t1 - early_t0, 0, 0, wb + bw.slab2, wb + bw.gw2o, wb + bw.gb2o, 0, early_slices));
+                OKR(launch_tn_tiles(sw, DZ, Xp, early_t0, early_t1 - early_t0, 0, 0, Dp, wb + bw.slab2, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o, 0,
+                                    early_slices));
             else
                 OKR(launch_tn_pairs(sw, DZ + (size_t)early_r0 * Dp, Xp + (size_t)early_r0 * Dp, (int)(early_r1 - early_r0), Dp, wb + bw.slab2, bw.slab_floats,
                                     wb + bw.gw2o, wb + bw.gb2o, 0, early_slices));
@@ -1057,7 +1043,8 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
             HIPOK(hipEventRecord(plan->ev_fork[2], sa));
             HIPOK(hipStreamWaitEvent(sw, plan->ev_fork[2], 0));
             if (two_streams) HIPOK(hipStreamWaitEvent(sw, plan->ev_level[j], 0));
-            OKR(tn_tiles(sw, t0, early_t0 - t0, early_t1, t1 - early_t1, wb + bw.slab2, wb + bw.gw2o, wb + bw.gb2o, 1, early_slices));
+            OKR(launch_tn_tiles(sw, DZ, Xp, t0, early_t0 - t0, early_t1, t1 - early_t1, Dp, wb + bw.slab2, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o, 1,
+                                early_slices));
             early_t0 = t0; early_t1 = t1;
             early_r0 = p.row_base_in(L - 1 - j); early_r1 = p.row_base_out(j + 1);
         }
@@ -1080,13 +1067,14 @@ extern "C" int cliora_chart_backward(cliora_plan* plan, const cliora_params* P, 
         ProfScope ps(CLIORA_KCLASS_WGRAD, s_);
         if (tiled) {
             if (ran_outside && !p.share)
-                OKR(tn_tiles(s_, p.T_in, p.T_out, 0, 0, wb + bw.slab, wb + bw.gw2o, wb + bw.gb2o, 0, 0));
+                OKR(launch_tn_tiles(s_, DZ, Xp, p.T_in, p.T_out, 0, 0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2o, wb + bw.gb2o, 0, 0));
             const long long ntl = (p.share && ran_outside) ? p.T_in + p.T_out : p.T_in;
             static const int tail_slices2 = [] { const char* e = getenv("CLIORA_WGRAD_TAIL_SLICES2"); return e ? atoi(e) : 72; }();
             if (J_early >= 0)
-                OKR(tn_tiles(s_, 0, early_t0, early_t1, ntl - early_t1, wb + bw.slab, wb + bw.gw2i, wb + bw.gb2i, 0, tail_slices2));
+                OKR(launch_tn_tiles(s_, DZ, Xp, 0, early_t0, early_t1, ntl - early_t1, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0,
+                                    tail_slices2));
             else
-                OKR(tn_tiles(s_, 0, ntl, 0, 0, wb + bw.slab, wb + bw.gw2i, wb + bw.gb2i, 0, 0));
+                OKR(launch_tn_tiles(s_, DZ, Xp, 0, ntl, 0, 0, Dp, wb + bw.slab, bw.slab_floats, wb + bw.gw2i, wb + bw.gb2i, 0, 0));
             return CLIORA_OK;
         }
         if (ran_outside && !p.share)

@@ -1198,8 +1198,11 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
             const float4 f0 = masked(q.g0, q.m0 >> (4 * ((2 * st) % CT)));
             const float4 f1 = masked(q.g1, q.m1 >> (4 * ((2 * st + (second ? 1 : 0)) % CT)));
             const int k = 32 * st + 4 * lg;
-            // DZ == nullptr (tiled mode): the weight gradient forms its operands itself (wgrad_tiles.hpp: tn_gemm_form), nothing is stored
-            if (st % gy == by && (!TILED || DZ != nullptr)) {
+#ifdef CLIORA_DIAG_NOXZ      // timing proxy (WRONG weight gradients): no X / DZ tile stores (profiles/r06_notes.md section 4)
+            if (false) {
+#else
+            if (st % gy == by) {
+#endif
                 if (TILED) {
                     uint32_t* zt = reinterpret_cast<uint32_t*>(ctx.zo) + (2 * st) * 256;
                     store_split_tile(zt, make_float4(ctx.pn * f0.x, ctx.pn * f0.y, ctx.pn * f0.z, ctx.pn * f0.w));
@@ -1255,7 +1258,11 @@ __global__ __launch_bounds__(512) void level_compose_bwd(const uint32_t* __restr
                                         x.z > 0.f ? pn * u.z : 0.f, x.w > 0.f ? pn * u.w : 0.f));
                 if (!TILED) st4(X + o, x);
             }
-            if (TILED && X != nullptr)          // the tile's lane slot 8 (row) + 2 (piece) = 2 lane: lane-linear
+#ifndef CLIORA_DIAG_NOXZ
+            if (TILED)          // the tile's lane slot 8 (row) + 2 (piece) = 2 lane: lane-linear
+#else
+            if (false)
+#endif
                 store_split_tile(reinterpret_cast<uint32_t*>(X) + ((size_t)(lv.tilebase + tile) * NT + by * CT + c) * 256 + 2 * lane,
                                  ok ? x : f4zero());
         }

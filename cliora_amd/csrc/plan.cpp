@@ -339,24 +339,6 @@ std::vector<int32_t> flatten_tables(Plan& p) {
     p.dev.lvl_base_in = put(p.lvl_base_in);
     p.dev.lvl_base_out = put(p.lvl_base_out);
     p.dev.level_geom = put(p.level_geom);
-    {   // the levels in the order of their 16-row pair tiles (inside 1 .. L-1, then outside 0 .. L-2): what the weight-gradient GEMM that
-        // forms its operands itself (wgrad_tiles.hpp: tn_gemm_form) needs to go from a tile index to the pair rows' operands.  The last
-        // entry is a sentinel (first tile = the total).  Absolute offsets into this flat array for the pair tables.
-        std::vector<int32_t> tl;
-        auto add = [&](long long first, int N, int Lc, int off, long long rowbase, size_t pa, size_t pb, int pass) {
-            const int32_t e[TLEVEL_INTS] = {(int32_t)first, N, Lc, off, (int32_t)rowbase, (int32_t)pa, (int32_t)pb, pass};
-            tl.insert(tl.end(), e, e + TLEVEL_INTS);
-        };
-        const int L = p.L;
-        for (int lv = 1; lv < L; ++lv)
-            add(p.tile_base_in(lv), lv, L - lv, p.level_offset[lv], p.row_base_in(lv), p.dev.pair_a_in + p.lvl_base_in[lv], p.dev.pair_b_in + p.lvl_base_in[lv], 0);
-        for (int lv = 0; lv + 1 < L; ++lv)
-            add(p.tile_base_out(lv), L - lv - 1, L - lv, p.level_offset[lv], p.row_base_out(lv), p.dev.pair_a_out + p.lvl_base_out[lv],
-                p.dev.pair_b_out + p.lvl_base_out[lv], 1);
-        p.n_tile_levels = (int)(tl.size() / TLEVEL_INTS);
-        add(p.T_in + p.T_out, 0, 1, 0, 0, 0, 0, 0);
-        p.dev.tile_levels = put(tl);
-    }
     if (p.arch == 1) build_row_maps(p);
     p.dev.arow = put(p.arow); p.dev.brow = put(p.brow); p.dev.trow = put(p.trow);
     if (flat.empty()) flat.push_back(0);

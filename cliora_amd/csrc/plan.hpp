@@ -21,7 +21,6 @@ constexpr int ROLE_OUTB = 3;  // outside cell used as PARENT in the outside pass
 constexpr int N_ROLES = 4;
 constexpr int HP_PARTS = 4;        // a cell's split range is cut into at most this many parts (level_compose_fwd tasks)
 constexpr int CLIORA_MAX_L = 64;   // sentence length bound: one split per lane in the score kernels
-constexpr int TLEVEL_INTS = 8;     // ints per entry of the device table tile_levels: {first tile, N, Lc, chart offset, pair-row base, pair_a offset, pair_b offset, pass}
 constexpr int PLEVEL_INTS = 8;     // ints per entry of Plan::level_geom {Lc, N, level offset, pair-row base, pair-table base, TG, SP, ntask}
 
 struct UseList {
@@ -112,8 +111,7 @@ struct Plan {
     // device copies (filled lazily by the HIP side)
     int32_t* d_tables = nullptr;
     size_t d_tables_count = 0;
-    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out, level_geom, tile_levels; } dev;
-    int n_tile_levels = 0;     // entries of the device table `tile_levels` (flatten_tables)
+    struct DevOff { size_t pair_a_in, pair_b_in, pair_a_out, pair_b_out; size_t use_off[N_ROLES], use_row[N_ROLES], use_stride[N_ROLES], use_partner[N_ROLES]; size_t arow, brow, trow, lvl_base_in, lvl_base_out, level_geom; } dev;
 
     int Lc(int level) const { return L - level; }
     int Nin(int level) const { return level; }

@@ -203,326 +203,4 @@ static __global__ __launch_bounds__(512) void tn_gemm_tiles(const uint32_t* __re
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// tn_gemm_form (round 6): the same GEMM with its operand tiles FORMED HERE instead of read back from HBM.
-//
-// level_compose_bwd wrote X = relu(PL(a) + PR(b)) and DZ = p_n (dG[t] masked by the ReLU bits of y_n) for every pair row as split-bf16
-// tiles (2 x 1.6 kB per pair row, 0.8 GB per c2 step, non-temporal) only for this kernel to read them once; a no-store build of that kernel
-// runs the c2 step 3.9 % and L 40 6.6 % faster (profiles/r06_noxz_proxy.txt).  Both operands are functions of CELL rows that sit in L2 /
-// the Infinity Cache (the chart's projections and dG: 64 + 21 MB at c2) plus 80 B of bits and one weight per pair row, so a stage's
-// tiles are built in LDS, in exactly the image the LDS-DMA used to deliver: per (tile h of the stage, 16-column tile c, row, 4-column
-// group q) one thread loads PL(a) + PR(b) (X) or dG + bits + p_n (DZ), forms the value the compose backward formed, splits it and stores
-// 8 bytes into each plane.  Same values, same tiles, same stage and MFMA order: the slab is bitwise tn_gemm_tiles' on materialised tiles.
-// The two waves of a SIMD (w and w + 4) run the two phases of a stage in opposite orders -- waves 0-3 the MFMAs of stage st then the
-// forming of stage st + 1, waves 4-7 the forming first -- so that one wave's loads and conversions sit under its partner's MFMAs; the
-// forming's registers are dead before the MFMA phase's operands are live.  A tile's level is found by a cursor over the plan's
-// tile_levels table (one thread per tile of the next stage, published through LDS before the stage barrier).
-// ---------------------------------------------------------------------------------------------------------------------------
-#ifndef CLIORA_FORM_ORDER
-#define CLIORA_FORM_ORDER 1
-#endif
-struct FormSrc {
-    const int32_t* tabs;            // the plan's device tables
-    int lev_off, nlev;              // tile_levels: offset in ints, entries (a sentinel entry follows)
-    const float* PI; int ldpi;      // inside-cell projections [PL | PR | QL (| PLo | QLo)]
-    int blk_plo;                    // which block the outside pass reads as the sibling's PL
-    const float* PO;                // outside-cell projections PRo (row stride Dp)
-    const float* dGi; const float* dGo;   // d loss / d aggregate per chart row, inside / outside chart
-    const uint32_t* ymask;          // ReLU bits of y: (R, 5, 4) words
-    const float* Pp;                // softmax weights per pair row
-    int B, C, Dp;
-};
-// What forming needs to know about ONE row of a stage (tile h, row r), prepared two stages ahead by thread 16 h + r and kept in LDS:
-// the row's dG and operand-projection pointers, its weight (0 for a row past the level's last cell: the tile's zero rows) and its ReLU bits.
-struct FormRow {
-    const float* dg;        // dG row of the target cell
-    const float* xa;        // PL row of the pair's a operand
-    const float* xb;        // PR row of its b operand
-    float pn;               // p_n, 0 when the row is past the last cell
-    int live;               // 0: no such tile (an odd tile count) -- nothing is formed for the row
-    uint32_t bits[20];      // (5 column blocks x 4 words) ReLU bits of y_n
-};
-constexpr int FORM_ROW_DW = sizeof(FormRow) / 4;     // 28 dwords
-
-template <int NT, int NIT, int NJT, int NJW, bool COLSUM>
-static __global__ __launch_bounds__(512) void tn_gemm_form(FormSrc fs, long long tile0, int ntiles, int tiles_per_slice, int nslices, int nkb,
-                                                           float* __restrict__ slab, float* __restrict__ colsum,
-                                                           int slice2, long long tile0b, int ntilesb) {
-    static_assert(2 * NJW > NJT, "the second half of the j-tiles needs a spare slot for the ones-tile");
-    static_assert(4 * NIT >= NT && NT <= 27, "four i-groups of at most NIT tiles");
-    static_assert(NT == 25, "the ReLU bits are kept as 5 column blocks of five 16-column tiles");
-    extern __shared__ __attribute__((aligned(1024))) uint32_t lds_q[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int iw = wave & 3, jw = wave >> 2;
-    const int i = lane & 15, g = lane >> 4;
-    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
-    const int kb = wq % nkb, slice = (wq / nkb) * 8 + xcd;
-    if (slice >= nslices) return;
-    constexpr int Mi = NT * 16, Nj = Mi;
-    const int jbase = NT / nkb, jrem = NT % nkb;
-    const int jt0 = kb * jbase + min(kb, jrem);
-    const int njt = jbase + (kb < jrem ? 1 : 0);
-    const int ju0 = jw * NJW;
-    const int njw = max(0, min(njt - ju0, NJW));
-    constexpr int ibase = NT / 4, irem = NT % 4;
-    const int it0 = iw * ibase + min(iw, irem);
-    const int nit = ibase + (iw < irem ? 1 : 0);
-    constexpr int xpart = 512 * NT, bufdw = 512 * (NT + NJT);
-    // behind the two stage buffers and the spare KiB: the row contexts of three stages, [3][32] FormRow
-    FormRow* srow = reinterpret_cast<FormRow*>(lds_q + 2 * bufdw + 256);
-
-    const bool second = slice >= slice2;
-    const long long tfirst = second ? tile0b : tile0;
-    const int tcount = second ? ntilesb : ntiles;
-    const int tbeg = (second ? slice - slice2 : slice) * tiles_per_slice;
-    const int tend = min(tcount, tbeg + tiles_per_slice);
-    const int nstages = tend > tbeg ? (tend - tbeg + 1) / 2 : 0;
-    if (nstages == 0) {                 // nothing to add: the slab slice must still hold zeros
-        float* out0 = slab + (size_t)slice * Mi * Nj;
-        for (int t = 0; t < NIT; ++t)
-            if (t < nit)
-                for (int u = 0; u < NJW; ++u)
-                    if (u < njw)
-                        for (int reg = 0; reg < 4; ++reg) out0[(size_t)((it0 + t) * 16 + g * 4 + reg) * Nj + (jt0 + ju0 + u) * 16 + i] = 0.f;
-        if (COLSUM && kb == 0 && jw == 1 && i == 0)
-            for (int t = 0; t < NIT; ++t)
-                if (t < nit)
-                    for (int reg = 0; reg < 4; ++reg) colsum[(size_t)slice * Mi + (it0 + t) * 16 + g * 4 + reg] = 0.f;
-        return;
-    }
-
-    f32x4 acc[NIT][NJW];
-#pragma unroll
-    for (int a = 0; a < NIT; ++a)
-#pragma unroll
-        for (int b = 0; b < NJW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool ones_here = COLSUM && kb == 0 && jw == 1;
-
-    // ---- row contexts: thread 16 h + r (< 32) owns row r of tile h of every stage; its cursor over the level table only moves forward.
-    // prep_issue(stage) starts the row's loads (weight, operand cells, bits), prep_commit writes the context -- two stages ahead of the
-    // forming that reads it, with a whole stage between issue and commit.
-    const int32_t* lev = fs.tabs + fs.lev_off;
-    int cursor = 0, cursor_r = 0;
-    const int ptid = tid - 256;           // the preparing threads sit in waves 4-6 (forming first, MFMAs second): what they prefetch lives across the forming only
-    const bool prow_t = ptid >= 0 && ptid < 32, pbit_t = ptid >= 0 && ptid < 160;
-    // the tile-level table in LDS (behind the row contexts): a tile's level is a cursor walk over it, no global round trip
-    int32_t* slev = reinterpret_cast<int32_t*>(srow + 3 * 32);
-    for (int k = tid; k < (fs.nlev + 1) * 8; k += 512) slev[k] = lev[k];
-    // the scalar part of a row's context: thread 256 + 16 h + r.  issue: the row's loads (operand cells, weight); commit: the context
-    struct PrepRow { int live, ca, cb, pass; float pn; size_t base; int offp; };
-    PrepRow pr{};
-    auto prep_row_issue = [&](int stage) {
-        const int h = ptid >> 4, row = ptid & 15;
-        pr.live = 0;
-        if (stage >= nstages || tbeg + 2 * stage + h >= tend) return;
-        const long long T = tfirst + tbeg + 2 * stage + h;
-        while (cursor_r + 1 < fs.nlev && (long long)slev[(cursor_r + 1) * 8] <= T) ++cursor_r;
-        const int32_t* e = slev + cursor_r * 8;
-        const int N = e[1], Lc = e[2], off = e[3];
-        const int rel = (int)(T - e[0]);
-        const int gt = rel / N, n = rel - gt * N;
-        const int ncell = fs.B * Lc;
-        const int t = gt * 16 + row;
-        const int tc = min(t, ncell - 1);
-        const int b = tc / Lc, p = tc - b * Lc;
-        const size_t prow = (size_t)e[4] + (size_t)tc * N + n;
-        const int idx = p * N + n;
-        pr.ca = fs.tabs[e[5] + idx]; pr.cb = fs.tabs[e[6] + idx];
-        pr.pn = t < ncell ? fs.Pp[prow] : 0.f;
-        pr.live = t < ncell ? 1 : 2;                     // 2: a zero row (X is zero as well)
-        pr.pass = e[7]; pr.base = (size_t)b * fs.C; pr.offp = off + p;
-    };
-    auto prep_row_commit = [&](int stage) {
-        FormRow* o = srow + (stage % 3) * 32 + ptid;
-        o->live = pr.live;
-        if (!pr.live) {                 // no such tile: pointers that can be loaded from (the forming's loads are unconditional), weight 0
-            o->pn = 0.f; o->dg = fs.dGi; o->xa = fs.PI; o->xb = fs.PI;
-            return;
-        }
-        const bool pass = pr.pass != 0;
-        o->pn = pr.pn;
-        o->dg = (pass ? fs.dGo : fs.dGi) + (pr.base + pr.offp) * fs.Dp;
-        o->xa = (pass ? fs.PI + (size_t)fs.blk_plo * fs.Dp : fs.PI) + (pr.base + pr.ca) * fs.ldpi;
-        o->xb = pass ? fs.PO + (pr.base + pr.cb) * fs.Dp : fs.PI + fs.Dp + (pr.base + pr.cb) * fs.ldpi;
-    };
-    // the ReLU bits of a row (80 bytes): thread 256 + 5 (16 h + r) + k copies piece k
-    u32x4 pbits = u32x4{0u, 0u, 0u, 0u};
-    auto prep_bits_issue = [&](int stage) {
-        const int r32 = ptid / 5, k = ptid - r32 * 5;
-        const int h = r32 >> 4, row = r32 & 15;
-        if (stage >= nstages || tbeg + 2 * stage + h >= tend) return;
-        const long long T = tfirst + tbeg + 2 * stage + h;
-        while (cursor + 1 < fs.nlev && (long long)slev[(cursor + 1) * 8] <= T) ++cursor;
-        const int32_t* e = slev + cursor * 8;
-        const int N = e[1], Lc = e[2];
-        const int rel = (int)(T - e[0]);
-        const int gt = rel / N, n = rel - gt * N;
-        const int tc = min(gt * 16 + row, fs.B * Lc - 1);
-        const size_t prow = (size_t)e[4] + (size_t)tc * N + n;
-        pbits = reinterpret_cast<const u32x4*>(fs.ymask + prow * 20)[k];
-    };
-    auto prep_bits_commit = [&](int stage) {
-        const int r32 = ptid / 5, k = ptid - r32 * 5;
-        *reinterpret_cast<u32x4*>(srow[(stage % 3) * 32 + r32].bits + 4 * k) = pbits;
-    };
-
-    // ---- forming a stage.  An item = (tile h of the stage, 16-column tile c, row, 4-column group q) = one float4 of an operand:
-    // 2 x NT x 64 DZ items, 2 x njt x 64 X items, dealt tid + 512 j.  Every load of the thread's items is issued before anything is
-    // converted (one round trip per stage).
-    constexpr int NZI = (2 * NT * 64 + 511) / 512, NXI = (2 * NJT * 64 + 511) / 512;
-    auto put = [&](uint32_t* dst, const float4 v) {
-        const uint32_t h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
-        const uint32_t l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
-        const uint32_t l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
-        typedef uint32_t v2u_ __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<v2u_*>(dst) = v2u_{h0, h1};
-        *reinterpret_cast<v2u_*>(dst + 128) = v2u_{l0, l1};
-    };
-    // Item e = tid + 512 j has q = tid & 3 and row = (tid >> 2) & 15 for EVERY j -- a thread always works on the same row and column group --
-    // and its (tile, column tile) index hc = wave + 8 j is wave-uniform: the row's two contexts (tile 0 / tile 1 of the stage) are read once
-    // per stage, the per-item offsets are scalar arithmetic.
-    const int fq = tid & 3, frow = (tid >> 2) & 15;
-    auto form = [&](int stage) {
-        uint32_t* buf = lds_q + (stage & 1) * bufdw;
-        const FormRow* r0 = srow + (stage % 3) * 32 + frow;
-        const FormRow* r1 = r0 + 16;
-        const int live0 = r0->live, live1 = r1->live;
-        const float* dg0 = r0->dg; const float* dg1 = r1->dg;
-        const float pn0 = r0->pn, pn1 = r1->pn;
-        float4 g4[NZI], a4[NXI], b4[NXI];
-        const int lo = frow * 8 + 2 * fq;            // the item's dword offset inside a tile plane
-#pragma unroll
-        for (int j = 0; j < NZI; ++j) {
-            const int hc = wave + 8 * j;             // wave-uniform
-            g4[j] = f4zero();
-            if (hc < 2 * NT) {
-                const int hh = hc >= NT ? 1 : 0, cc = hc - hh * NT;
-#ifndef CLIORA_DIAG_FORM_NOLOAD
-                g4[j] = ld4((hh ? dg1 : dg0) + cc * 16 + 4 * fq);       // unconditional (a dead row's context points at loadable rows): no branch between the loads
-#endif
-            }
-        }
-        {
-            const float* xa0 = r0->xa; const float* xa1 = r1->xa;
-            const float* xb0 = r0->xb; const float* xb1 = r1->xb;
-#pragma unroll
-            for (int j = 0; j < NXI; ++j) {
-                const int hc = wave + 8 * j;
-                a4[j] = f4zero(); b4[j] = f4zero();
-                if (hc < 2 * njt) {
-                    const int hh = hc >= njt ? 1 : 0, cc = hc - hh * njt;
-                    const int col = (jt0 + cc) * 16 + 4 * fq;
-#ifndef CLIORA_DIAG_FORM_NOLOAD
-                    a4[j] = ld4((hh ? xa1 : xa0) + col); b4[j] = ld4((hh ? xb1 : xb0) + col);
-#endif
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NZI; ++j) {
-            const int hc = wave + 8 * j;
-            if (hc >= 2 * NT) continue;
-            const int hh = hc >= NT ? 1 : 0, cc = hc - hh * NT;
-            if (!(hh ? live1 : live0)) continue;
-            const uint32_t nib = (hh ? r1 : r0)->bits[(cc / 5) * 4 + fq] >> (4 * (cc % 5));
-            const float pn = hh ? pn1 : pn0;
-            const float4 m = make_float4((nib & 1u) ? g4[j].x : 0.f, (nib & 2u) ? g4[j].y : 0.f, (nib & 4u) ? g4[j].z : 0.f, (nib & 8u) ? g4[j].w : 0.f);
-            put(buf + (hh * NT + cc) * 256 + lo, make_float4(pn * m.x, pn * m.y, pn * m.z, pn * m.w));
-        }
-#pragma unroll
-        for (int j = 0; j < NXI; ++j) {
-            const int hc = wave + 8 * j;
-            if (hc >= 2 * njt) continue;
-            const int hh = hc >= njt ? 1 : 0, cc = hc - hh * njt;
-            if (!(hh ? live1 : live0)) continue;
-            const bool zero = (hh ? live1 : live0) == 2;     // a row past the level's last cell
-            put(buf + xpart + (hh * NJT + cc) * 256 + lo,
-                zero ? f4zero() : make_float4(fmaxf(a4[j].x + b4[j].x, 0.f), fmaxf(a4[j].y + b4[j].y, 0.f), fmaxf(a4[j].z + b4[j].z, 0.f), fmaxf(a4[j].w + b4[j].w, 0.f)));
-        }
-    };
-
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)lds_q;
-    const uint32_t lane_b = (uint32_t)((4 * g + (i >> 2)) * 32 + 8 * (i & 3));
-    const uint32_t a_addr0 = lds0 + lane_b + (uint32_t)it0 * 1024u;
-    const uint32_t b_addr0 = lds0 + lane_b + (uint32_t)(xpart * 4) + (uint32_t)ju0 * 1024u;
-
-    auto mfma_phase = [&](int st) {
-        const bool h1 = tbeg + 2 * st + 1 < tend;
-        const uint32_t a_addr = a_addr0 + (uint32_t)((st & 1) * bufdw * 4), b_addr = b_addr0 + (uint32_t)((st & 1) * bufdw * 4);
-        TrOperand rb[NJW], ra[2];
-#pragma unroll
-        for (int u = 0; u < NJW; ++u) rb[u] = lds_tr_operand(b_addr + (uint32_t)u * 1024u, NJT * 1024u);
-        ra[0] = lds_tr_operand(a_addr, NT * 1024u);
-        u32x4 bh[NJW], bl[NJW];
-#pragma unroll
-        for (int u = 0; u < NJW; ++u) { lgkm_wait(rb[u]); tr_finish(rb[u], h1, bh[u], bl[u]); }
-        if (ones_here) {
-            bh[NJW - 1] = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-            bl[NJW - 1] = u32x4{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            u32x4 ah, al;
-            lgkm_wait(ra[t & 1]);
-            tr_finish(ra[t & 1], h1, ah, al);
-            if (t + 1 < NIT) ra[(t + 1) & 1] = lds_tr_operand(a_addr + (uint32_t)(t + 1) * 1024u, NT * 1024u);
-#pragma unroll
-            for (int u = 0; u < NJW; ++u) acc[t][u] = mfma32bf(al, bh[u], acc[t][u]);
-#pragma unroll
-            for (int u = 0; u < NJW; ++u) acc[t][u] = mfma32bf(ah, bl[u], acc[t][u]);
-#pragma unroll
-            for (int u = 0; u < NJW; ++u) acc[t][u] = mfma32bf(ah, bh[u], acc[t][u]);
-        }
-    };
-
-    // prologue: the row contexts of stages 0 and 1, the tiles of stage 0
-    __syncthreads();                     // the level table
-    if (prow_t) { prep_row_issue(0); prep_row_commit(0); prep_row_issue(1); prep_row_commit(1); }
-    if (pbit_t) { prep_bits_issue(0); prep_bits_commit(0); prep_bits_issue(1); prep_bits_commit(1); }
-    __syncthreads();
-    form(0);
-    for (int st = 0; st < nstages; ++st) {
-        const bool more = st + 1 < nstages;
-        __syncthreads();                 // stage st is formed by every wave, the rows of st + 1 are in LDS, buffer (st + 1) & 1 is free
-        if (prow_t) prep_row_issue(st + 2);      // (waves 4-6) the loads of the rows two stages ahead, committed behind this stage's forming
-        if (pbit_t) prep_bits_issue(st + 2);
-        // waves 0-3: MFMAs first; their SIMD partners 4-7: forming first.  One copy of each phase in the code (two half-steps, not
-        // unrolled): with the two orders written out the compiler spilled 247 registers
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-#ifdef CLIORA_DIAG_FORM_NOMFMA
-            if (half == jw) {}
-#else
-            if (half == jw) mfma_phase(st);
-#endif
-#ifndef CLIORA_DIAG_NOFORM
-            else if (more) form(st + 1);
-#endif
-            if (half == 0) {             // (waves 4-6, after their forming) the rows of stage st + 2: read behind the next barrier
-                if (prow_t) prep_row_commit(st + 2);
-                if (pbit_t) prep_bits_commit(st + 2);
-            }
-        }
-    }
-    float* out = slab + (size_t)slice * Mi * Nj;
-#pragma unroll
-    for (int t = 0; t < NIT; ++t)
-        if (t < nit)
-#pragma unroll
-            for (int u = 0; u < NJW; ++u)
-                if (u < njw)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        out[(size_t)((it0 + t) * 16 + g * 4 + reg) * Nj + (jt0 + ju0 + u) * 16 + i] = acc[t][u][reg];
-    if (ones_here && i == 0) {
-#pragma unroll
-        for (int t = 0; t < NIT; ++t)
-            if (t < nit)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) colsum[(size_t)slice * Mi + (it0 + t) * 16 + g * 4 + reg] = acc[t][NJW - 1][reg];
-    }
-}
-
 }  // namespace cliora
