@@ -278,6 +278,7 @@ class Trainer(object):
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.reducer = reducer                               # cliora_amd.parallel.FlatGradAllReduce or None
         self.defer_table_grads = True
+        self._loss_host, self._loss_ev, self._loss_pending = None, None, False      # pinned scalar + event of the per-step loss read (step(sync=True))
         self.fused = _native(*self.params)                   # clip + Adam as three launches over one flat buffer (heads.FusedClipAdam)
         if self.fused:
             self.optimizer = heads.FusedClipAdam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0, reducer=reducer)
@@ -292,6 +293,20 @@ class Trainer(object):
         with torch.set_grad_enabled(train):
             out = self.net(batch_map['sentences'], batch_map.get('obj_feats'), batch_map.get('neg_samples'), compute_loss)
         total = out.total() if isinstance(out, LossDict) else out['total_loss'].mean(dim=0).sum()
+        # sync=True returns the loss as a Python float like the reference's `.item()` (trainer.py:463).  Its value is final once the FORWARD is:
+        # it is copied to pinned host memory here, behind the forward, and read at the end of the step by waiting for THAT copy only -- the
+        # host then goes on to enqueue the next step while this one's backward and update still run, instead of waiting for them too.
+        loss_ev = None
+        if sync and total.is_cuda:
+            if self._loss_host is None:
+                self._loss_host = torch.empty((), dtype=torch.float32, pin_memory=True)
+                self._loss_ev = torch.cuda.Event()
+            if self._loss_pending:                        # the previous step's copy into the same pinned scalar (already waited for by its step)
+                self._loss_ev.synchronize()
+            self._loss_host.copy_(total.detach(), non_blocking=True)
+            self._loss_ev.record(torch.cuda.current_stream(total.device))
+            self._loss_pending = True
+            loss_ev = self._loss_ev
         if train:
             self.optimizer.zero_grad()
             # this step owns its gradients from backward to the update, so the embedding table's gradient is assembled once, in the flat
@@ -315,4 +330,8 @@ class Trainer(object):
             else:
                 torch.nn.utils.clip_grad_norm_(self.params, 5.0)
                 self.optimizer.step()
+        if loss_ev is not None:
+            loss_ev.synchronize()
+            self._loss_pending = False
+            return {'total_loss': float(self._loss_host)}
         return {'total_loss': float(total.detach()) if sync else total.detach()}
