@@ -373,7 +373,7 @@ def other_measurements(torch, dev, budget_steps=12):
                     note='spans: the device-built constituent span lists, one D2H copy (cliora_cky_spans); trees: nested tuples built from them on the host; '
                          'sentences_per_s = the trees variant (what rounds 1-4 reported under this key; round 5 reported the spans variant)')
 
-    def whole(vl, B=64, L=20, D=400, V=10000, E=1024, K=100, steps=budget_steps, warmup=3):
+    def whole(vl, B=64, L=20, D=400, V=10000, E=1024, K=100, steps=30, warmup=8):
         from cliora_amd import harness as H
         torch.manual_seed(1234)
         net = H.build_net(D, torch.nn.Embedding(V, E), obj_feats=vl, img_dim=2048, k_neg=K, vg_loss=vl, use_contr=vl).to(dev)
