@@ -516,6 +516,9 @@ def main():
                     help='take the N > 1 launch route at any N (also --gpus 1): this process starts torch.distributed.run as a child, the rank '
                          'initialises the process group and runs the gradient all-reduce -- the exact path `--gpus 8` takes, testable on one GPU')
     ap.add_argument('--launched', action='store_true', help=argparse.SUPPRESS)      # set by launch_ranks() on the ranks it starts
+    ap.add_argument('--share-device', action='store_true',
+                    help='self-test of the N > 1 path on a box with ONE GPU: every rank uses cuda:0 (use with --backend gloo: RCCL refuses two ranks on '
+                         'one device); the value is not a scaling figure')
     args = ap.parse_args()
 
     if (args.gpus > 1 or args.via_launcher) and 'WORLD_SIZE' not in os.environ:
@@ -533,7 +536,7 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if args.share_device else int(os.environ.get('LOCAL_RANK', '0'))
     use_dist = world > 1 or args.force_dist or args.launched
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -747,9 +750,10 @@ def main():
                        'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU',
                        'ranks_seen': ranks['ranks_seen'], 'world_size': world, 'via_launcher': bool(args.launched),
                        'per_rank_ms_per_step': ranks['per_rank_ms_per_step'],
-                       **({'gradient_exchange': 'RCCL all-reduce (backend %s) of one flat fp32 buffer of %d floats per step; %d of %d gradients copied in '
+                       **({'share_device': 'every rank on cuda:0 (self-test of the N > 1 path on one GPU: NOT a scaling figure)'} if args.share_device else {}),
+                       **({'gradient_exchange': '%s all-reduce (backend %s) of one flat fp32 buffer of %d floats per step; %d of %d gradients copied in '
                                                 '(the chart backward writes the rest in place)'
-                                                % (args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
+                                                % ('RCCL' if args.backend == 'nccl' else args.backend, args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
             'step_ms': dict(median=round(pct(step_ms, 0.5), 4), p10=round(pct(step_ms, 0.1), 4), p90=round(pct(step_ms, 0.9), 4),
                             note='per-step device time from HIP event pairs on the launch stream inside the timed region (rank 0)'),
             'roofline': roof,

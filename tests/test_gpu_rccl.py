@@ -67,3 +67,25 @@ def test_bench_via_launcher_takes_the_n_gpu_route_on_one_gpu():
     assert c['via_launcher'] is True and c['ranks_seen'] == c['world_size'] == 1, c
     assert c['per_rank_ms_per_step']['min'] > 0 and c['per_rank_ms_per_step']['max'] >= c['per_rank_ms_per_step']['min']
     assert c.get('gradient_exchange', '').startswith('RCCL'), c
+
+
+def test_bench_two_ranks_on_one_gpu_through_the_launcher():
+    """World size 2 on real kernels without a second GPU: `bench.py --gpus 2 --share-device --backend gloo` -- launch_ranks() starts two ranks
+    (torch.distributed.run), both on cuda:0, each with its own 64 sentences, the flat gradient buffer all-reduced through gloo (RCCL refuses
+    two ranks on one device).  Not a scaling figure: the point is that the N > 1 route -- rank-seeded batches, FlatGradAllReduce on gradients
+    the chart backward wrote in place, barrier + max-over-ranks timing, one JSON line from rank 0 -- runs on the GPU with N = 2
+    (batch_iterator.py:134-136, trainer.py:572-574)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(MASTER_PORT='29539', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-device', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
+           '--no-extras', '--no-cpu-baseline', '--no-kernel-events']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])          # rank 0 only
+    d = json.loads(lines[-1])
+    c = d['config']
+    assert d['n_gpus'] == 2 and c['global_batch'] == 128 and d['value'] > 0
+    assert c['ranks_seen'] == c['world_size'] == 2 and c['via_launcher'] is True, c
+    assert len(c['per_rank_ms_per_step']['all']) == 2 and 'share_device' in c
+    assert c['gradient_exchange'].startswith('gloo') and '; 0 of ' in c['gradient_exchange'], c
