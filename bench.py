@@ -469,9 +469,10 @@ def cliora_training_workload(args, torch, dist, _lib, dev, world, rank, local, u
                        'parallelism': 'dp%d (one flat-gradient all-reduce per step)' % world if world > 1 else 'single GPU',
                        'ranks_seen': ranks['ranks_seen'], 'world_size': world, 'via_launcher': bool(args.launched),
                        'per_rank_ms_per_step': ranks['per_rank_ms_per_step'],
-                       **({'gradient_exchange': 'RCCL all-reduce (backend %s) of one flat fp32 buffer of %d floats per step (chart + heads + ImageEncoder); '
+                       **({'share_device': 'every rank on cuda:0 (self-test of the N > 1 path on one GPU: NOT a scaling figure)'} if args.share_device else {}),
+                       **({'gradient_exchange': '%s all-reduce (backend %s) of one flat fp32 buffer of %d floats per step (chart + heads + ImageEncoder); '
                                                 '%d of %d gradients copied in (the chart backward writes the rest in place)'
-                                                % (args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
+                                                % ('RCCL' if args.backend == 'nccl' else args.backend, args.backend, reducer.flat.numel(), reducer.copied, len(reducer.params))} if use_dist else {})},
             'step_ms': dict(median=round(pct(step_ms, 0.5), 4), p10=round(pct(step_ms, 0.1), 4), p90=round(pct(step_ms, 0.9), 4),
                             note='per-step device time from HIP event pairs on the launch stream inside the timed region (rank 0)'),
             'roofline': dict(bound='hbm', kernel='whole step (no single dominant kernel is timed for this workload; see --workload c2)',

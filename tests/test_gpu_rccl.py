@@ -69,7 +69,8 @@ def test_bench_via_launcher_takes_the_n_gpu_route_on_one_gpu():
     assert c.get('gradient_exchange', '').startswith('RCCL'), c
 
 
-def test_bench_two_ranks_on_one_gpu_through_the_launcher():
+@pytest.mark.parametrize('workload', ['c2', 'c3'])
+def test_bench_two_ranks_on_one_gpu_through_the_launcher(workload):
     """World size 2 on real kernels without a second GPU: `bench.py --gpus 2 --share-device --backend gloo` -- launch_ranks() starts two ranks
     (torch.distributed.run), both on cuda:0, each with its own 64 sentences, the flat gradient buffer all-reduced through gloo (RCCL refuses
     two ranks on one device).  Not a scaling figure: the point is that the N > 1 route -- rank-seeded batches, FlatGradAllReduce on gradients
@@ -77,8 +78,10 @@ def test_bench_two_ranks_on_one_gpu_through_the_launcher():
     (batch_iterator.py:134-136, trainer.py:572-574)."""
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env.update(MASTER_PORT='29539', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # c3: the CLIORA training step of configs[3] (word branch on the caller lane, deferred table gradient, flat buffer over chart + heads)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-device', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
-           '--no-extras', '--no-cpu-baseline', '--no-kernel-events']
+           '--workload', workload, '--no-extras', '--no-cpu-baseline', '--no-kernel-events']
+    env['MASTER_PORT'] = '29539' if workload == 'c2' else '29540'
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
